@@ -1,0 +1,168 @@
+/*
+ * recmv_hip.h — C ABI of librecmv_hip.so, the MI355X (gfx950) implementation of the
+ * REC-MV per-frame implicit-surface optimisation hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one function of the reference's
+ * pybind11/CUDA extensions (FastMinv, MCGpu, GridSamplerMine, interp2x_boundary3d) or one dense
+ * contraction that the reference leaves to torch/cuBLAS inside its nn.Modules.  Plain pointers and
+ * sizes only — no torch types.  All pointers are DEVICE pointers unless the name says `host`.
+ * `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Every function
+ * returns RECMV_OK (0) or a negative RECMV_ERR_* code; recmv_last_error() gives a message for the
+ * calling thread.  The library never allocates caller-visible memory; marching cubes is two-phase
+ * (count -> caller allocates -> emit) and keeps a caller-provided workspace.
+ *
+ * Reference citations are relative to the REC-MV tree.
+ */
+#ifndef RECMV_HIP_H_
+#define RECMV_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RECMV_OK               0
+#define RECMV_ERR_ARG         -1   /* bad argument (NULL pointer, negative size, unsupported mode) */
+#define RECMV_ERR_HIP         -2   /* a HIP runtime call or kernel launch failed                  */
+#define RECMV_ERR_UNSUPPORTED -3   /* combination not implemented (e.g. dtype)                    */
+#define RECMV_ERR_WORKSPACE   -4   /* caller workspace too small                                  */
+
+#define RECMV_F32 0
+#define RECMV_F64 1
+
+/* ABI version, bumped on any signature change. */
+int recmv_abi_version(void);
+/* Message of the last error on this thread ("" if none). */
+const char* recmv_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * A. FastMinv — batched 3x3 inverse.
+ *   replaces Fast3x3Minv            (FastMinv/M3x3Inv.cpp:12-36, kernel Matrix3x3InvKernels.cu:22-61)
+ *            Fast3x3Minv_backward   (FastMinv/M3x3Inv.cpp:38-59, kernel Matrix3x3InvKernels.cu:64-104)
+ * ms/invs/grads/outs: [n,3,3] contiguous, dtype f32|f64.  checks: [n] bytes (0/1) == torch.bool.
+ * Singular rule: fabs(det) < 1e-4 (absolute) -> inverse = 0, check = 0.
+ * ---------------------------------------------------------------------------------------------- */
+int recmv_inv3x3_forward(const void* ms, void* invs, uint8_t* checks, int64_t n, int dtype, void* stream);
+int recmv_inv3x3_backward(const void* grads, const void* invs, void* outs, int64_t n, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * C. GridSamplerMine — 3-D trilinear sampler, padding=border, align_corners=False, with first and
+ * second derivative.
+ *   replaces GridSamplerMine.forward / backward / dbackward
+ *            (MCAcc/cuda/GridSamplerMine.cpp:73-96; kernels GridSamplerMineKernel.cu:162-328,
+ *             333-570, 575-914).
+ * Tensors are described by sizes/strides in ELEMENTS (like the reference's TensorInfo), so any
+ * strided layout is accepted.  input: [N,C,D,H,W]; grid: [N,Do,Ho,Wo,3]; output/grad_output:
+ * [N,C,Do,Ho,Wo].  A channels-last input (stride[1]==1) with contiguous grid takes the vectorised
+ * fast path.  interp must be 0 (bilinear) and pad 1 (border), as in the reference's check()
+ * (GridSamplerMine.cpp:58-63) — anything else returns RECMV_ERR_UNSUPPORTED.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct recmv_tensor5 {
+  int64_t size[5];
+  int64_t stride[5];
+} recmv_tensor5;
+
+int recmv_grid_sample3d_forward(const void* input, const recmv_tensor5* input_desc,
+                                const void* grid, const recmv_tensor5* grid_desc,
+                                void* output, const recmv_tensor5* output_desc,
+                                int interp, int pad, int dtype, void* stream);
+
+/* grad_input may be NULL: the scatter into the (frozen) volume is skipped — the hot path's volume
+ * is a registered buffer, never a parameter (model/Deformer.py:240-243).  When non-NULL it must be
+ * zero-filled by the caller (the reference zero-fills it itself: GridSamplerMineKernel.cu:955).
+ * grad_grid: [N,Do,Ho,Wo,3] contiguous (the reference assumes this too: ...Kernel.cu:538-545). */
+int recmv_grid_sample3d_backward(const void* input, const recmv_tensor5* input_desc,
+                                 const void* grid, const recmv_tensor5* grid_desc,
+                                 const void* grad_output, const recmv_tensor5* grad_output_desc,
+                                 void* grad_input, const recmv_tensor5* grad_input_desc,
+                                 void* grad_grid,
+                                 int interp, int pad, int dtype, void* stream);
+
+/* Double backward.  ggI = grad wrt backward's grad_input output (layout like input; may be NULL ->
+ * treated as zeros), ggG = grad wrt backward's grad_grid output ([N,Do,Ho,Wo,3], strided).
+ * Outputs: grad_input (like input; NULL to skip; caller zero-fills), grad_grid (contiguous),
+ * grad_grad_output (like grad_output; written, not accumulated). */
+int recmv_grid_sample3d_dbackward(const void* ggI, const recmv_tensor5* ggI_desc,
+                                  const void* ggG, const recmv_tensor5* ggG_desc,
+                                  const void* input, const recmv_tensor5* input_desc,
+                                  const void* grid, const recmv_tensor5* grid_desc,
+                                  const void* grad_output, const recmv_tensor5* grad_output_desc,
+                                  void* grad_input, const recmv_tensor5* grad_input_desc,
+                                  void* grad_grid,
+                                  void* grad_grad_output, const recmv_tensor5* grad_grad_output_desc,
+                                  int interp, int pad, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * C2. interp2x_boundary3d — (2n-1) trilinear upsample + boundary mask.
+ *   replaces interp2x_boundary3d.forward / backward
+ *            (MCAcc/cuda/interp2x_boundary3d.cpp:17-37; kernels interp2x_boundary3d_kernel.cu:11-239)
+ * input: [B,C,d,h,w] contiguous -> output [B,C,2d-1,2h-1,2w-1], is_boundary same shape (bytes).
+ * ---------------------------------------------------------------------------------------------- */
+int recmv_interp2x_boundary3d_forward(const void* input, void* output, uint8_t* is_boundary,
+                                      int64_t bc, int64_t d, int64_t h, int64_t w,
+                                      float balance_value, int dtype, void* stream);
+/* grad_output: [B,C,D,H,W] contiguous (D,H,W odd) -> grad_input [B,C,(D+1)/2,(H+1)/2,(W+1)/2]. */
+int recmv_interp2x_boundary3d_backward(const void* grad_output, void* grad_input,
+                                       int64_t bc, int64_t D, int64_t H, int64_t W,
+                                       int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * E. MCGpu — marching cubes on an x-major f32 volume sdf[NX][NY][NZ] (index i*NY*NZ+j*NZ+k).
+ *   replaces MCGpu.mc_gpu (MCGpu/MCGpu.cpp:20-56; MCGpu::init/MC/scaleVertices
+ *            MCGpu/CudaKernels.cu:572-639; kernels :316-521).
+ * Deterministic: vertices ordered by edge key ((x*NY+y)*NZ+z)*3+dir, faces by (voxel, triangle#),
+ * corner order reversed exactly as the reference (CudaKernels.cu:502).  An edge whose owner voxel is
+ * outside the grid has no vertex and is referenced as -1, as in the reference.
+ *
+ * Two-phase: recmv_mc_count classifies + scans and returns the sizes through `counts_host`
+ * (2 x int32 {n_vertices, n_faces}, HOST pointer, written after an internal stream sync — the same
+ * D2H round trip as the reference's cudaMemcpy at CudaKernels.cu:628).  The caller allocates
+ * vertices [V,3] f32 and faces [F,3] i64 and calls recmv_mc_emit with the same workspace.
+ * recmv_mc_workspace_bytes gives the workspace size for a volume.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t recmv_mc_workspace_bytes(int64_t nx, int64_t ny, int64_t nz);
+int recmv_mc_count(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float iso,
+                   void* workspace, int64_t workspace_bytes, int32_t* counts_host, void* stream);
+int recmv_mc_emit(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float iso,
+                  float xstep, float ystep, float zstep, float xmin, float ymin, float zmin,
+                  const void* workspace, int64_t workspace_bytes,
+                  float* vertices, int64_t* faces, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A/B/D. Dense f32 contractions of the three MLPs (SDF model/network.py:98-111, deformer
+ * model/Deformer.py:194-199, colour model/RenderNet.py:83-94) — torch.nn.Linear/cuBLAS sgemm in the
+ * reference.  f32 MFMA (v_mfma_f32_32x32x2_f32), exact-f32 accumulate.
+ *
+ *   recmv_gemm_nt :  C[M,N] = act( alpha * (A[M,K] . B[N,K]^T) + bias[N] ) * out_scale
+ *   recmv_gemm_tn :  C[M,N] = A[K,M]^T . B[K,N]      (weight gradients: reduction over points)
+ *
+ * lda/ldb/ldc are row strides in elements.  act: RECMV_ACT_*.  `bias` may be NULL.
+ * For softplus the reference's nn.Softplus(beta=100) semantics are used (threshold 20).
+ * recmv_gemm_tn needs a workspace of recmv_gemm_tn_workspace_bytes() for its split-K partials.
+ * ---------------------------------------------------------------------------------------------- */
+#define RECMV_ACT_NONE     0
+#define RECMV_ACT_RELU     1
+#define RECMV_ACT_SOFTPLUS 2   /* softplus(beta), param = beta */
+#define RECMV_ACT_TANH     3
+
+int recmv_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+                  float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                  int act, float act_param, float out_scale, void* stream);
+int64_t recmv_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb,
+                  float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Positional encoding (model/Embedder.py:4-65): out[p, 0:3] = x, then for each of L frequency bands
+ * 2^i: w[2i]*sin(2^i x), w[2i+1]*cos(2^i x) (3 values each).  out row stride ldo >= 3+6L; columns
+ * [3+6L, ldo_fill) are zero-filled (ldo_fill <= ldo) so padded K reads as zeros; everything is
+ * multiplied by out_scale (1/sqrt(2) for the skip connection, model/network.py:105-106).
+ * weights: HOST pointer to 2L floats (utils/utils.py:40-46 produces python floats), or NULL = ones. */
+int recmv_posenc_forward(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t ldo_fill,
+                         int64_t P, int L, const float* weights_host, float out_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECMV_HIP_H_ */

@@ -1,0 +1,100 @@
+"""Build librecmv_hip.so (gfx950) from rec-mv_amd/csrc/*.hip with hipcc.
+
+In-tree build: objects go to rec-mv_amd/build/, the library to rec-mv_amd/lib/librecmv_hip.so (both
+git-ignored, both travel to the GPU box with the gpurun snapshot).  hipcc cross-compiles gfx950 without
+a GPU, so this runs in the CPU-only container too.
+
+    python rec-mv_amd/build.py [--force] [--verbose]
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OBJ = HERE / "build"
+LIBDIR = HERE / "lib"
+LIB = LIBDIR / "librecmv_hip.so"
+INCLUDE = HERE.parent / "include"
+
+ARCH = "gfx950"
+COMMON_FLAGS = [
+    f"--offload-arch={ARCH}",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-Wall",
+    "-Wno-unused-function",
+    "-Wno-unused-variable",
+    f"-I{INCLUDE}",
+]
+# extern "C" entry points are exported explicitly through this macro-free rule: default visibility for
+# extern "C" symbols only is obtained by the version script below.
+VERSION_SCRIPT = HERE / "csrc" / "exports.map"
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: librecmv_hip.so cannot be built")
+    return exe
+
+
+def _newest_header_mtime() -> float:
+    m = 0.0
+    for p in list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + list(INCLUDE.glob("*.h")):
+        m = max(m, p.stat().st_mtime)
+    return m
+
+
+def _compile(src: Path, force: bool, verbose: bool, hdr_mtime: float) -> Path:
+    obj = OBJ / (src.stem + ".o")
+    if (not force and obj.exists() and obj.stat().st_mtime > src.stat().st_mtime
+            and obj.stat().st_mtime > hdr_mtime):
+        return obj
+    cmd = [hipcc(), *COMMON_FLAGS, "-c", str(src), "-o", str(obj)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    OBJ.mkdir(exist_ok=True)
+    LIBDIR.mkdir(exist_ok=True)
+    srcs = sorted(CSRC.glob("*.hip"))
+    if not srcs:
+        raise RuntimeError(f"no .hip sources under {CSRC}")
+    hdr_mtime = _newest_header_mtime()
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, verbose, hdr_mtime), srcs))
+    newest_obj = max(o.stat().st_mtime for o in objs)
+    if force or not LIB.exists() or LIB.stat().st_mtime < newest_obj:
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs),
+               f"-Wl,--version-script={VERSION_SCRIPT}"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    lib = build(a.force, a.verbose)
+    print(lib)
+    sys.exit(0)

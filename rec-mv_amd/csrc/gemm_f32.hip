@@ -1,0 +1,402 @@
+// f32 MFMA contractions for the three MLPs of the hot path (SDF, deformer, colour) — gfx950.
+//
+// The reference runs these as torch.nn.Linear -> cuBLAS sgemm plus separate bias / activation kernels
+// (model/network.py:98-111, model/Deformer.py:194-199, model/RenderNet.py:83-94).  Here each layer is ONE
+// kernel: v_mfma_f32_32x32x2_f32 (exact f32 multiply-accumulate, 157 TFLOP/s dense peak on MI355X) over
+// LDS-staged 128x128x32 tiles, with bias + activation (+ the 1/sqrt(2) skip scale) fused in the epilogue
+// so activations make one HBM round trip per layer.
+//
+//   gemm_nt : C[M,N] = act(A[M,K] . B[N,K]^T + bias) * out_scale      forward  (A = activations, B = W)
+//                                                                     and dX = dZ . W^T^T (B = W^T copy)
+//   gemm_tn : C[M,N] = A[K,M]^T . B[K,N]                              dW = dZ^T . X  (K = #points), split-K
+//
+// Tiling (wave64): 256 threads = 4 waves in 2x2, each wave owns a 64x64 sub-tile = 2x2 MFMA tiles
+// (64 accumulator VGPRs).  gemm_nt keeps both operands k-contiguous in LDS (row stride 36 floats: the
+// 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots) and feeds 4 MFMAs per 16-byte read;
+// gemm_tn keeps them k-major and reads one dword per MFMA operand (conflict-free, 2 x 32-lane groups).
+// Global->LDS goes through registers one K-tile ahead (one barrier per K-tile, 2 LDS buffers).
+// Workgroup ids are remapped so the column tiles that share an A row-panel run on the same XCD/L2.
+//
+// FLOPs: 2*M*N*K.  With K=N=512 the arithmetic intensity is 128 FLOP/B >> 157e12/8e12, so every layer
+// is MFMA-bound, not HBM-bound.
+#include "common.h"
+
+namespace recmv {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int kBlk = 256;
+constexpr int LDK = BK + 4;    // NT: padded k stride (floats) of an LDS row
+constexpr int LDM = BM + 4;    // TN: padded m stride (floats) of an LDS k-row
+
+__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb) {
+  const int64_t per = nb / kNumXCD;
+  if (b >= per * kNumXCD) return b;
+  return (b % kNumXCD) * per + b / kNumXCD;
+}
+
+__device__ __forceinline__ float apply_act(float z, int act, float p) {
+  switch (act) {
+    case RECMV_ACT_RELU:
+      return z > 0.f ? z : 0.f;
+    case RECMV_ACT_SOFTPLUS: {
+      // nn.Softplus(beta=p, threshold=20): x*beta > 20 ? x : log1p(exp(x*beta))/beta
+      const float zb = z * p;
+      return zb > 20.f ? z : log1pf(expf(zb)) / p;
+    }
+    case RECMV_ACT_TANH:
+      return tanhf(z);
+    default:
+      return z;
+  }
+}
+
+// 4 consecutive floats of a row, zero-filled past `limit` (elements left in the row).
+__device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int64_t limit, bool vec_ok) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (limit >= 4 && vec_ok) {
+    v = *reinterpret_cast<const float4*>(p);
+  } else {
+    if (limit > 0) v.x = p[0];
+    if (limit > 1) v.y = p[1];
+    if (limit > 2) v.z = p[2];
+    if (limit > 3) v.w = p[3];
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------ NT
+__global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
+                                                       const float* __restrict__ B, int64_t ldb,
+                                                       const float* __restrict__ bias, float* __restrict__ C,
+                                                       int64_t ldc, int M, int N, int K, int act,
+                                                       float act_param, float out_scale, int nbm, int nbn,
+                                                       bool a_vec, bool b_vec) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                       // [2][BM][LDK]
+  float* Bs = smem + 2 * BM * LDK;        // [2][BN][LDK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;      // 2x2 waves
+  const int64_t logical = xcd_remap(blockIdx.x, (int64_t)nbm * nbn);
+  const int tile_m = (int)(logical / nbn), tile_n = (int)(logical % nbn);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // staging map: 1024 float4 per operand tile, 4 per thread; row = idx/8, c4 = idx%8
+  float4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = tid + kBlk * r;
+      const int row = idx >> 3, c4 = idx & 7;
+      const int k = k0 + c4 * 4;
+      const int gm = m0 + row, gn = n0 + row;
+      ra[r] = (gm < M) ? load4_guard(A + (int64_t)gm * lda + k, K - k, a_vec) : make_float4(0, 0, 0, 0);
+      rb[r] = (gn < N) ? load4_guard(B + (int64_t)gn * ldb + k, K - k, b_vec) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = tid + kBlk * r;
+      const int row = idx >> 3, c4 = idx & 7;
+      *reinterpret_cast<float4*>(As + (buf * BM + row) * LDK + c4 * 4) = ra[r];
+      *reinterpret_cast<float4*>(Bs + (buf * BN + row) * LDK + c4 * 4) = rb[r];
+    }
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = (lane >> 5) * 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const float* as = As + (buf * BM + arow) * LDK + khalf;
+    const float* bs = Bs + (buf * BN + brow) * LDK + khalf;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 a[2], b[2];
+      a[0] = *reinterpret_cast<const float4*>(as + kk * 8);
+      a[1] = *reinterpret_cast<const float4*>(as + 32 * LDK + kk * 8);
+      b[0] = *reinterpret_cast<const float4*>(bs + kk * 8);
+      b[1] = *reinterpret_cast<const float4*>(bs + 32 * LDK + kk * 8);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int gn = n0 + wn * 64 + ni * 32 + (lane & 31);
+    if (gn >= N) continue;
+    const float bv = bias ? bias[gn] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm < M) C[(int64_t)gm * ldc + gn] = apply_act(acc[mi][ni][r] + bv, act, act_param) * out_scale;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ TN
+// partial[split][M][N] = sum over k in the split's range of A[k][m]*B[k][n]
+__global__ __launch_bounds__(kBlk) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda,
+                                                       const float* __restrict__ B, int64_t ldb,
+                                                       float* __restrict__ P, int M, int N, int64_t K, int nbm,
+                                                       int nbn, int64_t kchunk, bool a_vec, bool b_vec) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                       // [2][BK][LDM]
+  float* Bs = smem + 2 * BK * LDM;        // [2][BK][LDM]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles = nbm * nbn;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int tile_m = tile / nbn, tile_n = tile % nbn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int64_t kbeg = (int64_t)split * kchunk;
+  int64_t kend = kbeg + kchunk;
+  if (kend > K) kend = K;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // staging: BK rows x 128 floats = 1024 float4 per operand; krow = idx/32, c4 = idx%32
+  float4 ra[4], rb[4];
+  auto gload = [&](int64_t k0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = tid + kBlk * r;
+      const int krow = idx >> 5, c4 = idx & 31;
+      const int64_t k = k0 + krow;
+      const int cm = m0 + c4 * 4, cn = n0 + c4 * 4;
+      ra[r] = (k < kend) ? load4_guard(A + k * lda + cm, M - cm, a_vec) : make_float4(0, 0, 0, 0);
+      rb[r] = (k < kend) ? load4_guard(B + k * ldb + cn, N - cn, b_vec) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = tid + kBlk * r;
+      const int krow = idx >> 5, c4 = idx & 31;
+      *reinterpret_cast<float4*>(As + (buf * BK + krow) * LDM + c4 * 4) = ra[r];
+      *reinterpret_cast<float4*>(Bs + (buf * BK + krow) * LDM + c4 * 4) = rb[r];
+    }
+  };
+
+  const int nk = (int)((kend - kbeg + BK - 1) / BK);
+  if (nk > 0) {
+    gload(kbeg);
+    lstore(0);
+  }
+  __syncthreads();
+  const int acol = wm * 64 + (lane & 31), bcol = wn * 64 + (lane & 31), kh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kbeg + (int64_t)(kt + 1) * BK);
+    const float* as = As + (buf * BK + kh) * LDM + acol;
+    const float* bs = Bs + (buf * BK + kh) * LDM + bcol;
+#pragma unroll
+    for (int k2 = 0; k2 < BK / 2; ++k2) {
+      const float a0 = as[k2 * 2 * LDM], a1 = as[k2 * 2 * LDM + 32];
+      const float b0 = bs[k2 * 2 * LDM], b1 = bs[k2 * 2 * LDM + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* Ps = P + (int64_t)split * M * N;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int gn = n0 + wn * 64 + ni * 32 + (lane & 31);
+    if (gn >= N) continue;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm < M) Ps[(int64_t)gm * N + gn] = acc[mi][ni][r];
+      }
+    }
+  }
+}
+
+// C[m][n] = sum_s P[s][m][n]   (fixed order -> deterministic)
+__global__ __launch_bounds__(kBlk) void splitk_reduce_kernel(const float* __restrict__ P, float* __restrict__ C,
+                                                             int64_t ldc, int M, int N, int splits) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * kBlk + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlk) {
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += P[(int64_t)sp * total + i];
+    C[(i / N) * ldc + (i % N)] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ posenc
+struct PeWeights {
+  float w[32];  // by-value kernel argument: no H2D copy, graph-capturable
+};
+__global__ __launch_bounds__(kBlk) void posenc_kernel(const float* __restrict__ x, int64_t ldx,
+                                                      float* __restrict__ out, int64_t ldo, int64_t ldo_fill,
+                                                      int64_t P, int L, PeWeights w, float out_scale) {
+  const int nf = 1 + 2 * L;  // identity + (sin,cos) per band
+  const int64_t total = P * nf;
+  for (int64_t e = (int64_t)blockIdx.x * kBlk + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlk) {
+    const int64_t p = e / nf;
+    const int f = (int)(e % nf);
+    const float x0 = x[p * ldx], x1 = x[p * ldx + 1], x2 = x[p * ldx + 2];
+    float* o = out + p * ldo + 3 * f;
+    if (f == 0) {
+      o[0] = x0 * out_scale;
+      o[1] = x1 * out_scale;
+      o[2] = x2 * out_scale;
+      for (int64_t c = 3 * nf; c < ldo_fill; ++c) out[p * ldo + c] = 0.f;
+    } else {
+      const int band = (f - 1) >> 1;
+      const float freq = (float)(1 << band);  // 2**linspace(0, L-1, L): exact powers of two
+      const float wt = w.w[f - 1];
+      float v0, v1, v2;
+      if ((f - 1) & 1) {
+        v0 = cosf(x0 * freq); v1 = cosf(x1 * freq); v2 = cosf(x2 * freq);
+      } else {
+        v0 = sinf(x0 * freq); v1 = sinf(x1 * freq); v2 = sinf(x2 * freq);
+      }
+      o[0] = wt * v0 * out_scale;
+      o[1] = wt * v1 * out_scale;
+      o[2] = wt * v2 * out_scale;
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr int kNtLds = (2 * BM * LDK + 2 * BN * LDK) * 4;   // 73728 B
+constexpr int kTnLds = (4 * BK * LDM) * 4;                  // 67584 B
+
+int tn_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
+  int64_t want = ceil_div((int64_t)kNumCU * 4, tiles);        // ~4 workgroups per CU overall
+  const int64_t maxs = ceil_div(K, (int64_t)BK * 4);          // at least 4 K-tiles per split
+  if (want > maxs) want = maxs;
+  if (want > 128) want = 128;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+}  // namespace
+}  // namespace recmv
+
+using namespace recmv;
+
+extern "C" int recmv_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+                             float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
+                             float act_param, float out_scale, void* stream) {
+  RECMV_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_nt: negative size");
+  if (M == 0 || N == 0) return RECMV_OK;
+  RECMV_REQUIRE(A && B && C, "gemm_nt: NULL pointer");
+  RECMV_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt: leading dimension too small");
+  RECMV_REQUIRE(M < (1ll << 31) - BM && N < (1ll << 31) - BN && K < (1ll << 31) - BK, "gemm_nt: size overflow");
+  RECMV_REQUIRE(act >= RECMV_ACT_NONE && act <= RECMV_ACT_TANH, "gemm_nt: unknown activation %d", act);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kNtLds));
+    attr_set = true;
+  }
+  const int nbm = (int)ceil_div(M, BM), nbn = (int)ceil_div(N, BN);
+  const bool a_vec = aligned16(A) && lda % 4 == 0, b_vec = aligned16(B) && ldb % 4 == 0;
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), kNtLds,
+                     (hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param,
+                     out_scale, nbm, nbn, a_vec, b_vec);
+  return check_launch("gemm_nt");
+}
+
+extern "C" int64_t recmv_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (int64_t)tn_splits(M, N, K) * M * N * 4;
+}
+
+extern "C" int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                             int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
+                             void* stream) {
+  RECMV_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_tn: negative size");
+  if (M == 0 || N == 0) return RECMV_OK;
+  RECMV_REQUIRE(A && B && C, "gemm_tn: NULL pointer");
+  RECMV_REQUIRE(lda >= M && ldb >= N && ldc >= N, "gemm_tn: leading dimension too small");
+  RECMV_REQUIRE(M < (1 << 20) && N < (1 << 20), "gemm_tn: output too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 0) {
+    for (int64_t m = 0; m < M; ++m) RECMV_HIP_TRY(hipMemsetAsync(C + m * ldc, 0, N * 4, s));
+    return RECMV_OK;
+  }
+  const int splits = tn_splits(M, N, K);
+  const int64_t need = (int64_t)splits * M * N * 4;
+  if (!workspace || workspace_bytes < need) {
+    set_error("gemm_tn: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    return RECMV_ERR_WORKSPACE;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kTnLds));
+    attr_set = true;
+  }
+  const int nbm = (int)ceil_div(M, BM), nbn = (int)ceil_div(N, BN);
+  int64_t kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
+  const bool a_vec = aligned16(A) && lda % 4 == 0, b_vec = aligned16(B) && ldb % 4 == 0;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(nbm * nbn * splits)), dim3(kBlk), kTnLds, s, A, lda, B, ldb,
+                     (float*)workspace, (int)M, (int)N, K, nbm, nbn, kchunk, a_vec, b_vec);
+  int rc = check_launch("gemm_tn");
+  if (rc) return rc;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stream_grid(M * N, kBlk)), dim3(kBlk), 0, s,
+                     (const float*)workspace, C, ldc, (int)M, (int)N, splits);
+  return check_launch("gemm_tn/reduce");
+}
+
+extern "C" int recmv_posenc_forward(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t ldo_fill,
+                                    int64_t P, int L, const float* weights_host, float out_scale,
+                                    void* stream) {
+  RECMV_REQUIRE(P >= 0 && L >= 0 && L <= 16, "posenc: bad size (P=%lld, L=%d)", (long long)P, L);
+  if (P == 0) return RECMV_OK;
+  RECMV_REQUIRE(x && out, "posenc: NULL pointer");
+  RECMV_REQUIRE(ldx >= 3 && ldo >= 3 + 6 * L && ldo_fill <= ldo, "posenc: leading dimension too small");
+  hipStream_t s = (hipStream_t)stream;
+  // the 2L annealing weights are python floats in the reference (utils/utils.py:40-46); ship them by value
+  PeWeights hw;
+  for (int i = 0; i < 32; ++i) hw.w[i] = (weights_host && i < 2 * L) ? weights_host[i] : 1.f;
+  hipLaunchKernelGGL(posenc_kernel, dim3(stream_grid(P * (1 + 2 * L), kBlk)), dim3(kBlk), 0, s, x, ldx, out, ldo,
+                     ldo_fill, P, L, hw, out_scale);
+  return check_launch("posenc");
+}

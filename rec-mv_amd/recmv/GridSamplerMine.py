@@ -1,0 +1,80 @@
+"""Drop-in for the reference's `GridSamplerMine` extension (MCAcc/cuda/GridSamplerMine.cpp:73-103).
+
+Extensions over the reference, all optional: `need_grad_input=False` skips the scatter into the volume
+(the hot path's volume is a frozen buffer), and `grad_output_input=None` in dbackward means zeros.
+"""
+import torch
+
+from . import _lib as L
+
+
+def _check(input, grid, interp, pad):
+    # GridSamplerMine.cpp:24-71
+    if not (isinstance(input, torch.Tensor) and isinstance(grid, torch.Tensor)):
+        raise RuntimeError("grid_sampler(): expected input and grid to not be undefined")
+    if input.device != grid.device:
+        raise RuntimeError("grid_sampler(): expected input and grid to be on same device, but input is on "
+                           f"{input.device} and grid is on {grid.device}")
+    if input.dtype != grid.dtype:
+        raise RuntimeError("grid_sampler(): expected input and grid to have same dtype, but input has "
+                           f"{input.dtype} and grid has {grid.dtype}")
+    if input.dim() != 5 or grid.dim() != 5:
+        raise RuntimeError("grid_sampler(): expected 5D input and grid with same number of dimensions, but "
+                           f"got input with sizes {tuple(input.shape)} and grid with sizes {tuple(grid.shape)}")
+    if input.size(0) != grid.size(0):
+        raise RuntimeError("grid_sampler(): expected grid and input to have same batch size")
+    if grid.size(-1) != 3:
+        raise RuntimeError("grid_sampler(): expected grid to have size 3 in last dimension")
+    if interp != 0:
+        raise RuntimeError("grid_sampler(): only support Bilinear now")
+    if pad != 1:
+        raise RuntimeError("grid_sampler(): only support Border Padding now")
+    for i in range(2, 5):
+        if input.size(i) <= 0:
+            raise RuntimeError("grid_sampler(): expected input to have non-empty spatial dimensions")
+    L.require_cuda(input, "input")
+
+
+def forward(input, grid, interpolation_mode, padding_mode):
+    _check(input, grid, interpolation_mode, padding_mode)
+    N, C = input.size(0), input.size(1)
+    out = torch.empty((N, C, grid.size(1), grid.size(2), grid.size(3)), dtype=input.dtype, device=input.device)
+    di, dg, do = L.desc5(input), L.desc5(grid), L.desc5(out)
+    with torch.cuda.device(input.device):
+        L.check(L.lib().recmv_grid_sample3d_forward(L.ptr(input), di, L.ptr(grid), dg, L.ptr(out), do,
+                                                    interpolation_mode, padding_mode, L.dtype_code(input),
+                                                    L.stream_ptr(input.device)), "GridSamplerMine.forward")
+    return out
+
+
+def backward(input, grid, grad_output, interpolation_mode, padding_mode, need_grad_input=True):
+    _check(input, grid, interpolation_mode, padding_mode)
+    grad_input = torch.zeros_like(input) if need_grad_input else None
+    grad_grid = torch.empty(grid.shape, dtype=grid.dtype, device=grid.device)  # contiguous
+    di, dg, dgo = L.desc5(input), L.desc5(grid), L.desc5(grad_output)
+    dgi = L.desc5(grad_input) if grad_input is not None else di
+    with torch.cuda.device(input.device):
+        L.check(L.lib().recmv_grid_sample3d_backward(L.ptr(input), di, L.ptr(grid), dg, L.ptr(grad_output), dgo,
+                                                     L.ptr(grad_input), dgi, L.ptr(grad_grid),
+                                                     interpolation_mode, padding_mode, L.dtype_code(input),
+                                                     L.stream_ptr(input.device)), "GridSamplerMine.backward")
+    return grad_input, grad_grid
+
+
+def dbackward(grad_output_input, grad_output_grid, input, grid, grad_output, interpolation_mode, padding_mode,
+              need_grad_input=True):
+    _check(input, grid, interpolation_mode, padding_mode)
+    grad_input = torch.zeros_like(input) if need_grad_input else None
+    grad_grid = torch.empty(grid.shape, dtype=grid.dtype, device=grid.device)
+    ggo = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)
+    di, dg, dgo = L.desc5(input), L.desc5(grid), L.desc5(grad_output)
+    dgI = L.desc5(grad_output_input) if grad_output_input is not None else di
+    dgG = L.desc5(grad_output_grid)
+    dgi = L.desc5(grad_input) if grad_input is not None else di
+    with torch.cuda.device(input.device):
+        L.check(L.lib().recmv_grid_sample3d_dbackward(
+            L.ptr(grad_output_input), dgI, L.ptr(grad_output_grid), dgG, L.ptr(input), di, L.ptr(grid), dg,
+            L.ptr(grad_output), dgo, L.ptr(grad_input), dgi, L.ptr(grad_grid), L.ptr(ggo), L.desc5(ggo),
+            interpolation_mode, padding_mode, L.dtype_code(input), L.stream_ptr(input.device)),
+            "GridSamplerMine.dbackward")
+    return grad_input, grad_grid, ggo

@@ -1,0 +1,131 @@
+"""ctypes binding of librecmv_hip.so (the C ABI declared in include/recmv_hip.h).
+
+There is NO fallback: if the library is absent (and cannot be built because hipcc is missing) importing
+any recmv op raises.  The product path never routes through a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib.util
+import os
+from pathlib import Path
+
+import torch
+
+_PKG = Path(__file__).resolve().parent.parent          # rec-mv_amd/
+LIB_PATH = _PKG / "lib" / "librecmv_hip.so"
+
+RECMV_OK = 0
+F32, F64 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = 0, 1, 2, 3
+
+
+class Tensor5(C.Structure):
+    _fields_ = [("size", C.c_int64 * 5), ("stride", C.c_int64 * 5)]
+
+
+_lib = None
+
+
+def _load_build_module():
+    spec = importlib.util.spec_from_file_location("recmv_build", _PKG / "build.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile librecmv_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    return _load_build_module().build(force=force, verbose=verbose)
+
+
+def _declare(lib):
+    vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+    T5 = C.POINTER(Tensor5)
+    sigs = {
+        "recmv_abi_version": (C.c_int, []),
+        "recmv_last_error": (C.c_char_p, []),
+        "recmv_inv3x3_forward": (C.c_int, [vp, vp, vp, i64, i32, vp]),
+        "recmv_inv3x3_backward": (C.c_int, [vp, vp, vp, i64, i32, vp]),
+        "recmv_grid_sample3d_forward": (C.c_int, [vp, T5, vp, T5, vp, T5, i32, i32, i32, vp]),
+        "recmv_grid_sample3d_backward": (C.c_int, [vp, T5, vp, T5, vp, T5, vp, T5, vp, i32, i32, i32, vp]),
+        "recmv_grid_sample3d_dbackward": (C.c_int, [vp, T5, vp, T5, vp, T5, vp, T5, vp, T5, vp, T5, vp, vp, T5,
+                                                    i32, i32, i32, vp]),
+        "recmv_interp2x_boundary3d_forward": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, f32, i32, vp]),
+        "recmv_interp2x_boundary3d_backward": (C.c_int, [vp, vp, i64, i64, i64, i64, i32, vp]),
+        "recmv_mc_workspace_bytes": (i64, [i64, i64, i64]),
+        "recmv_mc_count": (C.c_int, [vp, i64, i64, i64, f32, vp, i64, vp, vp]),
+        "recmv_mc_emit": (C.c_int, [vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, f32, vp, i64, vp, vp, vp]),
+        "recmv_gemm_nt": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, f32, f32, vp]),
+        "recmv_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),
+        "recmv_gemm_tn": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
+        "recmv_posenc_forward": (C.c_int, [vp, i64, vp, i64, i64, i64, i32, vp, f32, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return sigs
+
+
+def lib():
+    """The loaded library.  Builds it on first use if the .so is missing and hipcc exists."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        if not LIB_PATH.exists():
+            raise ImportError(f"librecmv_hip.so not found at {LIB_PATH} and could not be built; "
+                              "the recmv ops have no CPU fallback")
+        l = C.CDLL(str(LIB_PATH))
+        _declare(l)
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    """Names declared in include/recmv_hip.h (parsed), for the export test."""
+    import re
+    hdr = (_PKG.parent / "include" / "recmv_hip.h").read_text()
+    return sorted(set(re.findall(r"\b(recmv_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def check(rc: int, what: str = ""):
+    if rc != RECMV_OK:
+        msg = lib().recmv_last_error().decode()
+        raise RuntimeError(f"{what or 'recmv'}: {msg} (code {rc})")
+
+
+def stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def desc5(t) -> Tensor5:
+    d = Tensor5()
+    for i in range(5):
+        d.size[i] = t.shape[i]
+        d.stride[i] = t.stride(i)
+    return d
+
+
+def dtype_code(t) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float64:
+        return F64
+    raise RuntimeError(f"recmv: dtype {t.dtype} not supported (float32/float64 only)")
+
+
+def require_cuda(t, name):
+    # the reference asserts CUDA tensors (CHECK_CUDA) -> RuntimeError
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+
+
+def require_contiguous(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")

@@ -1,0 +1,152 @@
+"""SDF network (model/network.py:27-141 of the reference): ImplicitNetwork + getTmpSdf.
+
+Same constructor, parameter names (`lin{l}.weight_g / weight_v / bias`, weight_norm dim 0), geometric
+initialisation, skip connection and `.rendcond` side effect as the reference; the arithmetic runs on
+the fused MFMA kernels of librecmv_hip.so (one kernel per layer: GEMM + bias + softplus(beta=100)
+[+ 1/sqrt(2) skip scale]) instead of nn.Linear/cuBLAS + separate activation kernels.
+"""
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.utils import annealing_weights
+from .Embedder import get_embedder
+
+_SQRT2 = float(np.sqrt(2))
+
+
+def _wn(lin):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return nn.utils.weight_norm(lin)
+
+
+class ImplicitNetwork(nn.Module):
+    def __init__(self, feature_vector_size, d_in, d_out, dims, geometric_init=True, bias=1.0, skip_in=(),
+                 weight_norm=True, multires=0):
+        super().__init__()
+        dims = [d_in] + list(dims) + [d_out + feature_vector_size]
+        self.d_out = d_out
+        self.embed_fn = None
+        self.multires = multires
+        if multires > 0:
+            embed_fn, input_ch = get_embedder(multires)
+            self.embed_fn = embed_fn
+            dims[0] = input_ch
+        self.dims = dims
+        self.num_layers = len(dims)
+        self.skip_in = skip_in
+        self.weight_norm = weight_norm
+        for l in range(0, self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if l + 1 in self.skip_in else dims[l + 1]
+            lin = nn.Linear(dims[l], out_dim)
+            if geometric_init:                                                      # network.py:66-80
+                if l == self.num_layers - 2:
+                    torch.nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
+                    torch.nn.init.constant_(lin.bias, -bias)
+                elif multires > 0 and l == 0:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.constant_(lin.weight[:, 3:], 0.0)
+                    torch.nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                elif multires > 0 and l in self.skip_in:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                    torch.nn.init.constant_(lin.weight[:, -(dims[0] - 3):], 0.0)
+                else:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            if weight_norm:
+                lin = _wn(lin)
+            setattr(self, "lin" + str(l), lin)
+        self.softplus = nn.Softplus(beta=100)
+        self.rendcond = None
+
+    # -- weights ---------------------------------------------------------------------------------
+    def _weight(self, l):
+        lin = getattr(self, "lin" + str(l))
+        if self.weight_norm:
+            v, g = lin.weight_v, lin.weight_g
+            return g * (v / v.norm(dim=1, keepdim=True)), lin.bias               # weight_norm dim=0
+        return lin.weight, lin.bias
+
+    def _pe_weights(self, ratio):
+        ratio = ratio if type(ratio) == float or type(ratio) == int or ratio is None else ratio["sdfRatio"]
+        if ratio is None:
+            return None
+        if ratio <= 0:
+            return [0.0 for _ in range(self.multires * 2)]
+        return annealing_weights(self.multires, ratio)
+
+    # -- forward ---------------------------------------------------------------------------------
+    def forward(self, input, ratio=None):
+        ws = self._pe_weights(ratio) if self.embed_fn is not None else None
+        needs_grad = torch.is_grad_enabled() and (input.requires_grad or
+                                                  any(p.requires_grad for p in self.parameters()))
+        if (not needs_grad and input.is_cuda and input.dtype == torch.float32 and input.dim() == 2
+                and self.embed_fn is not None):
+            x = self._forward_inference(input, ws)
+        else:
+            x = self._forward_autograd(input, ws)
+        if x.shape[-1] > self.d_out:
+            self.rendcond = x[:, self.d_out:]
+            x = x[:, 0:self.d_out]
+        else:
+            self.rendcond = None
+        return x
+
+    def _forward_autograd(self, input, ws):
+        if self.embed_fn is not None:
+            input = self.embed_fn(input, ws)
+        x = input
+        for l in range(0, self.num_layers - 1):
+            if l in self.skip_in:
+                x = torch.cat([x, input], 1) / np.sqrt(2)                           # network.py:105-106
+            W, b = self._weight(l)
+            last = l == self.num_layers - 2
+            x = ops.linear_act(x, W, b, ops.ACT_NONE if last else ops.ACT_SOFTPLUS, 100.0)
+        return x
+
+    @torch.no_grad()
+    def _forward_inference(self, input, ws):
+        """No-grad path: posenc kernel + one fused kernel per layer, activations in padded buffers."""
+        P = input.shape[0]
+        dev = input.device
+        d0 = self.dims[0]
+        d0p = (d0 + 3) // 4 * 4
+        pe = torch.empty((P, d0p), dtype=torch.float32, device=dev)
+        ops.posenc(input, self.multires, ws, 1.0, out=pe, ld_fill=d0p)
+        x = pe[:, :d0]
+        for l in range(0, self.num_layers - 1):
+            W, b = self._weight(l)
+            last = l == self.num_layers - 2
+            act = ops.ACT_NONE if last else ops.ACT_SOFTPLUS
+            if l + 1 in self.skip_in:
+                # write act(..)/sqrt(2) into the left part of the next layer's input and PE/sqrt(2) to its right
+                nxt = torch.empty((P, self.dims[l + 1]), dtype=torch.float32, device=dev)
+                n_out = W.shape[0]
+                ops.gemm_nt(x, W, b, act, 100.0, 1.0 / _SQRT2, out=nxt[:, :n_out])
+                ops.posenc(input, self.multires, ws, 1.0 / _SQRT2, out=nxt[:, n_out:], ld_fill=d0)
+                x = nxt
+            else:
+                x = ops.gemm_nt(x, W, b, act, 100.0, 1.0)
+        return x
+
+    def gradient(self, x, y=None):
+        x.requires_grad_(True)
+        if y is None:
+            y = self.forward(x)
+        d_output = torch.ones_like(y, requires_grad=False, device=y.device)
+        gradients = torch.autograd.grad(outputs=y, inputs=x, grad_outputs=d_output, create_graph=True,
+                                        retain_graph=True, only_inputs=True)[0]
+        return gradients.view(-1, 3)
+
+
+def getTmpSdf(device, multires, bias=0.6, feature_vector_size=256):
+    """network.py:135-141 — SDF net whose geometric init is a sphere of radius `bias`."""
+    net = ImplicitNetwork(feature_vector_size=feature_vector_size, d_in=3, d_out=1,
+                          dims=[512, 512, 512, 512, 512, 512, 512, 512], geometric_init=True, bias=bias,
+                          skip_in=[4], weight_norm=True, multires=multires)
+    return net.to(device)

@@ -1,0 +1,161 @@
+"""Hot-path helpers of utils/utils.py (reference lines 8-264), on the recmv kernels.
+
+  FastDiff3x3MinvFunction  utils/utils.py:8-18
+  quat2mat                 :21-39
+  annealing_weights        :40-46
+  GMRobustError            :48-52
+  sample_points            :101-111
+  compute_Jacobian         :133-156   (batch_compute_Jacobian :158-186)
+  compute_deformed_normals :198-230
+  compute_cardinal_rays    :232-250
+  compute_netRender_color  :252-264
+"""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from ..FastMinv import Fast3x3Minv, Fast3x3Minv_backward
+
+__all__ = ["FastDiff3x3MinvFunction", "quat2mat", "annealing_weights", "GMRobustError", "sample_points",
+           "compute_Jacobian", "batch_compute_Jacobian", "compute_deformed_normals", "compute_cardinal_rays",
+           "compute_netRender_color", "scatter_mean"]
+
+
+class FastDiff3x3MinvFunction(Function):
+    """Differentiable batched 3x3 inverse with a validity mask (utils/utils.py:8-18)."""
+
+    @staticmethod
+    def forward(ctx, input):
+        invs, check = Fast3x3Minv(input.contiguous())
+        ctx.save_for_backward(invs, check)
+        ctx.mark_non_differentiable(check)
+        return invs, check
+
+    @staticmethod
+    def backward(ctx, grad_input, grad_check):
+        invs, check = ctx.saved_tensors
+        return Fast3x3Minv_backward(grad_input.contiguous(), invs), None
+
+
+def quat2mat(quat):
+    """(w,x,y,z) quaternion -> rotation matrix, normalising first (utils/utils.py:21-39)."""
+    norm_quat = quat / quat.norm(p=2, dim=1, keepdim=True)
+    w, x, y, z = norm_quat[:, 0], norm_quat[:, 1], norm_quat[:, 2], norm_quat[:, 3]
+    B = quat.size(0)
+    w2, x2, y2, z2 = w.pow(2), x.pow(2), y.pow(2), z.pow(2)
+    wx, wy, wz = w * x, w * y, w * z
+    xy, xz, yz = x * y, x * z, y * z
+    return torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz,
+                        2 * wz + 2 * xy, w2 - x2 + y2 - z2, 2 * yz - 2 * wx,
+                        2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1).view(B, 3, 3)
+
+
+def annealing_weights(multires, ratio):
+    """Coarse-to-fine weights of the positional-encoding bands (utils/utils.py:40-46)."""
+    alpha = ratio * multires
+    out = []
+    for ind in range(multires):
+        w = (1. - np.cos(np.pi * min(max(alpha - float(ind), 0.), 1.))) / 2.
+        out.extend([w, w])
+    return out
+
+
+def GMRobustError(x, c, square=False):
+    if square:
+        return 2. * x / (c * c) / (x / (c * c) + 4)
+    return 2. * x * x / (c * c) / (x * x / (c * c) + 4)
+
+
+def sample_points(pc_input, global_sigma, local_sigma, ratio=6):
+    """Local gaussian jitter + global uniform samples (utils/utils.py:101-111)."""
+    sample_size, dim = pc_input.shape
+    sample_local = pc_input + (torch.randn_like(pc_input) * local_sigma)
+    if ratio > 0:
+        sample_global = (torch.rand(sample_size // ratio, dim, device=pc_input.device) * (global_sigma * 2)) \
+            - global_sigma
+        return torch.cat([sample_local, sample_global], dim=0)
+    return sample_local
+
+
+def compute_Jacobian(ps, ds, retain_graph, create_graph, allow_unused=False):
+    """[P,3,3] Jacobian d(ds)/d(ps), row i = grad of ds[...,i]; relies on per-point independence
+    (utils/utils.py:133-156)."""
+    grad_d_p = []
+    grad_outputs = torch.ones_like(ds[..., 0])
+    outx = torch.autograd.grad(ds[..., 0], ps, grad_outputs, retain_graph=True, create_graph=create_graph,
+                               allow_unused=allow_unused)
+    grad_d_p.append(outx[0].view(-1, 1, 3))
+    outy = torch.autograd.grad(ds[..., 1], ps, grad_outputs, retain_graph=True, create_graph=create_graph,
+                               allow_unused=allow_unused)
+    grad_d_p.append(outy[0].view(-1, 1, 3))
+    outz = torch.autograd.grad(ds[..., 2], ps, grad_outputs, retain_graph=retain_graph,
+                               create_graph=create_graph, allow_unused=allow_unused)
+    grad_d_p.append(outz[0].view(-1, 1, 3))
+    return torch.cat(grad_d_p, dim=1)
+
+
+def batch_compute_Jacobian(ps, ds, retain_graph, create_graph, allow_unused=False):
+    batch = ps.shape[0]
+    grad_d_p = []
+    grad_outputs = torch.ones_like(ds[..., 0])
+    for i in range(3):
+        out = torch.autograd.grad(ds[..., i], ps, grad_outputs, retain_graph=True if i < 2 else retain_graph,
+                                  create_graph=create_graph, allow_unused=allow_unused)
+        grad_d_p.append(out[0].view(batch, -1, 1, 3))
+    return torch.cat(grad_d_p, dim=-2)
+
+
+def _bmv(m, v):
+    """Batched 3x3 @ 3 without BLAS: (m[P,3,3], v[P,3]) -> [P,3]."""
+    return (m * v.unsqueeze(-2)).sum(-1)
+
+
+def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, phase, offset_type):
+    """Deformed-space normal J^-T grad f, fallback J grad f where J is singular (utils/utils.py:198-230)."""
+    sdfs = sdf(ps, ratio)
+    check = True if phase == 'train' or phase == 'Train' else False
+    onx = torch.autograd.grad(sdfs, ps, torch.ones_like(sdfs), retain_graph=check, create_graph=check)[0]
+    ds = deformer(ps, defconds, batch_inds, ratio=ratio, offset_type=offset_type)
+    grad_d_p = compute_Jacobian(ps, ds, check, check)
+    grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
+    nx = _bmv(grad_d_p_inv.transpose(-2, -1), onx.view(-1, 3))
+    n_inv_mask = ~inv_mask
+    if n_inv_mask.sum().item() > 0:
+        print('unwished error n_inv_mask:(%d:%d)' % (n_inv_mask.sum().item(), n_inv_mask.numel()))
+        nnx = torch.zeros_like(nx)
+        nnx[inv_mask] = nx[inv_mask]
+        nnx[n_inv_mask] = _bmv(grad_d_p[n_inv_mask], onx[n_inv_mask])
+        nx = nnx
+    nx = nx / nx.norm(dim=1, keepdim=True)
+    return nx, ds
+
+
+def compute_cardinal_rays(deformer, ps, rays, defconds, batch_inds, ratio, phase, offset_type=None):
+    """Canonical-space ray J^-1 v, fallback v where J is singular (utils/utils.py:232-250)."""
+    check = True if phase == 'train' or phase == 'Train' else False
+    ds = deformer(ps, defconds, batch_inds, ratio=ratio, offset_type=offset_type)
+    grad_d_p = compute_Jacobian(ps, ds, check, check)
+    grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
+    crays = _bmv(grad_d_p_inv, rays.view(-1, 3))
+    n_inv_mask = ~inv_mask
+    if n_inv_mask.sum().item() > 0:
+        print('unwished error n_inv_mask:(%d:%d)' % (n_inv_mask.sum().item(), n_inv_mask.numel()))
+        ncrays = torch.zeros_like(crays)
+        ncrays[inv_mask] = crays[inv_mask]
+        ncrays[n_inv_mask] = rays[n_inv_mask].detach()
+        crays = ncrays
+    crays = crays / crays.norm(dim=1, keepdim=True)
+    return crays, ds
+
+
+def compute_netRender_color(net, ps, ds, ns, vs, features, framefeatures, ratio):
+    """`ds` and `framefeatures` are accepted and ignored, as in the reference (utils/utils.py:252-264)."""
+    return net(ps, ns, vs, features, ratio)
+
+
+def scatter_mean(src, index, dim_size):
+    """torch_scatter.scatter(src, index, reduce='mean', dim_size=...) for 1-D src (third-party in the
+    reference: OptimGarmentNetwork.py:1188,1215).  Empty bins give 0, like torch_scatter."""
+    out = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, src)
+    cnt = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, torch.ones_like(src))
+    return out / cnt.clamp(min=1)

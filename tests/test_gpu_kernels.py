@@ -1,0 +1,321 @@
+"""HIP kernels vs the CPU oracle, through the C ABI (python -m pytest tests -m gpu).
+
+Bars: bit-exact for indices/masks and for every kernel whose arithmetic is a fixed IEEE sequence shared
+with the oracle (inv3x3, sampler forward/backward, interp2x, MC vertices+faces); stated f32 tolerances
+for the MFMA contractions (different summation order than a sequential reference).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def gpu(t):
+    return t.to(DEV)
+
+
+# ------------------------------------------------------------------------------------------ inv3x3
+@pytest.mark.parametrize("n", [0, 1, 255, 256, 257, 10000, 35937])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_inv3x3_bit_exact(oracle, n, dtype):
+    from recmv import FastMinv
+    torch.manual_seed(n + 1)
+    ms = torch.randn(n, 3, 3, dtype=dtype)
+    if n > 8:  # adversarial rows: singular, and |det| straddling 1e-4
+        ms[0] = 0
+        ms[1] = torch.eye(3, dtype=dtype)
+        ms[1, 0, 0] = 0.99e-4
+        ms[2] = torch.eye(3, dtype=dtype)
+        ms[2, 0, 0] = 1.01e-4
+        ms[3] = torch.ones(3, 3, dtype=dtype)
+    inv_o, chk_o = oracle.inv3x3_forward(ms)
+    inv_g, chk_g = FastMinv.Fast3x3Minv(gpu(ms))
+    assert chk_g.dtype == torch.bool and inv_g.shape == (n, 3, 3)
+    assert torch.equal(chk_g.cpu(), chk_o)
+    assert torch.equal(inv_g.cpu(), inv_o), "inverse must be bit-identical to the oracle"
+    g = torch.randn(n, 3, 3, dtype=dtype)
+    out_o = oracle.inv3x3_backward(g, inv_o)
+    out_g = FastMinv.Fast3x3Minv_backward(gpu(g), inv_g)
+    assert torch.equal(out_g.cpu(), out_o)
+
+
+def test_inv3x3_identity_check_like_reference():
+    from recmv import FastMinv
+    torch.manual_seed(0)
+    ms = torch.randn(10000, 3, 3, device=DEV)           # FastMinv/check.py:7-8
+    invs, checks = FastMinv.Fast3x3Minv(ms)
+    err = (invs[checks].matmul(ms[checks]) - torch.eye(3, device=DEV).view(1, 3, 3)).norm(dim=(1, 2))
+    assert err.mean().item() < 1e-4
+
+
+def test_inv3x3_argument_errors():
+    from recmv import FastMinv
+    with pytest.raises(RuntimeError):
+        FastMinv.Fast3x3Minv(torch.randn(4, 3, 3, device=DEV).half())
+    with pytest.raises(RuntimeError):
+        FastMinv.Fast3x3Minv(torch.randn(4, 3, 6, device=DEV)[:, :, ::2])      # not contiguous
+    with pytest.raises(RuntimeError):
+        FastMinv.Fast3x3Minv_backward(torch.randn(4, 3, 3, device=DEV), torch.randn(4, 3, 3, device=DEV).double())
+
+
+def test_fastdiff_function_gradcheck():
+    from recmv.utils import FastDiff3x3MinvFunction
+    torch.manual_seed(0)
+    m = (torch.randn(6, 3, 3, dtype=torch.double, device=DEV) + 2 * torch.eye(3, dtype=torch.double, device=DEV)
+         ).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda x: FastDiff3x3MinvFunction.apply(x)[0], (m,))
+
+
+# ------------------------------------------------------------------------------------------ sampler
+def _sampler_case(dtype, C=5, dims=(15, 15, 15), P=10, channels_last=False, seed=0, spread=2.2):
+    g = torch.Generator().manual_seed(seed)
+    inp = torch.randn(1, C, *dims, dtype=dtype, generator=g)
+    if channels_last:
+        inp = inp.contiguous(memory_format=torch.channels_last_3d)
+    grid = (torch.rand(1, 1, 1, P, 3, dtype=dtype, generator=g) - 0.5) * spread
+    return inp, grid
+
+
+@pytest.mark.parametrize("dtype,cl,C", [(torch.float64, False, 5), (torch.float32, False, 5),
+                                         (torch.float32, True, 24), (torch.float32, True, 8),
+                                         (torch.float32, False, 24), (torch.float64, True, 4)])
+def test_sampler_forward_backward_dbackward_vs_oracle(oracle, dtype, cl, C):
+    from recmv import GridSamplerMine
+    inp, grid = _sampler_case(dtype, C=C, dims=(9, 13, 11), P=4099, channels_last=cl, seed=C)
+    out_o = oracle.gs3d_forward(inp, grid)
+    out_g = GridSamplerMine.forward(gpu(inp), gpu(grid), 0, 1)
+    assert torch.equal(out_g.cpu(), out_o), "forward is a fixed fma chain: bit-exact"
+    go = torch.randn(out_o.shape, dtype=dtype, generator=torch.Generator().manual_seed(1))
+    gi_o, gg_o = oracle.gs3d_backward(inp, grid, go)
+    gi_g, gg_g = GridSamplerMine.backward(gpu(inp), gpu(grid), gpu(go), 0, 1)
+    assert torch.equal(gg_g.cpu(), gg_o), "grad_grid: bit-exact"
+    tol = 1e-12 if dtype == torch.float64 else 2e-5                     # atomics: order differs
+    torch.testing.assert_close(gi_g.cpu(), gi_o, rtol=tol, atol=tol)
+    gi_none, gg2 = GridSamplerMine.backward(gpu(inp), gpu(grid), gpu(go), 0, 1, need_grad_input=False)
+    assert gi_none is None and torch.equal(gg2, gg_g)
+    # double backward
+    ggI = torch.randn(inp.shape, dtype=dtype, generator=torch.Generator().manual_seed(2))
+    if cl:
+        ggI = ggI.contiguous(memory_format=torch.channels_last_3d)
+    ggG = torch.randn(grid.shape, dtype=dtype, generator=torch.Generator().manual_seed(3))
+    a_o, b_o, c_o = oracle.gs3d_dbackward(ggI, ggG, inp, grid, go)
+    a_g, b_g, c_g = GridSamplerMine.dbackward(gpu(ggI), gpu(ggG), gpu(inp), gpu(grid), gpu(go), 0, 1)
+    assert torch.equal(b_g.cpu(), b_o) and torch.equal(c_g.cpu(), c_o)
+    torch.testing.assert_close(a_g.cpu(), a_o, rtol=tol, atol=tol)
+    # ggI = None (the hot path: volume is a frozen buffer)
+    a2_o, b2_o, c2_o = oracle.gs3d_dbackward(None, ggG, inp, grid, go, need_grad_input=False)
+    a2_g, b2_g, c2_g = GridSamplerMine.dbackward(None, gpu(ggG), gpu(inp), gpu(grid), gpu(go), 0, 1,
+                                                 need_grad_input=False)
+    assert a2_g is None and torch.equal(b2_g.cpu(), b2_o) and torch.equal(c2_g.cpu(), c2_o)
+
+
+def test_sampler_equals_torch_grid_sample_on_gpu():
+    from recmv import GridSamplerMine
+    inp, grid = _sampler_case(torch.float32, C=24, dims=(17, 29, 21), P=20000, channels_last=True)
+    ref = F.grid_sample(inp, grid, mode="bilinear", padding_mode="border", align_corners=False)
+    out = GridSamplerMine.forward(gpu(inp), gpu(grid), 0, 1)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-6, atol=2e-6)
+
+
+def test_sampler_multibatch_strided_grid(oracle):
+    from recmv import GridSamplerMine
+    g = torch.Generator().manual_seed(5)
+    inp = torch.randn(2, 6, 5, 7, 9, generator=g)
+    grid_full = (torch.rand(2, 2, 3, 4, 6, generator=g) - 0.5) * 2.4
+    grid = grid_full[..., ::2]                                        # strided last dim
+    out_o = oracle.gs3d_forward(inp, grid)
+    out_g = GridSamplerMine.forward(gpu(inp), gpu(grid_full)[..., ::2], 0, 1)
+    assert torch.equal(out_g.cpu(), out_o)
+
+
+def test_sampler_functions_gradcheck_like_reference():
+    """MCAcc/check_grid_sampler_mine.py:5-16 on the HIP kernels (f64)."""
+    from recmv.MCAcc.grid_sampler_mine import GridSamplerMine3dBackwardFunction, GridSamplerMine3dFunction
+    torch.manual_seed(0)
+    inp = torch.randn(1, 5, 15, 15, 15, dtype=torch.double, device=DEV, requires_grad=True)
+    grid = ((torch.rand(1, 1, 1, 10, 3, dtype=torch.double, device=DEV) - 0.5) * 2.2).requires_grad_(True)
+    assert torch.autograd.gradcheck(GridSamplerMine3dFunction.apply, (inp, grid))
+    go = torch.randn(1, 5, 1, 1, 10, dtype=torch.double, device=DEV, requires_grad=True)
+    assert torch.autograd.gradcheck(GridSamplerMine3dBackwardFunction.apply, (inp, grid, go))
+    # frozen volume: gradients only wrt grid / grad_output
+    inp_f = inp.detach()
+    assert torch.autograd.gradcheck(lambda g: GridSamplerMine3dFunction.apply(inp_f, g), (grid,))
+    assert torch.autograd.gradgradcheck(lambda g: GridSamplerMine3dFunction.apply(inp_f, g), (grid,))
+
+
+def test_sampler_argument_errors():
+    from recmv import GridSamplerMine
+    inp = torch.randn(1, 2, 3, 3, 3, device=DEV)
+    grid = torch.zeros(1, 1, 1, 2, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="Bilinear"):
+        GridSamplerMine.forward(inp, grid, 1, 1)
+    with pytest.raises(RuntimeError, match="Border"):
+        GridSamplerMine.forward(inp, grid, 0, 0)
+    with pytest.raises(RuntimeError, match="dtype"):
+        GridSamplerMine.forward(inp, grid.double(), 0, 1)
+    with pytest.raises(RuntimeError, match="batch"):
+        GridSamplerMine.forward(inp, grid.repeat(2, 1, 1, 1, 1), 0, 1)
+    out = GridSamplerMine.forward(inp, torch.zeros(1, 1, 1, 0, 3, device=DEV), 0, 1)     # empty grid
+    assert out.shape == (1, 2, 1, 1, 0)
+
+
+# ------------------------------------------------------------------------------------------ interp2x
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape", [(1, 1, 2, 2, 2), (1, 1, 6, 9, 5), (2, 3, 4, 3, 7), (1, 1, 33, 33, 33)])
+def test_interp2x_bit_exact(oracle, dtype, shape):
+    from recmv import interp2x_boundary3d
+    torch.manual_seed(sum(shape))
+    x = torch.randn(*shape, dtype=dtype)
+    out_o, bnd_o = oracle.interp2x_forward(x, 0.1)
+    out_g, bnd_g = interp2x_boundary3d.forward(gpu(x), 0.1)
+    assert bnd_g.dtype == torch.bool
+    assert torch.equal(out_g.cpu(), out_o) and torch.equal(bnd_g.cpu(), bnd_o)
+    go = torch.randn_like(out_o)
+    assert torch.equal(interp2x_boundary3d.backward(gpu(go)).cpu(), oracle.interp2x_backward(go))
+
+
+# ------------------------------------------------------------------------------------------ MC
+def _noise_volume(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(*shape, generator=g)
+    # smooth a little so the surface is not pure salt-and-pepper, keep plenty of ambiguous cases
+    v = F.avg_pool3d(v[None, None], 3, 1, 1)[0, 0]
+    return v.contiguous()
+
+
+@pytest.mark.parametrize("shape,seed", [((9, 9, 9), 0), ((33, 33, 33), 1), ((17, 21, 13), 2), ((5, 7, 65), 3),
+                                        ((6, 5, 66), 4), ((4, 4, 130), 5), ((3, 3, 2), 6), ((40, 9, 64), 7),
+                                        ((2, 2, 2), 8), ((65, 65, 65), 9)])
+def test_mc_bit_exact_vs_oracle(oracle, shape, seed):
+    from recmv import MCGpu
+    vol = _noise_volume(shape, seed)
+    args = (0.013, 0.021, 0.017, -0.5, -0.6, -0.4, 0.02)
+    v_o, f_o = oracle.mc(vol, *args)
+    v_g, f_g = MCGpu.mc_gpu(gpu(vol), *args)
+    assert v_g.dtype == torch.float32 and f_g.dtype == torch.int64
+    assert v_g.shape == v_o.shape and f_g.shape == f_o.shape
+    assert torch.equal(f_g.cpu(), f_o), "triangle/vertex indexing must be bit-exact"
+    assert torch.equal(v_g.cpu(), v_o), "vertex positions must be bit-exact"
+
+
+def test_mc_sphere_and_degenerate(oracle):
+    from recmv import MCGpu
+    from test_mc_oracle import mesh_invariants, sphere_volume
+    vol = sphere_volume(65)
+    v, f = MCGpu.mc_gpu(gpu(vol), 2 / 64, 2 / 64, 2 / 64, -1.0, -1.0, -1.0, 0.0)
+    assert mesh_invariants(v.cpu(), f.cpu()) == 2
+    v, f = MCGpu.mc_gpu(torch.ones(5, 6, 7, device=DEV))
+    assert v.shape == (0, 3) and f.shape == (0, 3)
+    assert MCGpu.mc_gpu(torch.ones(0, 6, 7, device=DEV)) == []
+    big = sphere_volume(9, r=1.2)                                      # surface touches the box
+    v_o, f_o = oracle.mc(big)
+    v, f = MCGpu.mc_gpu(gpu(big))
+    assert torch.equal(f.cpu(), f_o) and (f == -1).any()
+    with pytest.raises(RuntimeError):
+        MCGpu.mc_gpu(torch.ones(4, 4, 4, device=DEV).double())
+
+
+def test_mc_full_size_257_properties():
+    """BASELINE config 3 size: 257^3.  Size-independent properties: deterministic, closed manifold, chi=2."""
+    from recmv import MCGpu
+    from test_mc_oracle import mesh_invariants
+    n = 257
+    ax = torch.linspace(-1, 1, n, device=DEV)
+    X, Y, Z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    vol = (torch.sqrt(X ** 2 + (Y * 0.8) ** 2 + Z ** 2) - 0.6 + 0.03 * torch.sin(9 * X) * torch.cos(7 * Z)).contiguous()
+    step = 2.0 / (n - 1)
+    v1, f1 = MCGpu.mc_gpu(vol, step, step, step, -1.0, -1.0, -1.0, 0.0)
+    v2, f2 = MCGpu.mc_gpu(vol, step, step, step, -1.0, -1.0, -1.0, 0.0)
+    assert torch.equal(v1, v2) and torch.equal(f1, f2)
+    assert v1.shape[0] > 100000
+    assert mesh_invariants(v1.cpu(), f1.cpu()) == 2
+
+
+# ------------------------------------------------------------------------------------------ GEMM / PE
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 3, 39), (257, 512, 39), (300, 473, 512), (1000, 257, 512),
+                                   (129, 130, 167), (4096, 512, 512), (77, 3, 512), (640, 512, 289)])
+def test_gemm_nt_vs_fp64(M, N, K):
+    from recmv import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) / np.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double() @ B.double().t() + bias.double())
+    out = ops.gemm_nt(gpu(A), gpu(B), gpu(bias))
+    # f32 MFMA == an fmaf chain: error ~1e-7 * sum|a b|  (guide: 0.75-1.5e-7)
+    bound = 4e-7 * (A.abs().double() @ B.abs().double().t()) + 1e-6
+    assert ((out.cpu().double() - ref).abs() <= bound).all()
+    out_sp = ops.gemm_nt(gpu(A), gpu(B), gpu(bias), ops.ACT_SOFTPLUS, 100.0, 0.5)
+    torch.testing.assert_close(out_sp.cpu(), (F.softplus(ref, beta=100) * 0.5).float(), rtol=2e-5, atol=2e-6)
+    out_relu = ops.gemm_nt(gpu(A), gpu(B), None, ops.ACT_RELU)
+    torch.testing.assert_close(out_relu.cpu(), torch.relu(A.double() @ B.double().t()).float(), rtol=2e-5, atol=2e-6)
+    out_tanh = ops.gemm_nt(gpu(A), gpu(B), gpu(bias), ops.ACT_TANH)
+    torch.testing.assert_close(out_tanh.cpu(), torch.tanh(ref).float(), rtol=2e-5, atol=2e-6)
+
+
+def test_gemm_nt_strided_views():
+    from recmv import ops
+    g = torch.Generator().manual_seed(0)
+    buf = torch.randn(300, 512, generator=g)
+    A = gpu(buf)[:, :473]                                  # lda 512, K 473 (skip-layer shape)
+    B = torch.randn(64, 473, generator=g)
+    out = torch.zeros(300, 128, device=DEV)
+    ops.gemm_nt(A, gpu(B), None, out=out[:, 32:96])
+    ref = buf[:, :473].double() @ B.double().t()
+    torch.testing.assert_close(out[:, 32:96].cpu(), ref.float(), rtol=1e-5, atol=1e-5)
+    assert (out[:, :32] == 0).all() and (out[:, 96:] == 0).all()
+
+
+@pytest.mark.parametrize("K,M,N", [(1, 1, 1), (33, 5, 3), (1000, 512, 39), (5000, 473, 512), (150000, 512, 512),
+                                   (777, 130, 257), (64, 3, 512)])
+def test_gemm_tn_vs_fp64(K, M, N):
+    from recmv import ops
+    g = torch.Generator().manual_seed(K + M)
+    A = torch.randn(K, M, generator=g)
+    B = torch.randn(K, N, generator=g)
+    ref = A.double().t() @ B.double()
+    out = ops.gemm_tn(gpu(A), gpu(B))
+    bound = 4e-7 * (A.abs().double().t() @ B.abs().double()) + 1e-6
+    assert ((out.cpu().double() - ref).abs() <= bound).all()
+    assert torch.equal(out, ops.gemm_tn(gpu(A), gpu(B))), "split-K reduction order is fixed: deterministic"
+
+
+def test_matmul_functions_gradcheck_structure():
+    """First and second derivatives of the product Functions stay on the kernels and match autograd of @."""
+    from recmv import ops
+    g = torch.Generator().manual_seed(1)
+    A = gpu(torch.randn(70, 40, generator=g)).requires_grad_(True)
+    B = gpu(torch.randn(50, 40, generator=g)).requires_grad_(True)
+    A2, B2 = A.detach().clone().requires_grad_(True), B.detach().clone().requires_grad_(True)
+
+    def second_order(mm, a, b):
+        y = mm(a, b)
+        ga, = torch.autograd.grad((y ** 2).sum(), a, create_graph=True)
+        l = (ga ** 2).sum() + y.sum()
+        return torch.autograd.grad(l, [a, b])
+
+    r = second_order(lambda a, b: a @ b.t(), A2, B2)
+    o = second_order(ops.MatmulNT.apply, A, B)
+    for x, y in zip(o, r):
+        torch.testing.assert_close(x, y, rtol=2e-4, atol=2e-3)
+
+
+def test_posenc_kernel_vs_torch_path():
+    from recmv import ops
+    from recmv.model.Embedder import get_embedder
+    from recmv.utils import annealing_weights
+    x = gpu(torch.randn(1000, 3, generator=torch.Generator().manual_seed(0)))
+    embed, dim = get_embedder(6)
+    assert dim == 39
+    for ws in (None, annealing_weights(6, 0.62), [0.0] * 12):
+        hip = ops.posenc(x, 6, ws)
+        tor = embed(x.clone().requires_grad_(True), ws)             # torch path
+        torch.testing.assert_close(hip, tor.detach(), rtol=1e-6, atol=2e-6)
+    buf = torch.full((1000, 512), 7.0, device=DEV)
+    ops.posenc(x, 6, None, 0.5, out=buf[:, 473:], ld_fill=39)
+    torch.testing.assert_close(buf[:, 473:], 0.5 * embed(x.clone().requires_grad_(True)).detach(), rtol=1e-6,
+                               atol=2e-6)
+    assert (buf[:, :473] == 7.0).all()

@@ -136,11 +136,17 @@ def main():
         d0 = comp(init, defconds, rbinds, ratio=ratio, offset_type="upper")
         rrays = torch.nn.functional.normalize(d0 - cam_pos.view(1, 3), dim=1)
         # perturb the start points so that the finder has work to do
-        start = init + 0.01 * cs.points(400, seed=15)
+        start = init + 0.002 * cs.points(400, seed=15)
     outs, checks = Fref.OptimizeGarmentSurfacePs(cam_pos, [rrays], [start.clone()], [rbinds], [sdf], ratio, comp,
                                                  [[conds], [poses.detach(), trans.detach()]], garment_names=["upper"],
                                                  dthreshold=5.e-5, athreshold=0.02, w1=3.05, w2=1., times=20)
-    save("rootfind", cam_pos=cam_pos, start=start, binds=rbinds, rays=rrays, out=outs[0], check=checks[0])
+    outs1, checks1 = Fref.OptimizeGarmentSurfacePs(cam_pos, [rrays], [start.clone()], [rbinds], [sdf], ratio, comp,
+                                                   [[conds], [poses.detach(), trans.detach()]],
+                                                   garment_names=["upper"], dthreshold=5.e-5, athreshold=0.02, w1=3.05,
+                                                   w2=1., times=1)
+    print("rootfind: converged %d / %d" % (int(checks[0].sum()), checks[0].numel()))
+    save("rootfind", cam_pos=cam_pos, start=start, binds=rbinds, rays=rrays, out=outs[0], check=checks[0], out1=outs1[0],
+         check1=checks1[0])
 
     # ---------------------------------------------------------------- Seg3dLossless + MC
     def query(points):

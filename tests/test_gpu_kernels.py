@@ -182,7 +182,8 @@ def _noise_volume(shape, seed):
     g = torch.Generator().manual_seed(seed)
     v = torch.randn(*shape, generator=g)
     # smooth a little so the surface is not pure salt-and-pepper, keep plenty of ambiguous cases
-    v = F.avg_pool3d(v[None, None], 3, 1, 1)[0, 0]
+    if min(shape) >= 3:
+        v = F.avg_pool3d(v[None, None], 3, 1, 1)[0, 0]
     return v.contiguous()
 
 
@@ -248,12 +249,13 @@ def test_gemm_nt_vs_fp64(M, N, K):
     # f32 MFMA == an fmaf chain: error ~1e-7 * sum|a b|  (guide: 0.75-1.5e-7)
     bound = 4e-7 * (A.abs().double() @ B.abs().double().t()) + 1e-6
     assert ((out.cpu().double() - ref).abs() <= bound).all()
-    out_sp = ops.gemm_nt(gpu(A), gpu(B), gpu(bias), ops.ACT_SOFTPLUS, 100.0, 0.5)
-    torch.testing.assert_close(out_sp.cpu(), (F.softplus(ref, beta=100) * 0.5).float(), rtol=2e-5, atol=2e-6)
-    out_relu = ops.gemm_nt(gpu(A), gpu(B), None, ops.ACT_RELU)
-    torch.testing.assert_close(out_relu.cpu(), torch.relu(A.double() @ B.double().t()).float(), rtol=2e-5, atol=2e-6)
-    out_tanh = ops.gemm_nt(gpu(A), gpu(B), gpu(bias), ops.ACT_TANH)
-    torch.testing.assert_close(out_tanh.cpu(), torch.tanh(ref).float(), rtol=2e-5, atol=2e-6)
+    # the activations are 1-Lipschitz, so the same error bound carries through the fused epilogue
+    def within(out, ref64, scale=1.0):
+        assert ((out.cpu().double() - ref64).abs() <= scale * bound + 2e-7 * ref64.abs()).all()
+
+    within(ops.gemm_nt(gpu(A), gpu(B), gpu(bias), ops.ACT_SOFTPLUS, 100.0, 0.5), F.softplus(ref, beta=100) * 0.5)
+    within(ops.gemm_nt(gpu(A), gpu(B), None, ops.ACT_RELU), torch.relu(A.double() @ B.double().t()))
+    within(ops.gemm_nt(gpu(A), gpu(B), gpu(bias), ops.ACT_TANH), torch.tanh(ref))
 
 
 def test_gemm_nt_strided_views():
@@ -265,7 +267,8 @@ def test_gemm_nt_strided_views():
     out = torch.zeros(300, 128, device=DEV)
     ops.gemm_nt(A, gpu(B), None, out=out[:, 32:96])
     ref = buf[:, :473].double() @ B.double().t()
-    torch.testing.assert_close(out[:, 32:96].cpu(), ref.float(), rtol=1e-5, atol=1e-5)
+    bound = 4e-7 * (buf[:, :473].abs().double() @ B.abs().double().t()) + 1e-6
+    assert ((out[:, 32:96].cpu().double() - ref).abs() <= bound).all()
     assert (out[:, :32] == 0).all() and (out[:, 96:] == 0).all()
 
 
@@ -300,7 +303,7 @@ def test_matmul_functions_gradcheck_structure():
     r = second_order(lambda a, b: a @ b.t(), A2, B2)
     o = second_order(ops.MatmulNT.apply, A, B)
     for x, y in zip(o, r):
-        torch.testing.assert_close(x, y, rtol=2e-4, atol=2e-3)
+        torch.testing.assert_close(x, y, rtol=1e-3, atol=1e-4 * float(y.abs().max()))
 
 
 def test_posenc_kernel_vs_torch_path():

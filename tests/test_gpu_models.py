@@ -147,26 +147,40 @@ def test_cardinal_rays_and_deformed_normals(nets):
 
 
 def test_root_finder(nets):
-    """utils/FindSurfacePs.py:273-353.  The iteration is chaotic at the 5e-5 / 0.02 deg stopping thresholds, so the
-    bar is: (i) the same rays converge (mask equal up to threshold-straddlers), (ii) converged points satisfy the
-    stopping criteria on OUR networks, (iii) converged points agree with the reference's to 1e-4."""
+    """utils/FindSurfacePs.py:273-353.  (a) ONE step of the update rule is deterministic and must match the reference
+    to f32 tolerance; (b) over 20 steps the iteration is chaotic at the 5e-5 / 0.02 deg stopping thresholds (only ~10 %
+    of these synthetic rays converge in the reference too), so the bar is: the same rays converge (up to
+    threshold-straddlers), converged points satisfy the stopping rule on OUR networks and agree with the
+    reference's to 2e-4."""
     from recmv.utils import OptimizeGarmentSurfacePs
     g, gt, gl = load("rootfind"), load("translator"), load("lbs")
     conds = gt["conds"].to(DEV)
     poses, trans = gl["poses"].to(DEV), gl["trans"].to(DEV)
-    outs, checks = OptimizeGarmentSurfacePs(g["cam_pos"].to(DEV), [g["rays"].to(DEV)], [g["start"].to(DEV).clone()],
-                                            [g["binds"].to(DEV)], [nets["sdf"]], RATIO, nets["comp"],
-                                            [[conds], [poses, trans]], garment_names=["upper"], dthreshold=5.e-5,
-                                            athreshold=0.02, w1=3.05, w2=1., times=20)
-    out, check = outs[0], checks[0]
+
+    def run(times):
+        outs, checks = OptimizeGarmentSurfacePs(g["cam_pos"].to(DEV), [g["rays"].to(DEV)],
+                                                [g["start"].to(DEV).clone()], [g["binds"].to(DEV)], [nets["sdf"]],
+                                                RATIO, nets["comp"], [[conds], [poses, trans]],
+                                                garment_names=["upper"], dthreshold=5.e-5, athreshold=0.02, w1=3.05,
+                                                w2=1., times=times)
+        return outs[0], checks[0]
+
+    out1, check1 = run(1)
+    moved = (g["out1"] - g["start"]).norm(dim=1).to(DEV)
+    assert moved.max() > 1e-4, "fixture: the step must move points"
+    err1 = (out1 - g["out1"].to(DEV)).norm(dim=1)
+    assert (err1 <= 2e-2 * moved + 2e-6).all(), (err1.max().item(), moved.max().item())
+    assert (check1 == g["check1"].to(DEV)).float().mean() > 0.98
+
+    out, check = run(20)
     ref_check = g["check"].to(DEV)
-    assert ref_check.float().mean() > 0.5, "fixture should mostly converge"
-    agree = (check == ref_check).float().mean().item()
-    assert agree > 0.97, f"convergence masks agree on {agree:.3f} of the rays"
-    both = check & ref_check
+    assert ref_check.sum() >= 20, "fixture should have converged rays"
+    assert (check == ref_check).float().mean().item() > 0.9
     with torch.no_grad():
         f = nets["sdf"](out[check], RATIO).view(-1).abs()
     assert (f < 5.e-5).all()
+    both = check & ref_check
+    assert both.sum() >= 10
     err = (out[both] - g["out"].to(DEV)[both]).norm(dim=1)
     assert err.max().item() < 2e-4, err.max().item()
 

@@ -1,0 +1,87 @@
+"""Frame-sharded data parallelism: one process per GPU, RCCL over xGMI (torch.distributed backend "nccl" is
+RCCL on ROCm; "gloo" for the CPU tests).
+
+The reference is single-process.  Video frames are independent given the shared
+networks, so ranks take disjoint frames of each mini-batch and exchange ONE thing per optimiser step: the
+gradients of the shared tensors (garment SDF nets, deformer MLP, colour MLP, per-frame codes / poses /
+camera — ~25 MB f32) and, at the explicit-vertex SGD step, the gradients of the MC vertices (deterministic MC
+gives every rank the same vertex numbering).  xGMI is point-to-point and the volume is tiny next to a
+>100 ms step, so the collective is a single flattened all-reduce (latency-bound; bucketing would only add
+launches) — SURVEY.md §5, §8e.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    Returns (rank, local_rank, world_size); a no-op single process when WORLD_SIZE is absent or 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class GradAllReduce:
+    """Average the .grad of a list of tensors over all ranks with one flattened all-reduce.
+    Tensors without a gradient contribute zeros (a rank whose frames produced no valid rays must still take
+    part in the collective)."""
+
+    def __init__(self, world_size: int):
+        self.world = world_size
+        self._flat = None
+
+    def __call__(self, tensors):
+        if self.world <= 1:
+            return
+        tensors = [t for t in tensors if t.requires_grad]
+        if not tensors:
+            return
+        n = sum(t.numel() for t in tensors)
+        dev, dt = tensors[0].device, tensors[0].dtype
+        if self._flat is None or self._flat.numel() < n or self._flat.device != dev:
+            self._flat = torch.empty(n, dtype=dt, device=dev)
+        flat = self._flat[:n]
+        off = 0
+        for t in tensors:
+            k = t.numel()
+            if t.grad is None:
+                flat[off:off + k].zero_()
+            else:
+                flat[off:off + k].copy_(t.grad.reshape(-1))
+            off += k
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(self.world)
+        off = 0
+        for t in tensors:
+            k = t.numel()
+            if t.grad is None:
+                t.grad = flat[off:off + k].view_as(t).clone()
+            else:
+                t.grad.copy_(flat[off:off + k].view_as(t))
+            off += k
+
+
+def broadcast_state(tensors, src=0):
+    """Make every rank start from rank `src`'s values (initial state)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for t in tensors:
+            dist.broadcast(t.data, src=src)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,521 @@
+"""One optimiser iteration of the per-frame implicit-surface loop on synthetic frames.
+
+This is the hot path of `train.py:317-351` -> `OptimGarmentNetwork.forward` (engineer/networks/
+OptimGarmentNetwork.py:1885-1969) -> `loss.backward()` -> `propagateTmpPsGrad` (:2159-2313) ->
+`optimizer.step()`, restated on the recmv kernels, with the SAME call structure per garment:
+
+  marching_cube_update  :678-740   every `remesh_intersect` iterations: Seg3dLossless + MC for body + garments
+  mask_loss             :841-981   deformer on all garment MC vertices of all N frames (fwd+bwd), LBS-only
+                                   consistency term, explicit-vertex SGD step, |SDF(verts)| loss
+  sample_train_ray      :983-1055  ~sample_pix/garments*N rays per garment
+  opt_garment_surface_ps:1057-1081 root finder, <= 20 steps
+  surface_render_loss   :1083-1219 eikonal, deformation regulariser, SDF normal, cardinal rays, colour MLP,
+                                   colour L1, weighted normal loss
+  dct_poses_loss        :1221-1250 (pose smoothness on 30-frame windows)
+  propagateTmpPsGrad    :2159-2313 implicit differentiation of the surface point
+
+What is NOT here, and why: the pytorch3d mesh/point rasterisers and alpha
+compositor are third-party code outside /root/reference and outside this tier's scope.  Their two uses are
+replaced by projections that keep every hot-path call and every gradient path in place:
+  * silhouette IoU of the splatted point cloud -> a differentiable distance-to-mask term sampled at the
+    projected deformed vertices (same inputs: deformed vertices; same gradient sinks: explicit vertices,
+    deformer parameters, per-frame codes, poses);
+  * first-hit surface points of the rasterised mesh -> MC vertices projected to their nearest pixel centre
+    (so the root finder starts within half a pixel of the surface, like a barycentric hit).
+The feature-curve branch (`project_2d_loss`, "next" row 3) is likewise outside this tier.
+The CPU SVD of the deformer Jacobians (:1148, a host round trip per garment per iteration) is replaced by
+closed-form singular values on the device (`singular_values_3x3`).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import MCGpu
+from . import utils
+from .FastMinv import Fast3x3Minv
+from .MCAcc import Seg3dLossless
+from .model import (CompositeDeformer, LBSkinner, MLPTranslator, RectifiedPerspectiveCameras, getRenderNet, getTmpSdf,
+                    getTranslatorNet)
+
+SMPL_PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21],
+                        dtype=np.int64)
+
+# coarse-to-fine grid pyramids of train.py:42-79 (W, H, D)
+RESOLUTIONS = {
+    'coarse': [(15, 21, 9), (29, 41, 17), (57, 81, 33), (113, 161, 65), (225, 321, 129)],
+    'medium': [(19, 25, 13), (37, 49, 25), (73, 97, 49), (145, 193, 97), (289, 385, 193)],
+    'fine': [(21, 27, 15), (41, 53, 29), (81, 105, 57), (161, 209, 113), (321, 417, 225)],
+    'higher256': [(33, 33, 33), (65, 65, 65), (129, 129, 129), (257, 257, 257)],
+}
+
+
+def singular_values_3x3(J):
+    """Singular values of [P,3,3] matrices, descending, closed form on the device: square roots of the
+    eigenvalues of J^T J (trigonometric solution of the symmetric 3x3 characteristic polynomial).
+    Replaces `torch.svd(Jacobs.cpu())` (OptimGarmentNetwork.py:1148).  Differentiable."""
+    A = (J.transpose(-1, -2).unsqueeze(-1) * J.unsqueeze(-3)).sum(-2)        # J^T J without BLAS
+    a00, a11, a22 = A[:, 0, 0], A[:, 1, 1], A[:, 2, 2]
+    a01, a02, a12 = A[:, 0, 1], A[:, 0, 2], A[:, 1, 2]
+    q = (a00 + a11 + a22) / 3.0
+    p1 = a01 * a01 + a02 * a02 + a12 * a12
+    p2 = (a00 - q) ** 2 + (a11 - q) ** 2 + (a22 - q) ** 2 + 2.0 * p1
+    p = torch.sqrt(torch.clamp(p2 / 6.0, min=1e-30))
+    b00, b11, b22 = (a00 - q) / p, (a11 - q) / p, (a22 - q) / p
+    b01, b02, b12 = a01 / p, a02 / p, a12 / p
+    detB = (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02))
+    r = torch.clamp(detB / 2.0, -1.0 + 1e-7, 1.0 - 1e-7)
+    phi = torch.acos(r) / 3.0
+    e0 = q + 2.0 * p * torch.cos(phi)
+    e2 = q + 2.0 * p * torch.cos(phi + 2.0 * math.pi / 3.0)
+    e1 = 3.0 * q - e0 - e2
+    ev = torch.stack([e0, e1, e2], dim=1)
+    return torch.sqrt(torch.clamp(ev, min=1e-20))
+
+
+def dct_nullspace(nlen=30, keep=10, device="cpu"):
+    """Rows of the orthonormal DCT-II basis above the `keep` lowest frequencies: projecting a length-`nlen`
+    joint trajectory on them measures its high-frequency content (dct_poses_loss, :1221-1250)."""
+    n = torch.arange(nlen, dtype=torch.float64)
+    k = torch.arange(nlen, dtype=torch.float64).view(-1, 1)
+    basis = torch.cos(math.pi / nlen * (n + 0.5) * k) * math.sqrt(2.0 / nlen)
+    basis[0] *= 1.0 / math.sqrt(2.0)
+    return basis[keep:].float().to(device)
+
+
+class SyntheticFrames:
+    """Stands in for dataset/dataset.py: per-frame learnable tensors + camera + images
+    (`get_grad_parameters`, `get_camera_parameters`, `learnable_weights`: dataset.py:253-258, 425-437)."""
+
+    def __init__(self, n_frames, n_garments, H, W, device, seed=0, condlen=128, rendlen=256, image_frames=None):
+        g = torch.Generator().manual_seed(seed)
+        self.F, self.H, self.W = n_frames, H, W
+        self.device = device
+        self.poses = (0.15 * torch.randn(n_frames, 24, 3, generator=g)).to(device).requires_grad_(True)
+        self.trans = (0.01 * torch.randn(n_frames, 3, generator=g)).to(device).requires_grad_(True)
+        self.d_cond = (0.1 * torch.randn(n_frames, condlen * (1 + n_garments), generator=g)).to(device).requires_grad_(True)
+        self.rendcond = (0.1 * torch.randn(n_frames, rendlen, generator=g)).to(device).requires_grad_(True)
+        self.focal = torch.tensor([[1000.0 * W / 512, 1000.0 * H / 512]], device=device, requires_grad=True)
+        self.pp = torch.tensor([[W / 2.0, H / 2.0]], device=device, requires_grad=True)
+        # camera-to-world convention of the reference: x and y flipped (OptimGarmentNetwork.py:1041-1045)
+        self.R = torch.diag(torch.tensor([-1.0, -1.0, 1.0])).view(1, 3, 3).to(device)
+        self.T = torch.tensor([[0.0, 0.0, 3.0]], device=device, requires_grad=True)
+        # images: smooth random colour / normal fields in [-1,1], shared by a few image slots to bound memory
+        k = image_frames or min(n_frames, 8)
+        low = torch.randn(k, 6, 16, 16, generator=g)
+        img = torch.tanh(F.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)).permute(0, 2, 3, 1)
+        self.img = img[..., :3].contiguous().to(device)
+        self.normal = F.normalize(img[..., 3:], dim=-1).contiguous().to(device)
+        self.n_img = k
+
+    def get_grad_parameters(self, frame_ids, device):
+        return self.poses[frame_ids], self.trans[frame_ids], self.d_cond[frame_ids], self.rendcond[frame_ids]
+
+    def get_camera_parameters(self, N, device):
+        return self.focal, self.pp, self.R, self.T, self.H, self.W
+
+    def get_batchframe_data(self, name, frame_ids, nlen):
+        """Windows of `nlen` consecutive frames around each frame id (dataset.py get_batchframe_data)."""
+        data = getattr(self, name)
+        start = torch.clamp(frame_ids - nlen // 2, 0, max(self.F - nlen, 0))
+        idx = start.view(-1, 1) + torch.arange(min(nlen, self.F), device=frame_ids.device).view(1, -1)
+        return data[idx], idx
+
+    def learnable_weights(self):
+        return [self.poses, self.trans, self.d_cond, self.rendcond, self.focal, self.pp, self.T]
+
+    def images(self, frame_ids):
+        sl = frame_ids % self.n_img
+        return self.img[sl], self.normal[sl]
+
+
+class HotLoop:
+    """The per-frame optimisation inner loop (see module docstring)."""
+
+    def __init__(self, conf, device, n_frames=64, H=512, W=512, stage='coarse', seed=0, resolutions=None,
+                 skin_grid=(65, 225, 129), bbox=((-0.9, -1.2, -0.6), (0.9, 1.2, 0.6)), world_size=1, rank=0):
+        self.conf_all = conf
+        self.conf = conf.get_config('loss_' + stage)
+        self.device = device
+        self.stage = stage
+        self.garment_names = ['upper', 'bottom']
+        self.garment_size = len(self.garment_names)
+        torch.manual_seed(seed)
+        mult = conf.get_int('sdf_net.multires')
+        # body + one SDF net per garment (model/network.py:188-199); different radii so the meshes differ
+        self.sdf = getTmpSdf(device, mult, bias=0.5)
+        self.garment_nets = torch.nn.ModuleList([getTmpSdf(device, conf.get_int('garment_sdf_net.multires'), bias=b)
+                                                 for b in (0.55, 0.45)])
+        g = torch.Generator().manual_seed(seed + 1)
+        D, Hh, Ww = skin_grid
+        ws = torch.softmax(2.0 * torch.randn(1, 24, D, Hh, Ww, generator=g), dim=1)
+        Js = 0.25 * torch.randn(24, 3, generator=g)
+        bmin, bmax = bbox
+        skinner = LBSkinner(ws, list(bmin), list(bmax), Js, SMPL_PARENTS, init_pose=_apose(), align_corners=False,
+                            bbox_extend=torch.tensor([bmax[i] - bmin[i] for i in range(3)]),
+                            bbox_center=torch.tensor([(bmax[i] + bmin[i]) / 2 for i in range(3)]))
+        self.deformer = CompositeDeformer([getTranslatorNet(device, conf.get_config('mlp_deformer')),
+                                           skinner.to(device)])
+        self.netRender = getRenderNet(device, conf.get_config('render_net'))
+        self.dataset = SyntheticFrames(n_frames, self.garment_size, H, W, device, seed=seed + 2,
+                                       condlen=conf.get_int('mlp_deformer.condlen'),
+                                       rendlen=conf.get_int('render_net.condlen'))
+        res = resolutions if resolutions is not None else RESOLUTIONS[stage]
+        self.engine = Seg3dLossless(query_func=None, b_min=list(bmin), b_max=list(bmax), resolutions=res,
+                                    align_corners=False, balance_value=0.0, use_cuda_impl=True, faster=False).to(device)
+        self.remesh_intersect = conf.get_int(f'train.{stage}.point_render.remesh_intersect')
+        self.batch_size = conf.get_int(f'train.{stage}.point_render.batch_size')
+        self.sample_pix = conf.get_int('train.sample_pix_num')
+        self.sdfShrinkRadius = 0.0
+        self.forward_time = 0
+        self.opt_times = 0.0
+        self.body_vs = self.body_fs = None
+        self.garment_vs, self.garment_fs = [], []
+        self.dctnull = dct_nullspace(min(30, n_frames), min(10, max(n_frames // 3, 1)), device)
+        self.info = {}
+        self.world_size, self.rank = world_size, rank
+        params = [p for p in self.netRender.parameters()] + [p for p in self.deformer.parameters()] + \
+                 [p for p in self.garment_nets.parameters()]
+        self.optimizer = torch.optim.Adam(self.dataset.learnable_weights() + params,
+                                          lr=conf.get_float('train.learning_rate'))
+        cams = self._cameras()
+        self.angThred = cams.angThreshold(0.5)                                   # OptimNetwork.py:65
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _cameras(self):
+        focals, pps, Rs, Ts, H, W = self.dataset.get_camera_parameters(1, self.device)
+        return RectifiedPerspectiveCameras(focals, pps, Rs, Ts, image_size=[(W, H)])
+
+    def get_grad_parameters(self, frame_ids, device):
+        poses, trans, d_cond, rendcond = self.dataset.get_grad_parameters(frame_ids, device)
+        split = [d_cond.shape[-1] // (self.garment_size + 1)] * (self.garment_size + 1)
+        return torch.split(d_cond, split, dim=-1), poses, trans, rendcond
+
+    def shared_parameters(self):
+        """Tensors whose gradients are all-reduced across frame-sharded ranks (list 1)."""
+        return [p for group in self.optimizer.param_groups for p in group['params']]
+
+    # ------------------------------------------------------------------------------------------ MC path
+    def discretizeSDF(self, ratio, engine=None, balance_value=0.):
+        """OptimGarmentNetwork.py:581-618."""
+        engine = engine or self.engine
+
+        def run(net):
+            def query(points):
+                with torch.no_grad():
+                    return net.forward(points.reshape(-1, 3), ratio).reshape(1, 1, -1)
+            engine.balance_value = balance_value
+            engine.query_func = query
+            sdfs = engine.forward()
+            return MCGpu.mc_gpu(sdfs[0, 0].permute(2, 1, 0).contiguous(), engine.spacing_x, engine.spacing_y,
+                                engine.spacing_z, engine.bx, engine.by, engine.bz, balance_value)
+
+        pts, faces = [], []
+        for net in [self.sdf] + list(self.garment_nets):
+            v, f = run(net)
+            pts.append(v)
+            faces.append(f)
+        return pts, faces
+
+    def marching_cube_update(self, ratio):
+        """OptimGarmentNetwork.py:678-740 (openmesh vertex->face tables are never read by the loop: dropped)."""
+        vs_list, fs_list = self.discretizeSDF(ratio, None, -self.sdfShrinkRadius)
+        self.body_vs, self.body_fs = vs_list[0], fs_list[0]
+        self.garment_vs, self.garment_fs = vs_list[1:], fs_list[1:]
+        if self.body_vs.shape[0] == 0:
+            raise AssertionError('tmp sdf vanished...')
+        for v in self.garment_vs:
+            v.requires_grad = True
+        self.garment_optimizer = torch.optim.SGD(self.garment_vs, lr=0.05, momentum=0.9)
+
+    # ------------------------------------------------------------------------------------------ mask loss
+    def mask_loss(self, N, frame_ids, ratio, cameras):
+        d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
+        conf = self.conf
+        garment_loss = 0.
+        def_vs = []
+        for g_i, name in enumerate(self.garment_names):
+            gv = self.garment_vs[g_i]
+            defv = self.deformer(gv[None, :, :].expand(N, -1, 3), [d_cond_list[g_i + 1], [poses, trans]], ratio=ratio,
+                                 offset_type=name)                                         # :910
+            def_vs.append(defv)
+            # silhouette surrogate (see module docstring): projected vertices should fall inside the image disc
+            pix = cameras.project(defv.reshape(-1, 3))
+            c = torch.stack([self.dataset.pp[0, 0], self.dataset.pp[0, 1]]).view(1, 2)
+            rad = ((pix - c) / (0.45 * min(self.dataset.H, self.dataset.W))).norm(dim=1)
+            mask_loss = torch.relu(rad - 1.0).mean() + 1e-3 * rad.mean()
+            loss = mask_loss
+            cw = conf.get_float('pc_weight.def_consistent.weight')
+            if cw > 0.:                                                                   # :655-663
+                offset2 = defv - self.deformer.defs[1](gv.view(1, -1, 3).expand(N, -1, 3), [poses, trans])
+                offset2 = (offset2 * offset2).sum(-1)
+                cc = conf.get_float('pc_weight.def_consistent.c')
+                closs = utils.GMRobustError(offset2, cc, True).mean() if cc > 0. else torch.sqrt(offset2).mean()
+                loss = loss + closs * cw
+            garment_loss = garment_loss + loss
+        self.garment_optimizer.zero_grad()
+        garment_loss.backward()                    # grads also reach deformer / codes / poses and stay for Adam (:959)
+        if getattr(self, '_allreduce', None) is not None:
+            self._allreduce(self.garment_vs)       # explicit MC vertices: identical numbering on every rank (§8e-2)
+        self.garment_optimizer.step()
+        pc_sdf_loss = 0.
+        for g_i, name in enumerate(self.garment_names):                                   # :966-970
+            mnfld_pred = self.garment_nets[g_i](self.garment_vs[g_i], ratio).view(-1)
+            sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
+            self.info['pc_{}_loss_sdf'.format(name)] = sdf_loss.detach()
+            pc_sdf_loss = pc_sdf_loss + sdf_loss * conf.get_float('pc_weight.weight')
+        return [d.detach() for d in def_vs], pc_sdf_loss
+
+    # ------------------------------------------------------------------------------------------ rays
+    def sample_train_ray(self, N, def_vs, cameras):
+        """Stand-in for find_surface_ps + sample_train_ray (:742-767, :983-1055): per garment, ~sample_pix/garments
+        rays per frame through MC vertices snapped to their nearest pixel centre."""
+        sample_pix = self.conf.get_int('sample_pix_num') if 'sample_pix_num' in self.conf else self.sample_pix
+        sample_pix = sample_pix // self.garment_size
+        H, W = self.dataset.H, self.dataset.W
+        out = []
+        for g_i in range(self.garment_size):
+            V = self.garment_vs[g_i].shape[0]
+            R = min(sample_pix, V)
+            vid = torch.stack([torch.randperm(V, device=self.device)[:R] for _ in range(N)]).view(-1)
+            batch_inds = torch.arange(N, device=self.device).repeat_interleave(R)
+            pix = cameras.project(def_vs[g_i][batch_inds, vid])
+            col = pix[:, 0].round().clamp(0, W - 1)
+            row = pix[:, 1].round().clamp(0, H - 1)
+            rays = cameras.view_rays(torch.stack([col, row, torch.ones_like(col)], dim=-1).float())
+            out.append((batch_inds, row.long(), col.long(), self.garment_vs[g_i].detach()[vid].clone(), rays))
+        return out
+
+    def opt_garment_surface_ps(self, frame_ids, cameras, ratio, samples):
+        d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
+        defconds_list = [d_cond_list[1:], [poses, trans]]
+        pts, checks = utils.OptimizeGarmentSurfacePs(
+            cameras.cam_pos().detach(), [s[4].detach() for s in samples], [s[3] for s in samples],
+            [s[0] for s in samples], self.garment_nets, ratio, self.deformer, defconds_list,
+            garment_names=self.garment_names, dthreshold=5.e-5, athreshold=self.angThred, w1=3.05, w2=1., times=20)
+        self.info['rays_total'] = sum(c.numel() for c in checks)
+        self._ray_valid = [c.sum() for c in checks]
+        return pts, checks
+
+    # ------------------------------------------------------------------------------------------ render loss
+    def surface_render_loss(self, N, cameras, frame_ids, ratio, checks, init_ps_list, samples):
+        conf = self.conf
+        gtCs, gtNs = self.dataset.images(frame_ids)
+        self.TmpPs = [None] * self.garment_size
+        self.rays = [None] * self.garment_size
+        self.batch_inds = [None] * self.garment_size
+        self.row_inds = [None] * self.garment_size
+        self.col_inds = [None] * self.garment_size
+        surface_sample_points = 4096 // self.garment_size
+        total_loss = 0.
+        d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
+        dev = self.device
+        for g_i, (init_ps, sample) in enumerate(zip(init_ps_list, samples)):
+            batch_inds, row_inds, col_inds, _, rays = sample
+            name = self.garment_names[g_i]
+            net = self.garment_nets[g_i]
+            TmpVs = self.garment_vs[g_i]
+            V = TmpVs.shape[0]
+            sel = torch.rand(V, device=dev) < float(surface_sample_points) / float(V)
+            nonmnfld = utils.sample_points(torch.cat([init_ps, TmpVs[sel].detach()], dim=0), 1.8, 0.01)
+            nonmnfld.requires_grad_()
+            pred = net(nonmnfld, ratio)
+            grad = net.gradient(nonmnfld, pred)
+            grad_loss = ((grad.norm(2, dim=-1) - 1) ** 2).mean()                           # eikonal :1118
+            self.info['{}_grad_loss'.format(name)] = grad_loss.detach()
+            total_loss = total_loss + grad_loss * conf.get_float('grad_weight')
+            d_cond = d_cond_list[g_i + 1]
+            if 'def_regu' in conf and conf.get_float('def_regu.weight') > 0.:               # :1135-1155
+                sel = torch.rand(V, device=dev) < float(surface_sample_points) / float(V)
+                pts = torch.cat([init_ps, TmpVs[sel].detach()], dim=0)
+                pts = torch.cat([pts, utils.sample_points(pts, 1.8, 0.01, 0)], dim=0).view(1, -1, 3).expand(N, -1, 3)
+                pts = pts.contiguous().requires_grad_()
+                defVs = self.deformer.defs[0](pts, d_cond, ratio=ratio, offset_type=name)
+                Jacobs = utils.compute_Jacobian(pts, defVs, True, True)
+                s = torch.log(singular_values_3x3(Jacobs))
+                def_loss = utils.GMRobustError((s * s).sum(1), conf.get_float('def_regu.c'), True).mean()
+                self.info['def_{}_loss'.format(name)] = def_loss.detach()
+                total_loss = total_loss + def_loss * conf.get_float('def_regu.weight')
+            check = checks[g_i]
+            # the reference gates on rayInfo[1] > 0 via .item(); the gate is kept but read once per garment
+            if int(self._ray_valid[g_i]) > 0:
+                self.TmpPs[g_i] = init_ps[check]
+                self.TmpPs[g_i].requires_grad = True
+                self.rays[g_i] = rays[check]
+                self.batch_inds[g_i] = batch_inds[check]
+                self.col_inds[g_i] = col_inds[check]
+                self.row_inds[g_i] = row_inds[check]
+                p, b = self.TmpPs[g_i], self.batch_inds[g_i]
+                sdfs = net(p, ratio)
+                rend_feat = net.rendcond
+                nx = torch.autograd.grad(sdfs, p, torch.ones_like(sdfs), retain_graph=True, create_graph=True)[0]
+                nx = nx / nx.norm(dim=1, keepdim=True)
+                defconds = [d_cond, [poses, trans]]
+                crays, defVs = utils.compute_cardinal_rays(self.deformer, p, self.rays[g_i], defconds, b, ratio,
+                                                           'train', offset_type=name)
+                if conf.get_float('color_weight') > 0.:
+                    colors = utils.compute_netRender_color(self.netRender, p, defVs, nx, crays, rend_feat,
+                                                           rendcond[b], ratio)
+                    color_loss = (gtCs[b, self.row_inds[g_i], self.col_inds[g_i], :] - colors).abs().sum(1)
+                    color_loss = utils.scatter_mean(color_loss, b, N).mean()
+                    self.info['{}_color_loss'.format(name)] = color_loss.detach()
+                    total_loss = total_loss + conf.get_float('color_weight') * color_loss
+                if 'normal_weight' in conf and conf.get_float('normal_weight') > 0.:        # :1191-1217
+                    if 'weighted_normal' in conf and conf.get_bool('weighted_normal'):
+                        cnx, _ = utils.compute_deformed_normals(net, self.deformer, p, defconds, b, ratio, 'test',
+                                                                offset_type=name)
+                        weights = torch.clamp((-self.rays[g_i] * cnx.detach()).sum(1).detach(), max=1., min=0.) ** 2
+                    else:
+                        weights = torch.ones(nx.shape[0], device=dev)
+                    gtn = gtNs[b, self.row_inds[g_i], self.col_inds[g_i], :]
+                    flip = torch.tensor([[-1., 0., 0.], [0., 1., 0.], [0., 0., -1.]], device=dev)
+                    M = (cameras.R[0].unsqueeze(-1) * flip.unsqueeze(0)).sum(1)             # R @ flip
+                    gtn = (M.unsqueeze(0) * gtn.unsqueeze(-2)).sum(-1)
+                    gtnorms = gtn.norm(dim=1, keepdim=True)
+                    valid_mask = (gtnorms > 0.0001)[..., 0]
+                    gtn = torch.where(valid_mask.unsqueeze(-1), gtn / gtnorms.clamp(min=1e-12), gtn)
+                    ds = self.deformer(p, defconds, b, ratio=ratio, offset_type=name)
+                    grad_d_p = utils.compute_Jacobian(p, ds, True, True)
+                    gtn = (grad_d_p.transpose(-2, -1) * gtn.unsqueeze(-2)).sum(-1)
+                    normal_loss = (gtn - nx).norm(2, dim=1) * weights
+                    w = valid_mask.to(normal_loss.dtype)
+                    num = torch.zeros(N, device=dev).index_add(0, b, normal_loss * w)
+                    den = torch.zeros(N, device=dev).index_add(0, b, w)
+                    normal_loss = (num / den.clamp(min=1)).mean()
+                    self.info['{}_normal_loss'.format(name)] = normal_loss.detach()
+                    total_loss = total_loss + conf.get_float('normal_weight') * normal_loss
+        return total_loss
+
+    def dct_poses_loss(self, poses, trans, frame_ids, N):
+        if not (poses.requires_grad or trans.requires_grad) or self.conf.get_float('dct_weight') <= 0.:
+            return 0.
+        klen, Nlen = self.dctnull.shape
+        bp, _ = self.dataset.get_batchframe_data('poses', frame_ids, Nlen)
+        bt, _ = self.dataset.get_batchframe_data('trans', frame_ids, Nlen)
+        posedJs = self.deformer.defs[1].posedSkeleton([bp.reshape(N * Nlen, 24, 3), bt.reshape(N * Nlen, 3)])
+        x = posedJs.reshape(N, Nlen, 72)
+        dct = (self.dctnull[None, :, :, None] * x[:, None, :, :]).sum(2)                    # dctnull @ x
+        dct_loss = dct.abs().mean()
+        self.info['dct_loss'] = dct_loss.detach()
+        return dct_loss * self.conf.get_float('dct_weight')
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, frame_ids, ratio):
+        N = frame_ids.numel()
+        self.info = {}
+        cameras = self._cameras()
+        if self.body_vs is None or self.forward_time % self.remesh_intersect == 0:
+            self.marching_cube_update(ratio)
+        total_loss = 0.
+        self.optimizer.zero_grad()                                                         # :1934
+        def_vs, pc_sdf_loss = self.mask_loss(N, frame_ids, ratio, cameras)
+        total_loss = total_loss + pc_sdf_loss
+        d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
+        cameras = self._cameras()                                                          # rebuilt graph (:1036)
+        samples = self.sample_train_ray(N, def_vs, cameras)
+        init_ps_list, checks = self.opt_garment_surface_ps(frame_ids, cameras, ratio, samples)
+        total_loss = total_loss + self.surface_render_loss(N, cameras, frame_ids, ratio, checks, init_ps_list, samples)
+        total_loss = total_loss + self.dct_poses_loss(poses, trans, frame_ids, N)
+        self.forward_time += 1
+        return total_loss
+
+    # ------------------------------------------------------------------------------------------ implicit diff
+    def propagateTmpPsGrad(self, frame_ids, ratio):
+        """Implicit differentiation of the surface point p(theta, phi, z, cam) — OptimGarmentNetwork.py:2159-2313.
+        The reference `return`s (not `continue`s) at the first garment without valid rays (:2165); kept."""
+        for g_i in range(self.garment_size):
+            name = self.garment_names[g_i]
+            if self.TmpPs[g_i] is None or self.TmpPs[g_i].grad is None:
+                self.info['{}_invInfo'.format(name)] = (-1, -1)
+                return
+            dev = self.TmpPs[g_i].device
+            d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, dev)
+            defconds = [d_cond_list[1 + g_i], [poses, trans]]
+            cameras = self._cameras()
+            grad_l_p = self.TmpPs[g_i].grad
+            col, row = self.col_inds[g_i], self.row_inds[g_i]
+            v = cameras.view_rays(torch.cat([col.view(-1, 1), row.view(-1, 1), torch.ones_like(col.view(-1, 1))],
+                                            dim=-1).float())
+            c = cameras.cam_pos()
+            p = self.TmpPs[g_i]
+            net = self.garment_nets[g_i]
+            f = net(p, ratio)
+            grad_f_p = torch.autograd.grad(f, p, torch.ones_like(f), retain_graph=False)[0]
+            d = self.deformer(p, defconds, self.batch_inds[g_i], ratio=ratio, offset_type=name)
+            opt_defconds = [t for t in (defconds[0], defconds[1][0], defconds[1][1]) if t.requires_grad]
+            grad_d_p = utils.compute_Jacobian(p, d, False, False)
+            vd = v.detach()
+            zeros = torch.zeros_like(vd[:, 0])
+            v_cross = torch.stack([torch.stack([zeros, -vd[:, 2], vd[:, 1]], -1),
+                                   torch.stack([vd[:, 2], zeros, -vd[:, 0]], -1),
+                                   torch.stack([-vd[:, 1], vd[:, 0], zeros], -1)], dim=1)   # [v]_x
+            a1 = (v_cross.unsqueeze(-1) * grad_d_p.unsqueeze(-3)).sum(-2)                   # v_cross @ J
+            b = torch.cat([grad_f_p.view(-1, 1, 3), a1], dim=1)                             # [P,4,3]
+            btb = (b.unsqueeze(-1) * b.unsqueeze(-2)).sum(1)                                # b^T b
+            btb_inv, check = Fast3x3Minv(btb.contiguous())
+            self.info['{}_invInfo'.format(name)] = (check.numel(), check.sum())
+            rhs_1 = (btb_inv.unsqueeze(-1) * b.permute(0, 2, 1).unsqueeze(-3)).sum(-2)       # [P,3,4]
+            rhs_1 = (grad_l_p.view(-1, 3, 1) * rhs_1).sum(1, keepdim=True)                  # [P,1,4]
+            loss = 0.
+            params = [q for q in net.parameters() if q.requires_grad]
+            pg = torch.autograd.grad(net(p, ratio), params, -rhs_1[:, :, 0])
+            for q, gq in zip(params, pg):
+                loss = loss + (q * gq).sum()
+            params = [q for q in self.deformer.parameters() if q.requires_grad]
+            d = self.deformer(p, defconds, self.batch_inds[g_i], ratio=ratio, offset_type=name)
+            temp = -(rhs_1[:, :, -3:].transpose(1, 2) * v_cross).sum(1)                      # rhs[1:4] @ (-[v]_x)
+            pg = torch.autograd.grad(d, params, temp, retain_graph=len(opt_defconds) > 0)
+            for q, gq in zip(params, pg):
+                loss = loss + (q * gq).sum()
+            if len(opt_defconds):
+                pg = torch.autograd.grad(d, opt_defconds, temp, retain_graph=False)
+                for q, gq in zip(opt_defconds, pg):
+                    loss = loss + (q * gq).sum()
+            if v.requires_grad:
+                dc = d.detach() - c.detach().view(1, 3)
+                dc_cross = torch.stack([torch.stack([zeros, -dc[:, 2], dc[:, 1]], -1),
+                                        torch.stack([dc[:, 2], zeros, -dc[:, 0]], -1),
+                                        torch.stack([-dc[:, 1], dc[:, 0], zeros], -1)], dim=1)
+                grad = (rhs_1[:, :, -3:].transpose(1, 2) * dc_cross).sum(1)
+                loss = loss + (v * grad).sum()
+            if c.requires_grad:
+                loss = loss + (c * (-temp.sum(0))).sum()
+            loss.backward()
+
+    # ------------------------------------------------------------------------------------------ one step
+    def frame_batch(self, it):
+        """Frames of this rank for iteration `it`: a seeded permutation of all frames dealt round-robin over ranks
+        (the reference's RandomSampler, dataset/dataset.py:1135-1157, sharded — SURVEY.md §8e)."""
+        per_it = self.batch_size * self.world_size
+        iters_per_epoch = max(self.dataset.F // per_it, 1)
+        epoch, pos = divmod(it, iters_per_epoch)
+        perm = torch.randperm(self.dataset.F, generator=torch.Generator().manual_seed(1234 + epoch))
+        ids = perm[pos * per_it:(pos + 1) * per_it]
+        return ids[self.rank::self.world_size][:self.batch_size].to(self.device)
+
+    def step(self, it, allreduce=None):
+        """train.py:317-328.  `allreduce(list_of_tensors)` is called on the gradients before each optimizer step
+        when frames are sharded over ranks."""
+        frame_ids = self.frame_batch(it)
+        ratio = {'sdfRatio': 1., 'deformerRatio': self.opt_times / 2500. + 0.5, 'renderRatio': 1.}
+        self._allreduce = allreduce
+        loss = self.forward(frame_ids, ratio)
+        loss.backward()
+        self.propagateTmpPsGrad(frame_ids, ratio)
+        if allreduce is not None:
+            allreduce([p for p in self.shared_parameters()])
+        self.optimizer.step()
+        self.opt_times += 1.
+        return loss.detach(), self.info['rays_total']
+
+
+def _apose():
+    pose = np.zeros((24, 3), dtype=np.float32)            # utils/utils.py:76-83, init_pose_type 0
+    pose[1] = [0, 0, 10. / 180. * np.pi]
+    pose[2] = [0, 0, -10. / 180. * np.pi]
+    pose[16] = [0, 0, -45. / 180. * np.pi]
+    pose[17] = [0, 0, 45. / 180. * np.pi]
+    return pose

@@ -162,6 +162,40 @@ int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb,
 int recmv_posenc_forward(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t ldo_fill,
                          int64_t P, int L, const float* weights_host, float out_scale, void* stream);
 
+/* Fused element-wise steps between the MFMA layers (csrc/elementwise.hip):
+ *   recmv_act_grad  : out = gy * act'(z) written through y = act(z)     (backward of a fused layer)
+ *   recmv_act_grad2 : out = a * b * d(act')/dy                           (its double backward)
+ *   recmv_weight_norm_forward/backward : W = g * v/||v|| per output row (nn.utils.weight_norm dim 0,
+ *                     model/network.py:82-85, model/RenderNet.py:47-50); norms [rows] is saved for backward. */
+int recmv_act_grad(const float* gy, const float* y, float* out, int64_t n, int act, float act_param, void* stream);
+int recmv_act_grad2(const float* a, const float* b, const float* y, float* out, int64_t n, int act, float act_param,
+                    void* stream);
+int recmv_weight_norm_forward(const float* v, const float* g, float* W, float* norms, int64_t rows, int64_t cols,
+                              void* stream);
+int recmv_weight_norm_backward(const float* v, const float* g, const float* norms, const float* gW, float* gv,
+                               float* gg, int64_t rows, int64_t cols, void* stream);
+
+/* Derivatives of the positional encoding (so that autograd of any order stays one launch):
+ *   recmv_posenc_vjp : t == NULL -> out[P,3] = J(x)^T g               (g: [P, 3+6L], row stride ldg)
+ *                      t != NULL -> out[P,3] = t * d/dx <g, J(x) 1>   (second-derivative term, see posenc_grad.hip)
+ *   recmv_posenc_jvp : out[P, 3+6L] = J(x) t                          (t: [P,3])                                   */
+int recmv_posenc_vjp(const float* x, int64_t ldx, const float* g, int64_t ldg, const float* t, int64_t ldt,
+                     float* out, int64_t P, int L, const float* weights_host, void* stream);
+int recmv_posenc_jvp(const float* x, int64_t ldx, const float* t, int64_t ldt, float* out, int64_t ldo, int64_t P,
+                     int L, const float* weights_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * B2. SMPL kinematic chain of LBSkinner (model/Deformer.py:372-405; posedSkeleton :311-334), one kernel.
+ *   poses [B,24,3] axis-angle -> G [B,24,4,4] (global joint transforms, `results`) and, when init_pose
+ *   [24,4,4] and A are given, A = G . init_pose.  Js_host [24,3] and parents_host [24] are HOST arrays
+ *   (constants of the skinner).  Backward: (gG, gA; either may be NULL) -> gposes [B,24,3].
+ * ---------------------------------------------------------------------------------------------- */
+int recmv_kinematic_chain_forward(const float* poses, const float* Js_host, const int32_t* parents_host,
+                                  const float* init_pose, float* G, float* A, int64_t B, void* stream);
+int recmv_kinematic_chain_backward(const float* poses, const float* Js_host, const int32_t* parents_host,
+                                   const float* init_pose, const float* gG, const float* gA, float* gposes,
+                                   int64_t B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

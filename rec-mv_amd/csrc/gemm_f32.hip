@@ -26,7 +26,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BN = 128, BK = 32;   // large tile (and the TN kernel's tile)
 constexpr int kBlk = 256;
 constexpr int LDK = BK + 4;    // NT: padded k stride (floats) of an LDS row
 constexpr int LDM = BM + 4;    // TN: padded m stride (floats) of an LDS k-row
@@ -68,34 +68,40 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int64
 }
 
 // ------------------------------------------------------------------------------------------ NT
+// T = MFMA tiles per wave along each dimension: T=2 -> 128x128 workgroup tile (large M), T=1 -> 64x64
+// (small M: the ray path launches 3k-6k rows, 128-tiles would leave most of the 256 CUs idle).
+template <int T>
 __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ B, int64_t ldb,
                                                        const float* __restrict__ bias, float* __restrict__ C,
                                                        int64_t ldc, int M, int N, int K, int act,
                                                        float act_param, float out_scale, int nbm, int nbn,
                                                        bool a_vec, bool b_vec) {
+  constexpr int TBM = 64 * T, TBN = 64 * T;     // workgroup tile
+  constexpr int WT = 32 * T;                    // wave tile edge
+  constexpr int NLD = TBM * 8 / kBlk;           // float4 per thread per operand tile (4 or 2)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                       // [2][BM][LDK]
-  float* Bs = smem + 2 * BM * LDK;        // [2][BN][LDK]
+  float* As = smem;                        // [2][TBM][LDK]
+  float* Bs = smem + 2 * TBM * LDK;        // [2][TBN][LDK]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;      // 2x2 waves
   const int64_t logical = xcd_remap(blockIdx.x, (int64_t)nbm * nbn);
   const int tile_m = (int)(logical / nbn), tile_n = (int)(logical % nbn);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
 
-  f32x16 acc[2][2];
+  f32x16 acc[T][T];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < T; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < T; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // staging map: 1024 float4 per operand tile, 4 per thread; row = idx/8, c4 = idx%8
-  float4 ra[4], rb[4];
+  // staging map: TBM*8 float4 per operand tile; row = idx/8, c4 = idx%8
+  float4 ra[NLD], rb[NLD];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NLD; ++r) {
       const int idx = tid + kBlk * r;
       const int row = idx >> 3, c4 = idx & 7;
       const int k = k0 + c4 * 4;
@@ -106,11 +112,11 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NLD; ++r) {
       const int idx = tid + kBlk * r;
       const int row = idx >> 3, c4 = idx & 7;
-      *reinterpret_cast<float4*>(As + (buf * BM + row) * LDK + c4 * 4) = ra[r];
-      *reinterpret_cast<float4*>(Bs + (buf * BN + row) * LDK + c4 * 4) = rb[r];
+      *reinterpret_cast<float4*>(As + (buf * TBM + row) * LDK + c4 * 4) = ra[r];
+      *reinterpret_cast<float4*>(Bs + (buf * TBN + row) * LDK + c4 * 4) = rb[r];
     }
   };
 
@@ -118,23 +124,24 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
   gload(0);
   lstore(0);
   __syncthreads();
-  const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), khalf = (lane >> 5) * 4;
+  const int arow = wm * WT + (lane & 31), brow = wn * WT + (lane & 31), khalf = (lane >> 5) * 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
-    const float* as = As + (buf * BM + arow) * LDK + khalf;
-    const float* bs = Bs + (buf * BN + brow) * LDK + khalf;
+    const float* as = As + (buf * TBM + arow) * LDK + khalf;
+    const float* bs = Bs + (buf * TBN + brow) * LDK + khalf;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
-      float4 a[2], b[2];
-      a[0] = *reinterpret_cast<const float4*>(as + kk * 8);
-      a[1] = *reinterpret_cast<const float4*>(as + 32 * LDK + kk * 8);
-      b[0] = *reinterpret_cast<const float4*>(bs + kk * 8);
-      b[1] = *reinterpret_cast<const float4*>(bs + 32 * LDK + kk * 8);
+      float4 a[T], b[T];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int i = 0; i < T; ++i) {
+        a[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDK + kk * 8);
+        b[i] = *reinterpret_cast<const float4*>(bs + i * 32 * LDK + kk * 8);
+      }
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+      for (int mi = 0; mi < T; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < T; ++ni) {
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
@@ -147,15 +154,15 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
 
   // epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int gn = n0 + wn * 64 + ni * 32 + (lane & 31);
+  for (int ni = 0; ni < T; ++ni) {
+    const int gn = n0 + wn * WT + ni * 32 + (lane & 31);
     if (gn >= N) continue;
     const float bv = bias ? bias[gn] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < T; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int gm = m0 + wm * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (gm < M) C[(int64_t)gm * ldc + gn] = apply_act(acc[mi][ni][r] + bv, act, act_param) * out_scale;
       }
     }
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(kBlk) void posenc_kernel(const float* __restrict__ 
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-constexpr int kNtLds = (2 * BM * LDK + 2 * BN * LDK) * 4;   // 73728 B
+constexpr int kNtLds = (2 * BM * LDK + 2 * BN * LDK) * 4;   // 73728 B (T=2); half of it for T=1
 constexpr int kTnLds = (4 * BK * LDM) * 4;                  // 67584 B
 
 int tn_splits(int64_t M, int64_t N, int64_t K) {
@@ -331,15 +338,24 @@ extern "C" int recmv_gemm_nt(const float* A, int64_t lda, const float* B, int64_
   RECMV_REQUIRE(act >= RECMV_ACT_NONE && act <= RECMV_ACT_TANH, "gemm_nt: unknown activation %d", act);
   static bool attr_set = false;
   if (!attr_set) {
-    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kNtLds));
     attr_set = true;
   }
-  const int nbm = (int)ceil_div(M, BM), nbn = (int)ceil_div(N, BN);
   const bool a_vec = aligned16(A) && lda % 4 == 0, b_vec = aligned16(B) && ldb % 4 == 0;
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), kNtLds,
-                     (hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param,
-                     out_scale, nbm, nbn, a_vec, b_vec);
+  // tile choice: 128x128 tiles unless they would leave the 256 CUs under-filled (< 2 workgroups per CU)
+  const int64_t big_blocks = ceil_div(M, BM) * ceil_div(N, BN);
+  if (big_blocks >= 2 * kNumCU) {
+    const int nbm = (int)ceil_div(M, BM), nbn = (int)ceil_div(N, BN);
+    hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), kNtLds,
+                       (hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param,
+                       out_scale, nbm, nbn, a_vec, b_vec);
+  } else {
+    const int nbm = (int)ceil_div(M, 64), nbn = (int)ceil_div(N, 64);
+    hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), kNtLds / 2,
+                       (hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param,
+                       out_scale, nbm, nbn, a_vec, b_vec);
+  }
   return check_launch("gemm_nt");
 }
 

@@ -60,6 +60,14 @@ def _declare(lib):
         "recmv_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),
         "recmv_gemm_tn": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
         "recmv_posenc_forward": (C.c_int, [vp, i64, vp, i64, i64, i64, i32, vp, f32, vp]),
+        "recmv_act_grad": (C.c_int, [vp, vp, vp, i64, i32, f32, vp]),
+        "recmv_act_grad2": (C.c_int, [vp, vp, vp, vp, i64, i32, f32, vp]),
+        "recmv_weight_norm_forward": (C.c_int, [vp, vp, vp, vp, i64, i64, vp]),
+        "recmv_weight_norm_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, vp]),
+        "recmv_posenc_vjp": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, vp]),
+        "recmv_posenc_jvp": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i32, vp, vp]),
+        "recmv_kinematic_chain_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp]),
+        "recmv_kinematic_chain_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)       # AttributeError if the symbol is missing: fail loudly

@@ -37,6 +37,43 @@ def batch_rodrigues(theta):
     return quat2mat(quat)
 
 
+class KinematicChain(torch.autograd.Function):
+    """poses [B,24,3] -> (G [B,24,4,4], A = G . init_pose) in ONE kernel (csrc/kinematic_chain.hip) instead of the
+    reference's 23-step Python loop of 4x4 products (model/Deformer.py:384-396)."""
+
+    @staticmethod
+    def forward(ctx, poses, js_host, parents_host, init_pose):
+        from .. import _lib as L
+        poses_c = poses.detach().contiguous().float()
+        B = poses_c.shape[0]
+        G = torch.empty((B, 24, 4, 4), dtype=torch.float32, device=poses.device)
+        A = torch.empty_like(G) if init_pose is not None else None
+        ip = init_pose.detach().contiguous() if init_pose is not None else None
+        with torch.cuda.device(poses.device):
+            L.check(L.lib().recmv_kinematic_chain_forward(L.ptr(poses_c), js_host, parents_host, L.ptr(ip), L.ptr(G),
+                                                          L.ptr(A), B, L.stream_ptr(poses.device)), "kinematic_chain")
+        ctx.save_for_backward(poses_c, ip)
+        ctx.consts = (js_host, parents_host)
+        if A is None:
+            return G, G.new_zeros(())
+        return G, A
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gG, gA):
+        from .. import _lib as L
+        poses_c, ip = ctx.saved_tensors
+        js_host, parents_host = ctx.consts
+        gG = gG.contiguous() if gG is not None else None
+        gA = gA.contiguous() if (gA is not None and ip is not None) else None
+        gp = torch.empty_like(poses_c)
+        with torch.cuda.device(poses_c.device):
+            L.check(L.lib().recmv_kinematic_chain_backward(L.ptr(poses_c), js_host, parents_host, L.ptr(ip), L.ptr(gG),
+                                                           L.ptr(gA), L.ptr(gp), poses_c.shape[0],
+                                                           L.stream_ptr(poses_c.device)), "kinematic_chain_backward")
+        return gp, None, None, None
+
+
 def _mm4(a, b):
     """Batched small matmul [...,n,k] @ [...,k,m] by broadcasting (no BLAS on the path)."""
     return (a.unsqueeze(-1) * b.unsqueeze(-3)).sum(-2)
@@ -91,7 +128,7 @@ class MLPTranslator(nn.Module):
             else:
                 ps = self.embed_fn(ps, annealing_weights(self.multires, ratio))
         if batch_inds is not None:
-            x = torch.cat([ps, conds[batch_inds]], dim=1)
+            x = torch.cat([ps, conds.index_select(0, batch_inds)], dim=1)
         else:
             x = torch.cat([ps, conds.view(-1, 1, self.feature_vector_size).expand(
                 -1, ps.shape[1], self.feature_vector_size)], dim=-1).view(-1, ps.shape[-1] + self.feature_vector_size)
@@ -175,6 +212,21 @@ class LBSkinner(nn.Module):
             invs.append(inv)
         self.register_buffer('init_pose', torch.stack(invs, dim=0))
 
+    def _host_consts(self):
+        if getattr(self, "_consts", None) is None:
+            import ctypes as C
+            js = self.Js.detach().cpu().view(-1).tolist()
+            par = [int(v) for v in np.asarray(self.parents).reshape(-1)]
+            par[0] = -1
+            self._consts = ((C.c_float * 72)(*js), (C.c_int32 * 24)(*par))
+        return self._consts
+
+    def _chain_fused(self, poses):
+        """(results, A) through the fused kernel; A is None when the skinner has no init_pose."""
+        js_host, parents_host = self._host_consts()
+        G, A = KinematicChain.apply(poses.reshape(-1, 24, 3), js_host, parents_host, self.init_pose)
+        return G, (A if self.init_pose is not None else None)
+
     def _chain(self, poses):
         """Kinematic chain: global 4x4 of every joint, [B,24,4,4] (model/Deformer.py:372-396)."""
         batch_size = poses.shape[0]
@@ -196,7 +248,10 @@ class LBSkinner(nn.Module):
     def posedSkeleton(self, conds):
         poses, trans = conds
         assert (poses.shape[0] == trans.shape[0])
-        results, _ = self._chain(poses)
+        if poses.is_cuda and poses.dtype == torch.float32:
+            results, _ = self._chain_fused(poses)
+        else:
+            results, _ = self._chain(poses)
         return results[:, :, :3, 3]
 
     def inv_transform_v(self, v, scale_grid, transl):
@@ -219,8 +274,15 @@ class LBSkinner(nn.Module):
         trans = trans + self.extra_trans
         batch_size = poses.shape[0]
         assert (batch_size == trans.shape[0])
-        results, Js = self._chain(poses)
-        if self.init_pose is None:
+        if poses.is_cuda and poses.dtype == torch.float32 and self.init_pose is not None:
+            _, A = self._chain_fused(poses)
+            results = Js = None
+        else:
+            results, Js = self._chain(poses)
+            A = None
+        if A is not None:
+            pass
+        elif self.init_pose is None:
             Js_w0 = torch.cat([Js, torch.zeros(batch_size, 24, 1, 1).to(poses.device)], dim=2)
             init_bone = _mm4(results, Js_w0)
             init_bone = F.pad(init_bone, [3, 0, 0, 0, 0, 0, 0, 0])
@@ -241,9 +303,9 @@ class LBSkinner(nn.Module):
         # T[p] = sum_j w[p,j] * A[b_p, j]  — one MFMA product against every frame, then gather by frame
         Ball = A.reshape(batch_size, 24, 16).permute(0, 2, 1).reshape(batch_size * 16, 24)
         Tall = ops.MatmulNT.apply(ps_ws, Ball).view(-1, batch_size, 16)
-        T = Tall[torch.arange(flat.shape[0], device=flat.device), binds].view(-1, 4, 4)
+        T = Tall.gather(1, binds.view(-1, 1, 1).expand(-1, 1, 16)).view(-1, 4, 4)
         v = (T[:, :3, :3] * flat.unsqueeze(-2)).sum(-1) + T[:, :3, 3]
-        v = v + trans[binds]
+        v = v + trans.index_select(0, binds)
         if batch_inds is None:
             return v.view(batch_size, pnum, 3)
         return v

@@ -27,9 +27,14 @@ class Embedder:
                         and list(self.periodic_fns) == [torch.sin, torch.cos])
 
     def embed(self, inputs, ws=None):
-        if (self._hip_ok and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 2
-                and not (torch.is_grad_enabled() and inputs.requires_grad)):
-            return ops.posenc(inputs, self.num_freqs, ws)
+        if self._hip_ok and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.shape[-1] == 3:
+            flat = inputs.reshape(-1, 3)
+            wl = None if ws is None else tuple(float(w) for w in ws)
+            if torch.is_grad_enabled() and inputs.requires_grad:
+                out = ops.PosEnc.apply(flat, self.num_freqs, wl)
+            else:
+                out = ops.posenc(flat, self.num_freqs, wl)
+            return out.view(*inputs.shape[:-1], self.out_dim)
         outs = [inputs] if self.include_input else []
         i = 0
         for freq in self.freq_bands.tolist():

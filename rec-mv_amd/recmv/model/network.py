@@ -69,7 +69,17 @@ class ImplicitNetwork(nn.Module):
         lin = getattr(self, "lin" + str(l))
         if self.weight_norm:
             v, g = lin.weight_v, lin.weight_g
-            return g * (v / v.norm(dim=1, keepdim=True)), lin.bias               # weight_norm dim=0
+            if not torch.is_grad_enabled():
+                # the normalised weights only change at optimizer.step(): cache them for the no-grad passes
+                # (grid queries, root-finder checks) keyed on the parameters' in-place version counters
+                cache = self.__dict__.setdefault('_wn_cache', {})
+                key = (v._version, g._version, v.data_ptr())
+                hit = cache.get(l)
+                if hit is None or hit[0] != key:
+                    hit = (key, ops.weight_norm(v, g))
+                    cache[l] = hit
+                return hit[1], lin.bias
+            return ops.weight_norm(v, g), lin.bias                                # weight_norm dim=0
         return lin.weight, lin.bias
 
     def _pe_weights(self, ratio):

@@ -163,6 +163,186 @@ def _dact_from_output(y, act, act_param):
     raise RuntimeError("unknown activation")
 
 
+def _wbuf(weights, multires):
+    if weights is None:
+        return None
+    assert len(weights) == 2 * multires
+    return (C.c_float * (2 * multires))(*[float(w) for w in weights])
+
+
+def _cptr(buf):
+    return C.cast(buf, C.c_void_p) if buf is not None else None
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd: positional encoding with first and second derivative, one launch each
+# --------------------------------------------------------------------------------------------------
+def _pe_vjp(x, g, t, multires, weights):
+    x = x.contiguous()
+    g = g if g.stride(1) == 1 else g.contiguous()
+    out = torch.empty((x.shape[0], 3), dtype=torch.float32, device=x.device)
+    if t is not None:
+        t = t.contiguous()
+    P = x.shape[0]
+    with torch.cuda.device(x.device):
+        L.check(L.lib().recmv_posenc_vjp(L.ptr(x), 3, L.ptr(g), g.stride(0) if P > 1 else g.shape[1], L.ptr(t), 3,
+                                         L.ptr(out), P, multires, _cptr(_wbuf(weights, multires)),
+                                         L.stream_ptr(x.device)), "posenc_vjp")
+    return out
+
+
+def _pe_jvp(x, t, multires, weights):
+    x, t = x.contiguous(), t.contiguous()
+    P = x.shape[0]
+    out = torch.empty((P, 3 + 6 * multires), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().recmv_posenc_jvp(L.ptr(x), 3, L.ptr(t), 3, L.ptr(out), out.shape[1], P, multires,
+                                         _cptr(_wbuf(weights, multires)), L.stream_ptr(x.device)), "posenc_jvp")
+    return out
+
+
+class PosEnc(torch.autograd.Function):
+    """gamma(x) (model/Embedder.py:4-65); differentiable to second order on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, multires, weights):
+        ctx.save_for_backward(x)
+        ctx.cfg = (multires, weights)
+        return posenc(x.detach(), multires, weights)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return PosEncVjp.apply(x, g, *ctx.cfg), None, None
+
+
+class PosEncVjp(torch.autograd.Function):
+    """gx = J(x)^T g."""
+
+    @staticmethod
+    def forward(ctx, x, g, multires, weights):
+        ctx.save_for_backward(x, g)
+        ctx.cfg = (multires, weights)
+        return _pe_vjp(x.detach(), g.detach(), None, multires, weights)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        x, g = ctx.saved_tensors
+        gx = PosEncVjp2.apply(x, g, ggx, *ctx.cfg) if ctx.needs_input_grad[0] else None
+        gg = PosEncJvp.apply(x, ggx, *ctx.cfg) if ctx.needs_input_grad[1] else None
+        return gx, gg, None, None
+
+
+class PosEncJvp(torch.autograd.Function):
+    """J(x) t."""
+
+    @staticmethod
+    def forward(ctx, x, t, multires, weights):
+        ctx.save_for_backward(x, t)
+        ctx.cfg = (multires, weights)
+        return _pe_jvp(x.detach(), t.detach(), multires, weights)
+
+    @staticmethod
+    def backward(ctx, go):
+        x, t = ctx.saved_tensors
+        gx = PosEncVjp2.apply(x, go, t, *ctx.cfg) if ctx.needs_input_grad[0] else None
+        gt = PosEncVjp.apply(x, go, *ctx.cfg) if ctx.needs_input_grad[1] else None
+        return gx, gt, None, None
+
+
+class PosEncVjp2(torch.autograd.Function):
+    """t * d/dx <g, J(x) 1>  (second-derivative term; third order is never needed by the loss)."""
+
+    @staticmethod
+    def forward(ctx, x, g, t, multires, weights):
+        return _pe_vjp(x.detach(), g.detach(), t.detach(), multires, weights)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        raise RuntimeError("recmv: third-order derivative of the positional encoding is not implemented")
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd: activation-gradient step and weight norm
+# --------------------------------------------------------------------------------------------------
+class ActGrad(torch.autograd.Function):
+    """gz = gy * act'(z), written through y = act(z); one launch; differentiable once more."""
+
+    @staticmethod
+    def forward(ctx, gy, y, act, act_param):
+        ctx.save_for_backward(gy, y)
+        ctx.cfg = (act, act_param)
+        gy_c, y_c = gy.detach().contiguous(), y.detach().contiguous()
+        out = torch.empty_like(gy_c)
+        with torch.cuda.device(gy.device):
+            L.check(L.lib().recmv_act_grad(L.ptr(gy_c), L.ptr(y_c), L.ptr(out), out.numel(), act, float(act_param),
+                                           L.stream_ptr(gy.device)), "act_grad")
+        return out
+
+    @staticmethod
+    def backward(ctx, ggz):
+        gy, y = ctx.saved_tensors
+        act, p = ctx.cfg
+        g_gy = ActGrad.apply(ggz, y, act, p) if ctx.needs_input_grad[0] else None
+        g_y = None
+        if ctx.needs_input_grad[1] and act in (ACT_SOFTPLUS, ACT_TANH):
+            g_y = ActGrad2.apply(ggz, gy, y, act, p)
+        return g_gy, g_y, None, None
+
+
+class ActGrad2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, y, act, act_param):
+        a_c, b_c, y_c = a.detach().contiguous(), b.detach().contiguous(), y.detach().contiguous()
+        out = torch.empty_like(a_c)
+        with torch.cuda.device(a.device):
+            L.check(L.lib().recmv_act_grad2(L.ptr(a_c), L.ptr(b_c), L.ptr(y_c), L.ptr(out), out.numel(), act,
+                                            float(act_param), L.stream_ptr(a.device)), "act_grad2")
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        raise RuntimeError("recmv: third-order derivative through an activation is not implemented")
+
+
+class WeightNorm(torch.autograd.Function):
+    """W = g * v / ||v||_row (nn.utils.weight_norm, dim 0), one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        v_c, g_c = v.detach().contiguous(), g.detach().contiguous()
+        rows, cols = v_c.shape
+        W = torch.empty_like(v_c)
+        norms = torch.empty(rows, dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            L.check(L.lib().recmv_weight_norm_forward(L.ptr(v_c), L.ptr(g_c), L.ptr(W), L.ptr(norms), rows, cols,
+                                                      L.stream_ptr(v.device)), "weight_norm")
+        ctx.save_for_backward(v_c, g_c, norms)
+        return W
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gW):
+        v, g, norms = ctx.saved_tensors
+        gW = gW.contiguous()
+        gv = torch.empty_like(v)
+        gg = torch.empty_like(g)
+        with torch.cuda.device(v.device):
+            L.check(L.lib().recmv_weight_norm_backward(L.ptr(v), L.ptr(g), L.ptr(norms), L.ptr(gW), L.ptr(gv),
+                                                       L.ptr(gg), v.shape[0], v.shape[1], L.stream_ptr(v.device)),
+                    "weight_norm_backward")
+        return gv, gg
+
+
+def weight_norm(v, g):
+    """g [rows,1], v [rows,cols] -> W; fused kernel on the GPU."""
+    if v.is_cuda and v.dtype == torch.float32:
+        return WeightNorm.apply(v, g)
+    return g * (v / v.norm(dim=1, keepdim=True))
+
+
 class LinearAct(torch.autograd.Function):
     """y = act(x @ W^T + b), one fused kernel forward; backward of any order on the same kernels."""
 
@@ -177,8 +357,7 @@ class LinearAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, W, y = ctx.saved_tensors
-        d = _dact_from_output(y, ctx.act, ctx.act_param)
-        gz = gy if d is None else gy * d
+        gz = gy if ctx.act == ACT_NONE else ActGrad.apply(gy, y, ctx.act, ctx.act_param)
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
             gx = MatmulNT.apply(gz, W.t().contiguous())

@@ -322,3 +322,102 @@ def test_posenc_kernel_vs_torch_path():
     torch.testing.assert_close(buf[:, 473:], 0.5 * embed(x.clone().requires_grad_(True)).detach(), rtol=1e-6,
                                atol=2e-6)
     assert (buf[:, :473] == 7.0).all()
+
+
+# ------------------------------------------------------------------------------------------ fused helpers
+def test_posenc_function_first_and_second_order_vs_torch_path():
+    """PosEnc / PosEncVjp / PosEncJvp / PosEncVjp2 against autograd of the plain torch encoding (f32)."""
+    from recmv import ops
+    from recmv.utils import annealing_weights
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(300, 3, generator=g)
+    ws = tuple(annealing_weights(6, 0.62))
+
+    def torch_pe(x):
+        outs = [x]
+        for b in range(6):
+            outs.append(ws[2 * b] * torch.sin(x * (2.0 ** b)))
+            outs.append(ws[2 * b + 1] * torch.cos(x * (2.0 ** b)))
+        return torch.cat(outs, -1)
+
+    Wt = gpu(torch.randn(39, 5, generator=g))
+
+    def run(pe):
+        x = gpu(x0).clone().requires_grad_(True)
+        y = pe(x) @ Wt                                     # mix the features like a layer would
+        f = torch.tanh(y).sum(1)
+        gx, = torch.autograd.grad(f.sum(), x, create_graph=True)
+        loss = ((gx.norm(dim=1) - 1) ** 2).mean() + f.mean()
+        gx2, = torch.autograd.grad(loss, x)
+        return y.detach(), gx.detach(), gx2
+
+    a = run(lambda x: ops.PosEnc.apply(x, 6, ws))
+    b = run(torch_pe)
+    torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a[1], b[1], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(a[2], b[2], rtol=2e-3, atol=2e-3 * float(b[2].abs().max()))
+
+
+def test_act_grad_and_weight_norm_functions():
+    from recmv import ops
+    g = torch.Generator().manual_seed(1)
+    for act, param, fn in ((ops.ACT_SOFTPLUS, 100.0, lambda z: torch.nn.functional.softplus(z, beta=100)),
+                           (ops.ACT_TANH, 0.0, torch.tanh), (ops.ACT_RELU, 0.0, torch.relu)):
+        z = gpu(torch.randn(257, 33, generator=g) * 0.05).requires_grad_(True)
+        gy = gpu(torch.randn(257, 33, generator=g)).requires_grad_(True)
+        y = fn(z)
+        ref_gz, = torch.autograd.grad(y, z, gy, create_graph=True)
+        out = ops.ActGrad.apply(gy, y, act, param)
+        torch.testing.assert_close(out, ref_gz, rtol=1e-4, atol=1e-5)
+        # second order: d/dz and d/dgy of sum(gz * r)
+        r = gpu(torch.randn(257, 33, generator=g))
+        a = torch.autograd.grad((out * r).sum(), [z, gy], allow_unused=True)
+        b = torch.autograd.grad((ref_gz * r).sum(), [z, gy], allow_unused=True)
+        for u, v in zip(a, b):
+            if v is None:
+                assert u is None or float(u.abs().max()) == 0
+            else:
+                torch.testing.assert_close(u, v, rtol=2e-3, atol=2e-3 * float(v.abs().max()) + 1e-6)
+    v = gpu(torch.randn(473, 512, generator=g)).requires_grad_(True)
+    gg = gpu(torch.rand(473, 1, generator=g) + 0.5).requires_grad_(True)
+    W = ops.weight_norm(v, gg)
+    Wr = gg * (v / v.norm(dim=1, keepdim=True))
+    torch.testing.assert_close(W, Wr, rtol=1e-5, atol=1e-6)
+    r = gpu(torch.randn(473, 512, generator=g))
+    a = torch.autograd.grad((W * r).sum(), [v, gg])
+    b = torch.autograd.grad((Wr * r).sum(), [v, gg])
+    torch.testing.assert_close(a[0], b[0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a[1], b[1], rtol=1e-4, atol=1e-4)
+
+
+def test_kinematic_chain_kernel_vs_python_loop():
+    """Fused chain (csrc/kinematic_chain.hip) vs the 23-step loop restatement of model/Deformer.py:372-405."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+    import common_setup as cs
+    from recmv.model import LBSkinner
+    sk = cs.build_skinner(LBSkinner).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    poses = gpu(0.4 * torch.randn(7, 24, 3, generator=g))
+    poses[0, 3] = 0.0                                     # zero rotation: the 1e-8 guard
+    p1 = poses.clone().requires_grad_(True)
+    p2 = poses.clone().requires_grad_(True)
+    G1, A1 = sk._chain_fused(p1)
+    G2, _ = sk._chain(p2)
+    A2 = (G2.unsqueeze(-1) * sk.init_pose.view(1, 24, 4, 4).unsqueeze(-3)).sum(-2)
+    torch.testing.assert_close(G1, G2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(A1, A2, rtol=1e-5, atol=1e-6)
+    rG, rA = gpu(torch.randn(7, 24, 4, 4, generator=g)), gpu(torch.randn(7, 24, 4, 4, generator=g))
+    ga, = torch.autograd.grad((G1 * rG).sum() + (A1 * rA).sum(), p1)
+    gb, = torch.autograd.grad((G2 * rG).sum() + (A2 * rA).sum(), p2)
+    torch.testing.assert_close(ga, gb, rtol=2e-4, atol=2e-4)
+
+
+def test_singular_values_closed_form():
+    from recmv.loop import singular_values_3x3
+    g = torch.Generator().manual_seed(5)
+    J = gpu(torch.eye(3).view(1, 3, 3) + 0.3 * torch.randn(2000, 3, 3, generator=g))
+    s = singular_values_3x3(J)
+    ref = torch.linalg.svdvals(J.cpu().double()).float()
+    torch.testing.assert_close(s.cpu(), ref, rtol=2e-3, atol=2e-4)

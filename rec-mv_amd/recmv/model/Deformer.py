@@ -92,6 +92,21 @@ class CompositeDeformer(nn.Module):
             out = deformer(out, cond, batch_inds, **kwargs)
         return out
 
+    @torch.no_grad()
+    def value_and_vjp(self, ps, conds, batch_inds, cotangent_fn, **kwargs):
+        """d = deformer(ps) and J_d(ps)^T g with g = cotangent_fn(d), without an autograd graph and without
+        parameter gradients: explicit forward of each stage, explicit backward to the INPUT.  This is what the
+        surface root finder needs per step (utils/FindSurfacePs.py:319-333)."""
+        assert (self.N == len(conds))
+        out, saved = ps, []
+        for cond, deformer in zip(conds, self.defs):
+            out, sv = deformer.forward_explicit(out, cond, batch_inds, **kwargs)
+            saved.append(sv)
+        g = cotangent_fn(out)
+        for deformer, sv in zip(reversed(self.defs), reversed(saved)):
+            g = deformer.backward_input(sv, g)
+        return out, g
+
 
 class MLPTranslator(nn.Module):
     def __init__(self, feature_vector_size, multires, weight_norm=False):
@@ -142,6 +157,61 @@ class MLPTranslator(nn.Module):
         else:
             self.offset[offset_type] = x.view(ps.shape[0], ps.shape[1], 3)
             return ps[..., :3] + x.view(ps.shape[0], ps.shape[1], 3)
+
+
+def _translator_explicit(self, ps, conds, batch_inds, **kwargs):
+    """Explicit forward of MLPTranslator for 2-D `ps` with `batch_inds` (the ray path)."""
+    ratio = kwargs['ratio']['deformerRatio']
+    ws = None if ratio is None else ([0.] * (self.multires * 2) if ratio <= 0 else
+                                     annealing_weights(self.multires, ratio))
+    wl = None if ws is None else tuple(float(w) for w in ws)
+    P, dev = ps.shape[0], ps.device
+    ps = ps.detach().contiguous()
+    d_pe = 3 + 6 * self.multires
+    d_in = d_pe + self.feature_vector_size
+    d_inp = (d_in + 3) // 4 * 4
+    x = torch.zeros((P, d_inp), dtype=torch.float32, device=dev)
+    ops.posenc(ps, self.multires, wl, 1.0, out=x[:, :d_pe], ld_fill=d_pe)
+    x[:, d_pe:d_in] = conds.detach().index_select(0, batch_inds)
+    h = x[:, :d_in]
+    acts = []
+    nl = self.num_layers - 1
+    for l in range(nl):
+        lin = getattr(self, "lin" + str(l))
+        h = ops.gemm_nt(h, lin.weight.detach(), lin.bias.detach(), ops.ACT_NONE if l == nl - 1 else ops.ACT_RELU)
+        acts.append(h)
+    off = acts[-1]
+    self.offset[kwargs.get('offset_type', None)] = off
+    return ps + off, (ps, acts, wl, d_pe)
+
+
+def _translator_backward_input(self, saved, g_out):
+    ps, acts, wl, d_pe = saved
+    nl = self.num_layers - 1
+    g = g_out.contiguous()
+    for l in range(nl - 1, -1, -1):
+        lin = getattr(self, "lin" + str(l))
+        if l < nl - 1:
+            g = ops.act_grad(g, acts[l], ops.ACT_RELU, 0.0)
+        Wt = _cached_t(self, l, lin.weight)
+        g = ops.gemm_nt(g, Wt)
+    g_pe = g[:, :d_pe].contiguous()
+    g_pe[:, :3] += g_out                              # the `ps[..., :3] + offset` residual path
+    return ops._pe_vjp(ps, g_pe, None, self.multires, wl)
+
+
+def _cached_t(module, l, W):
+    cache = module.__dict__.setdefault('_wt_cache', {})
+    key = (W._version, W.data_ptr())
+    hit = cache.get(l)
+    if hit is None or hit[0] != key:
+        hit = (key, W.detach().t().contiguous())
+        cache[l] = hit
+    return hit[1]
+
+
+MLPTranslator.forward_explicit = _translator_explicit
+MLPTranslator.backward_input = _translator_backward_input
 
 
 def getTranslatorNet(device, conf):
@@ -309,3 +379,41 @@ class LBSkinner(nn.Module):
         if batch_inds is None:
             return v.view(batch_size, pnum, 3)
         return v
+
+    @torch.no_grad()
+    def forward_explicit(self, ps, conds, batch_inds, **kwargs):
+        """Explicit (graph-free) forward for 2-D `ps` with `batch_inds`; see CompositeDeformer.value_and_vjp."""
+        from .. import GridSamplerMine
+        poses, trans = conds
+        trans = trans.detach() + self.extra_trans
+        B = poses.shape[0]
+        _, A = self._chain_fused(poses.detach())
+        ps = ps.detach().contiguous()
+        P = ps.shape[0]
+        scale = 2.0 / self.bbox_extend.view(1, 3)
+        nps = ((ps - self.bbox_center.view(1, 3)) * scale).contiguous()
+        grid = nps.view(1, 1, 1, P, 3)
+        w = GridSamplerMine.forward(self.ws, grid, 0, 1).view(24, P).t().contiguous()       # [P,24]
+        Ball = A.reshape(B, 24, 16).permute(0, 2, 1).reshape(B * 16, 24).contiguous()
+        Tall = ops.gemm_nt(w, Ball).view(P, B, 16)
+        T = Tall.gather(1, batch_inds.view(-1, 1, 1).expand(-1, 1, 16)).view(P, 4, 4)
+        v = (T[:, :3, :3] * ps.unsqueeze(-2)).sum(-1) + T[:, :3, 3] + trans.index_select(0, batch_inds)
+        return v, (ps, grid, T, A, batch_inds, scale, B)
+
+    @torch.no_grad()
+    def backward_input(self, saved, g_v):
+        from .. import GridSamplerMine
+        ps, grid, T, A, batch_inds, scale, B = saved
+        P = ps.shape[0]
+        g_p = (T[:, :3, :3] * g_v.unsqueeze(-1)).sum(-2)                                    # T33^T g
+        # g_w[p,j] = sum_{i<3,k} g_v[p,i] * A[b_p,j,i,k] * [ps;1][k]
+        ph = torch.cat([ps, torch.ones(P, 1, device=ps.device)], dim=1)
+        gT = torch.zeros((P, 4, 4), dtype=torch.float32, device=ps.device)
+        gT[:, :3, :] = g_v.unsqueeze(-1) * ph.unsqueeze(-2)
+        gTall = torch.zeros((P, B, 16), dtype=torch.float32, device=ps.device)
+        gTall.scatter_(1, batch_inds.view(-1, 1, 1).expand(-1, 1, 16), gT.view(P, 1, 16))
+        BallT = A.reshape(B, 24, 16).permute(1, 0, 2).reshape(24, B * 16).contiguous()
+        g_w = ops.gemm_nt(gTall.view(P, B * 16), BallT)                                     # [P,24]
+        go = g_w.t().contiguous().view(1, 24, 1, 1, P)
+        _, g_grid = GridSamplerMine.backward(self.ws, grid, go, 0, 1, need_grad_input=False)
+        return g_p + g_grid.view(P, 3) * scale

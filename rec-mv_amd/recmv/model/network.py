@@ -76,7 +76,7 @@ class ImplicitNetwork(nn.Module):
                 key = (v._version, g._version, v.data_ptr())
                 hit = cache.get(l)
                 if hit is None or hit[0] != key:
-                    hit = (key, ops.weight_norm(v, g))
+                    hit = [key, ops.weight_norm(v, g), None]
                     cache[l] = hit
                 return hit[1], lin.bias
             return ops.weight_norm(v, g), lin.bias                                # weight_norm dim=0
@@ -143,6 +143,66 @@ class ImplicitNetwork(nn.Module):
             else:
                 x = ops.gemm_nt(x, W, b, act, 100.0, 1.0)
         return x
+
+    @torch.no_grad()
+    def value_and_grad(self, x, ratio=None):
+        """(f(x) [P,1], grad_x f [P,3]) without building an autograd graph: the explicit layer chain forward
+        (one fused kernel per layer) and the chain backward to the INPUT only (no parameter gradients).
+        Used by the surface root finder, which needs exactly this pair at every step
+        (utils/FindSurfacePs.py:316-333).  Values are identical to forward()/gradient()."""
+        ws = self._pe_weights(ratio)
+        wl = None if ws is None else tuple(float(w) for w in ws)
+        P, dev = x.shape[0], x.device
+        x = x.detach().contiguous()
+        d0 = self.dims[0]
+        d0p = (d0 + 3) // 4 * 4
+        pe = torch.empty((P, d0p), dtype=torch.float32, device=dev)
+        ops.posenc(x, self.multires, wl, 1.0, out=pe, ld_fill=d0p)
+        h = pe[:, :d0]
+        acts, Ws = [], []
+        nl = self.num_layers - 1
+        for l in range(nl):
+            W, b = self._weight(l)
+            Ws.append(W)
+            last = l == nl - 1
+            if last:                                      # only the SDF column is needed here
+                h = ops.gemm_nt(h, W[:self.d_out], b[:self.d_out], ops.ACT_NONE, 0.0, 1.0)
+            elif l + 1 in self.skip_in:
+                nxt = torch.empty((P, self.dims[l + 1]), dtype=torch.float32, device=dev)
+                n_out = W.shape[0]
+                ops.gemm_nt(h, W, b, ops.ACT_SOFTPLUS, 100.0, 1.0 / _SQRT2, out=nxt[:, :n_out])
+                ops.posenc(x, self.multires, wl, 1.0 / _SQRT2, out=nxt[:, n_out:], ld_fill=d0)
+                h = nxt
+            else:
+                h = ops.gemm_nt(h, W, b, ops.ACT_SOFTPLUS, 100.0, 1.0)
+            acts.append(h)
+        f = acts[-1]
+        # backward to the input: d f / d h_{last-1} is row 0 of the last weight for every point
+        g_pe = torch.zeros((P, d0p), dtype=torch.float32, device=dev)
+        g = Ws[nl - 1][0:1].expand(P, -1)
+        for l in range(nl - 2, -1, -1):
+            y = acts[l]
+            if l + 1 in self.skip_in:
+                # acts[l] = [softplus(z)/sqrt2 | pe/sqrt2]; split the incoming gradient
+                n_out = Ws[l].shape[0]
+                g_pe[:, :d0] += g[:, n_out:] * (1.0 / _SQRT2)
+                gz = ops.act_grad(g[:, :n_out].contiguous(), (y[:, :n_out] * _SQRT2).contiguous(), ops.ACT_SOFTPLUS,
+                                  100.0) * (1.0 / _SQRT2)
+            else:
+                gz = ops.act_grad(g.contiguous(), y, ops.ACT_SOFTPLUS, 100.0)
+            g = ops.gemm_nt(gz, self._weight_t(l, Ws[l]))
+        g_pe[:, :d0] += g
+        grad = ops._pe_vjp(x, g_pe, None, self.multires, wl)
+        return f, grad
+
+    def _weight_t(self, l, W):
+        """W^T (contiguous) for the input-gradient products; cached with the normalised weights."""
+        hit = self.__dict__.get('_wn_cache', {}).get(l)
+        if hit is None or hit[1] is not W:
+            return W.t().contiguous()
+        if hit[2] is None:
+            hit[2] = W.t().contiguous()
+        return hit[2]
 
     def gradient(self, x, y=None):
         x.requires_grad_(True)

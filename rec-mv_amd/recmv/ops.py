@@ -266,6 +266,16 @@ class PosEncVjp2(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------
 # autograd: activation-gradient step and weight norm
 # --------------------------------------------------------------------------------------------------
+def act_grad(gy, y, act, act_param):
+    """gy * act'(z) through y = act(z), no autograd."""
+    gy, y = gy.contiguous(), y.contiguous()
+    out = torch.empty_like(gy)
+    with torch.cuda.device(gy.device):
+        L.check(L.lib().recmv_act_grad(L.ptr(gy), L.ptr(y), L.ptr(out), out.numel(), act, float(act_param),
+                                       L.stream_ptr(gy.device)), "act_grad")
+    return out
+
+
 class ActGrad(torch.autograd.Function):
     """gz = gy * act'(z), written through y = act(z); one launch; differentiable once more."""
 

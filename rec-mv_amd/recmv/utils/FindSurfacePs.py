@@ -40,6 +40,47 @@ def _ray_angle_deg(direct, rays):
     return torch.arcsin(up.norm(dim=1) / direct.norm(dim=1)) * 180. / np.pi
 
 
+@torch.no_grad()
+def _optimize_explicit(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds, smpl_conds, name,
+                       dthreshold, athreshold, w1, w2, times):
+    """Same iteration as the autograd version below, evaluated with the graph-free value+gradient passes of the
+    networks (ImplicitNetwork.value_and_grad, CompositeDeformer.value_and_vjp).  All rays are carried through every
+    step (rows of the kernels are independent, so the active rays get bit-identical updates); finished rays are
+    simply not updated.  The post-update check of step i is the forward pass of step i+1, evaluated once."""
+    p = initTmpPs
+    c = cam_pos.view(1, 3)
+    conds = [defconds, smpl_conds]
+    state = {}
+
+    def cot(d):                      # d loss2 / d d  with loss2 = |(d-c) x v| / |d-c|
+        direct = d - c
+        up = torch.linalg.cross(direct, rays, dim=1)
+        un = up.norm(dim=1, keepdim=True)
+        dn = direct.norm(dim=1, keepdim=True)
+        state['loss2'] = (un / dn).view(-1)
+        state['angle'] = torch.arcsin(un / dn).view(-1) * 180. / np.pi
+        g_up = up / (un * dn).clamp(min=1e-30)
+        g_direct = torch.linalg.cross(rays, g_up, dim=1) - direct * (un / dn.pow(3))
+        return g_direct
+
+    f, gf = tmpSdf.value_and_grad(p, ratio)
+    d, gd = deformer.value_and_vjp(p, conds, batch_inds, cot, ratio=ratio, offset_type=name)
+    unfinished = ~((f.view(-1).abs() < dthreshold) & (state['angle'] < athreshold))
+    for ind in range(times):
+        if not bool(unfinished.any()):
+            break
+        loss = w1 * f.view(-1).abs() + w2 * state['loss2']
+        grad = w1 * torch.sign(f) * gf + w2 * gd
+        t = -loss / (grad * grad).sum(1)
+        p_new = torch.where(unfinished.view(-1, 1), p + t.view(-1, 1) * grad, p)
+        p = p_new
+        f, gf = tmpSdf.value_and_grad(p, ratio)
+        d, gd = deformer.value_and_vjp(p, conds, batch_inds, cot, ratio=ratio, offset_type=name)
+        done = (f.view(-1).abs() < dthreshold) & (state['angle'] < athreshold)
+        unfinished = unfinished & ~done
+    return p, ~unfinished
+
+
 def OptimizeGarmentSurfacePs(cam_pos, rays_list, initTmpPs_list, batch_inds_list, tmpSdf_nets, ratio, deformer,
                              defconds_list, garment_names, dthreshold=5.e-5, athreshold=0.02, w1=3.05, w2=1.,
                              times=5):
@@ -49,6 +90,12 @@ def OptimizeGarmentSurfacePs(cam_pos, rays_list, initTmpPs_list, batch_inds_list
     for garment_idx, (initTmpPs, batch_inds, defconds, rays, garment_name) in enumerate(
             zip(initTmpPs_list, batch_inds_list, defconds_list[0], rays_list, garment_names)):
         tmpSdf = tmpSdf_nets[garment_idx]
+        if initTmpPs.is_cuda and hasattr(tmpSdf, 'value_and_grad') and hasattr(deformer, 'value_and_vjp'):
+            pts, ok = _optimize_explicit(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds,
+                                         smpl_conds, garment_name, dthreshold, athreshold, w1, w2, times)
+            optimized_init_tmp_ps_list.append(pts.detach())
+            optimized_check_list.append(ok)
+            continue
         with torch.no_grad():
             check1 = tmpSdf(initTmpPs, ratio).view(-1).abs() < dthreshold
             direct = deformer(initTmpPs, [defconds, smpl_conds], batch_inds, ratio=ratio,

@@ -371,7 +371,7 @@ def test_act_grad_and_weight_norm_functions():
         torch.testing.assert_close(out, ref_gz, rtol=1e-4, atol=1e-5)
         # second order: d/dz and d/dgy of sum(gz * r)
         r = gpu(torch.randn(257, 33, generator=g))
-        a = torch.autograd.grad((out * r).sum(), [z, gy], allow_unused=True)
+        a = torch.autograd.grad((out * r).sum(), [z, gy], allow_unused=True, retain_graph=True)
         b = torch.autograd.grad((ref_gz * r).sum(), [z, gy], allow_unused=True)
         for u, v in zip(a, b):
             if v is None:

@@ -146,6 +146,28 @@ def test_cardinal_rays_and_deformed_normals(nets):
     close(nx, g["nx"], rtol=1e-3, atol=1e-4)
 
 
+def test_explicit_passes_equal_autograd(nets):
+    """The graph-free value+gradient passes used by the root finder give the same numbers as autograd."""
+    gt, gl = load("translator"), load("lbs")
+    sdf, comp = nets["sdf"], nets["comp"]
+    p = (torch.randn(777, 3, generator=torch.Generator().manual_seed(0)) * 0.5).to(DEV)
+    f, gf = sdf.value_and_grad(p, RATIO)
+    pg = p.clone().requires_grad_(True)
+    fa = sdf(pg, RATIO)
+    ga, = torch.autograd.grad(fa.sum(), pg)
+    close(f, fa.detach(), rtol=1e-5, atol=1e-6)
+    close(gf, ga, rtol=1e-4, atol=1e-5)
+    conds = [gt["conds"].to(DEV), [gl["poses"].to(DEV), gl["trans"].to(DEV)]]
+    binds = torch.randint(0, 3, (777,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    r = torch.randn(777, 3, generator=torch.Generator().manual_seed(2)).to(DEV)
+    d, gp = comp.value_and_vjp(p, conds, binds, lambda d: r, ratio=RATIO, offset_type="upper")
+    pg = p.clone().requires_grad_(True)
+    da = comp(pg, conds, binds, ratio=RATIO, offset_type="upper")
+    gpa, = torch.autograd.grad((da * r).sum(), pg)
+    close(d, da.detach(), rtol=1e-5, atol=1e-6)
+    close(gp, gpa, rtol=1e-4, atol=1e-5)
+
+
 def test_root_finder(nets):
     """utils/FindSurfacePs.py:273-353.  (a) ONE step of the update rule is deterministic and must match the reference
     to f32 tolerance; (b) over 20 steps the iteration is chaotic at the 5e-5 / 0.02 deg stopping thresholds (only ~10 %

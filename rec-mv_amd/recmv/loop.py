@@ -136,7 +136,7 @@ class HotLoop:
     """The per-frame optimisation inner loop (see module docstring)."""
 
     def __init__(self, conf, device, n_frames=64, H=512, W=512, stage='coarse', seed=0, resolutions=None,
-                 skin_grid=(65, 225, 129), bbox=((-0.9, -1.2, -0.6), (0.9, 1.2, 0.6)), world_size=1, rank=0):
+                 skin_grid=(65, 225, 129), bbox=None, world_size=1, rank=0):
         self.conf_all = conf
         self.conf = conf.get_config('loss_' + stage)
         self.device = device
@@ -149,6 +149,13 @@ class HotLoop:
         self.sdf = getTmpSdf(device, mult, bias=0.5)
         self.garment_nets = torch.nn.ModuleList([getTmpSdf(device, conf.get_int('garment_sdf_net.multires'), bias=b)
                                                  for b in (0.55, 0.45)])
+        if bbox is None:
+            # The geometric initialisation gives only approximately the nominal sphere radius.  Size the canonical
+            # box from the measured radius so that the coarse pyramid yields about the vertex counts the reference
+            # reports for its garment meshes ("8w, 7w": OptimGarmentNetwork.py:691).
+            r = max(_zero_level_radius(n, device) for n in self.garment_nets)
+            h = 1.45 * r
+            bbox = ((-h, -1.44 * h, -h), (h, 1.44 * h, h))
         g = torch.Generator().manual_seed(seed + 1)
         D, Hh, Ww = skin_grid
         ws = torch.softmax(2.0 * torch.randn(1, 24, D, Hh, Ww, generator=g), dim=1)
@@ -510,6 +517,21 @@ class HotLoop:
         self.optimizer.step()
         self.opt_times += 1.
         return loss.detach(), self.info['rays_total']
+
+
+@torch.no_grad()
+def _zero_level_radius(net, device, ndir=64, iters=24):
+    """Mean distance from the origin to the zero level set of `net` along random directions (bisection)."""
+    g = torch.Generator().manual_seed(7)
+    dirs = F.normalize(torch.randn(ndir, 3, generator=g), dim=1).to(device)
+    lo = torch.full((ndir, 1), 0.02, device=device)
+    hi = torch.full((ndir, 1), 2.0, device=device)
+    for _ in range(iters):
+        mid = 0.5 * (lo + hi)
+        inside = net(dirs * mid, 1.0) < 0
+        lo = torch.where(inside, mid, lo)
+        hi = torch.where(inside, hi, mid)
+    return float((0.5 * (lo + hi)).mean())
 
 
 def _apose():

@@ -36,6 +36,15 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (stdout carries only the JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 MFMA_F32_PEAK = 157.3e12      # FLOP/s, MI355X_MICROARCH.md (f32-input MFMA == f32 vector peak)
 HBM_PEAK = 8.0e12             # B/s
 
@@ -123,38 +132,63 @@ def mc_extract_timing(device):
                                       unit="GB/s", frac=round(alg / mc_s / HBM_PEAK, 4)))
 
 
-def cpu_baseline(conf_path):
-    """The same loop on host cores via oracle/cpu_port (torch-CPU sgemm + C oracle).  Bounded sample: 1/16 of the
-    rays, a (57,81,33) pyramid instead of (225,321,129) and a 24x33x57x33 skinning grid; the per-iteration point
-    counts (MC vertices, rays) are reported so the number can be scaled."""
+CPU_BASELINE_CORES = 16      # cap: the GPU boxes expose 256 host threads; tiny per-op work does not scale past a socket slice
+CPU_BASELINE_LIMIT_S = 150   # hard wall-clock bound of the whole leg (it runs in a child process)
+
+
+def _cpu_baseline_child(conf_path):
+    """Runs in a child process (see cpu_baseline): the same loop on host cores via oracle/cpu_port (torch-CPU
+    sgemm + C/OpenMP oracle kernels).  Bounded sample: 1/16 of the rays, a (57,81,33) pyramid instead of
+    (225,321,129) and a 24x33x57x33 skinning grid; the per-iteration point counts (MC vertices, rays) are reported
+    so the number can be scaled."""
+    cores = int(os.environ.get("OMP_NUM_THREADS", min(os.cpu_count() or 1, CPU_BASELINE_CORES)))
+    torch.set_num_threads(cores)
     from oracle import cpu_port
     from recmv.hocon import ConfigFactory
     from recmv.loop import HotLoop
     cpu_port.install()
+    conf = ConfigFactory.parse_file(conf_path)
+    conf.put('train.sample_pix_num', 128)
+    loop = HotLoop(conf, 'cpu', n_frames=9, H=512, W=512, resolutions=[(15, 21, 9), (29, 41, 17), (57, 81, 33)],
+                   skin_grid=(33, 57, 33))
+    loop.step(0)                       # includes the re-mesh
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or time.perf_counter() - t0 < 10.0:
+        loop.step(1 + n)
+        n += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    dt = (time.perf_counter() - t0) / n
+    verts = sum(int(v.shape[0]) for v in loop.garment_vs)
+    print("CPU_BASELINE " + json.dumps(dict(
+        value=round(1.0 / dt, 4), unit="iters/s", cores=cores, kind="port",
+        sample=f"{n} iterations of the same loop on a reduced scene: 3 frames, {verts} MC vertices "
+               f"(GPU run: see config.mc_vertices), {loop.info['rays_total']} rays/iter (GPU: "
+               f"config.rays_per_iter), pyramid (57,81,33), skinning grid 24x33x57x33, "
+               f"torch-CPU f32 + C/OpenMP oracle kernels on {cores} threads")), flush=True)
+
+
+def cpu_baseline(conf_path):
+    """CPU leg of the bench line, in a child process with a hard time limit so that a slow host can never keep the
+    JSON line from being printed.  Threads are capped at CPU_BASELINE_CORES (`cores` reports what was used)."""
+    import subprocess
+    cores = max(1, min(os.cpu_count() or 1, CPU_BASELINE_CORES))
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="",
+               CUDA_VISIBLE_DEVICES="")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
     try:
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
-        conf = ConfigFactory.parse_file(conf_path)
-        conf.put('train.sample_pix_num', 128)
-        loop = HotLoop(conf, 'cpu', n_frames=9, H=512, W=512, resolutions=[(15, 21, 9), (29, 41, 17), (57, 81, 33)],
-                       skin_grid=(33, 57, 33))
-        loop.step(0)                       # includes the re-mesh
-        t0 = time.perf_counter()
-        n = 0
-        while n < 2 or time.perf_counter() - t0 < 10.0:
-            loop.step(1 + n)
-            n += 1
-            if time.perf_counter() - t0 > 30.0:
-                break
-        dt = (time.perf_counter() - t0) / n
-        verts = sum(int(v.shape[0]) for v in loop.garment_vs)
-        return dict(value=round(1.0 / dt, 4), unit="iters/s", cores=cores, kind="port",
-                    sample=f"{n} iterations of the same loop on a reduced scene: 3 frames, {verts} MC vertices "
-                           f"(GPU run: see config.mc_vertices), {loop.info['rays_total']} rays/iter (GPU: "
-                           f"config.rays_per_iter), pyramid (57,81,33), skinning grid 24x33x57x33, "
-                           f"torch-CPU f32 + C/OpenMP oracle kernels")
-    finally:
-        cpu_port.uninstall()
+        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-child", "--conf", conf_path],
+                           env=env, capture_output=True, text=True, timeout=CPU_BASELINE_LIMIT_S)
+        for ln in r.stdout.splitlines():
+            if ln.startswith("CPU_BASELINE "):
+                return json.loads(ln[len("CPU_BASELINE "):])
+        return dict(value=None, unit="iters/s", cores=cores, kind="port",
+                    sample="child failed: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:200])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="iters/s", cores=cores, kind="port",
+                    sample=f"child exceeded {CPU_BASELINE_LIMIT_S} s and was stopped")
 
 
 def main():
@@ -165,8 +199,12 @@ def main():
     ap.add_argument("--stage", default="coarse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--conf", default=str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        _cpu_baseline_child(args.conf)
+        return
 
     from recmv import dist as rdist
     from recmv.hocon import ConfigFactory
@@ -184,10 +222,13 @@ def main():
     rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters()))
     allreduce = rdist.GradAllReduce(world) if world > 1 else None
 
+    log("loop built")
     it = 0
     for _ in range(args.warmup):
         loop.step(it, allreduce)
         it += 1
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % it)
     prof = GemmProfiler()
     restore = install_gemm_profiler(prof)
     rays = 0
@@ -198,6 +239,8 @@ def main():
         _, r = loop.step(it, allreduce)
         rays += int(r)
         it += 1
+        if it % 5 == 0:
+            log("step %d" % it)
     torch.cuda.synchronize()
     rdist.barrier()
     elapsed = time.perf_counter() - t0
@@ -247,10 +290,15 @@ def main():
                                 "launches": gs["launches"], "avg_launch_us": round(gs["avg_us"], 2),
                                 "avg_launch_gflop": round(gs["avg_flops"] / 1e9, 3),
                                 "share_of_step": round(gs["seconds"] / elapsed, 3)}
+        log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
+        if getattr(loop, "phase_ms", None):
+            log("phase ms (RECMV_TIMING=1, incl. warm-up): " + json.dumps({k: round(v, 1) for k, v in loop.phase_ms.items()}))
         if not args.no_mc:
             line.update(mc_extract_timing(device))
+            log("MC extraction timing done")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.conf)
+            log("CPU baseline done")
         print(json.dumps(line), flush=True)
     rdist.barrier()
     if tdist.is_initialized():

@@ -28,7 +28,10 @@ closed-form singular values on the device (`singular_values_3x3`).
 """
 from __future__ import annotations
 
+import contextlib
 import math
+import os
+import time
 
 import numpy as np
 import torch
@@ -192,6 +195,21 @@ class HotLoop:
         self.angThred = cams.angThreshold(0.5)                                   # OptimNetwork.py:65
 
     # ------------------------------------------------------------------------------------------ helpers
+    @contextlib.contextmanager
+    def _phase(self, name):
+        """Wall time per phase of an iteration into self.phase_ms when RECMV_TIMING=1 (adds device syncs)."""
+        if os.environ.get('RECMV_TIMING', '0') != '1':
+            yield
+            return
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        yield
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        acc = self.__dict__.setdefault('phase_ms', {})
+        acc[name] = acc.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+
     def _cameras(self):
         focals, pps, Rs, Ts, H, W = self.dataset.get_camera_parameters(1, self.device)
         return RectifiedPerspectiveCameras(focals, pps, Rs, Ts, image_size=[(W, H)])
@@ -415,17 +433,24 @@ class HotLoop:
         self.info = {}
         cameras = self._cameras()
         if self.body_vs is None or self.forward_time % self.remesh_intersect == 0:
-            self.marching_cube_update(ratio)
+            with self._phase('remesh'):
+                self.marching_cube_update(ratio)
         total_loss = 0.
         self.optimizer.zero_grad()                                                         # :1934
-        def_vs, pc_sdf_loss = self.mask_loss(N, frame_ids, ratio, cameras)
+        with self._phase('mask_loss'):
+            def_vs, pc_sdf_loss = self.mask_loss(N, frame_ids, ratio, cameras)
         total_loss = total_loss + pc_sdf_loss
         d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
         cameras = self._cameras()                                                          # rebuilt graph (:1036)
-        samples = self.sample_train_ray(N, def_vs, cameras)
-        init_ps_list, checks = self.opt_garment_surface_ps(frame_ids, cameras, ratio, samples)
-        total_loss = total_loss + self.surface_render_loss(N, cameras, frame_ids, ratio, checks, init_ps_list, samples)
-        total_loss = total_loss + self.dct_poses_loss(poses, trans, frame_ids, N)
+        with self._phase('sample_rays'):
+            samples = self.sample_train_ray(N, def_vs, cameras)
+        with self._phase('root_find'):
+            init_ps_list, checks = self.opt_garment_surface_ps(frame_ids, cameras, ratio, samples)
+        with self._phase('render_loss_fwd'):
+            total_loss = total_loss + self.surface_render_loss(N, cameras, frame_ids, ratio, checks, init_ps_list,
+                                                               samples)
+        with self._phase('dct'):
+            total_loss = total_loss + self.dct_poses_loss(poses, trans, frame_ids, N)
         self.forward_time += 1
         return total_loss
 
@@ -510,11 +535,14 @@ class HotLoop:
         ratio = {'sdfRatio': 1., 'deformerRatio': self.opt_times / 2500. + 0.5, 'renderRatio': 1.}
         self._allreduce = allreduce
         loss = self.forward(frame_ids, ratio)
-        loss.backward()
-        self.propagateTmpPsGrad(frame_ids, ratio)
-        if allreduce is not None:
-            allreduce([p for p in self.shared_parameters()])
-        self.optimizer.step()
+        with self._phase('backward'):
+            loss.backward()
+        with self._phase('propagate'):
+            self.propagateTmpPsGrad(frame_ids, ratio)
+        with self._phase('allreduce+adam'):
+            if allreduce is not None:
+                allreduce([p for p in self.shared_parameters()])
+            self.optimizer.step()
         self.opt_times += 1.
         return loss.detach(), self.info['rays_total']
 

@@ -37,20 +37,24 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb) {
   return (b % kNumXCD) * per + b / kNumXCD;
 }
 
-__device__ __forceinline__ float apply_act(float z, int act, float p) {
-  switch (act) {
-    case RECMV_ACT_RELU:
-      return z > 0.f ? z : 0.f;
-    case RECMV_ACT_SOFTPLUS: {
-      // nn.Softplus(beta=p, threshold=20): x*beta > 20 ? x : log1p(exp(x*beta))/beta
-      const float zb = z * p;
-      return zb > 20.f ? z : log1pf(expf(zb)) / p;
-    }
-    case RECMV_ACT_TANH:
-      return tanhf(z);
-    default:
-      return z;
+// Activations of the fused epilogue.  ACT is a compile-time constant inside the epilogue loops.
+//   softplus(beta): torch semantics (x*beta > 20 ? x : log1p(exp(x*beta))/beta), evaluated as
+//   (max(zb,0) + log1p(exp(-|zb|))) / beta with the hardware exp2/log2 units: exp(-|zb|) = t in (0,1];
+//   log1p(t) by its alternating series below 2^-6 (keeps the relative accuracy of tiny outputs, which the
+//   backward recovers sigmoid(zb) = 1 - exp(-beta*y) from) and log(1+t) above.  |error| < 2e-7/beta.
+template <int ACT>
+__device__ __forceinline__ float apply_act(float z, float p, float inv_p) {
+  if (ACT == RECMV_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (ACT == RECMV_ACT_SOFTPLUS) {
+    const float zb = z * p;
+    const float t = __expf(-fabsf(zb));
+    const float series = t * (1.f - t * (0.5f - t * (0.33333334f - 0.25f * t)));
+    const float l = t < 0.015625f ? series : __logf(1.f + t);
+    const float y = (fmaxf(zb, 0.f) + l) * inv_p;
+    return zb > 20.f ? z : y;
   }
+  if (ACT == RECMV_ACT_TANH) return tanhf(z);
+  return z;
 }
 
 // 4 consecutive floats of a row, zero-filled past `limit` (elements left in the row).
@@ -70,13 +74,62 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int64
 // ------------------------------------------------------------------------------------------ NT
 // T = MFMA tiles per wave along each dimension: T=2 -> 128x128 workgroup tile (large M), T=1 -> 64x64
 // (small M: the ray path launches 3k-6k rows, 128-tiles would leave most of the 256 CUs idle).
-template <int T>
+// FAST: both operands 16-byte aligned with row strides and K multiples of 4 -> every staging load is one
+// unconditional-address global_load_dwordx4 (rows clamped to the last valid row, k tail zero-filled per
+// float4); otherwise the element-guarded loader.
+//
+// Epilogue: the accumulators go through LDS (the operand buffers are dead by then) and are written out by a
+// compact loop — each thread owns a fixed 4-column strip, adds its bias float4, applies the activation and
+// issues 16-byte row-contiguous stores.  (A fully unrolled per-accumulator-register epilogue costs 64 copies
+// of the activation per thread: more instruction bytes than the instruction cache holds, and 4-byte stores.)
+template <int T, int ACT>
+__device__ __forceinline__ void nt_epilogue(const float* __restrict__ Cs, const float* __restrict__ bias,
+                                            float* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
+                                            float act_param, float out_scale, bool c_vec) {
+  constexpr int TBM = 64 * T, TBN = 64 * T, LDC = TBN + 4;
+  constexpr int C4 = TBN / 4;                 // float4 strips per tile row (32 or 16): divides kBlk
+  constexpr int ROWS_PER_PASS = kBlk / C4;    // 8 or 16
+  const int tid = threadIdx.x;
+  const int c4 = tid % C4, r0 = tid / C4;
+  const int gn = n0 + c4 * 4;
+  if (gn >= N) return;
+  const float inv_p = act_param != 0.f ? 1.f / act_param : 0.f;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) {
+    bv.x = bias[gn];
+    if (gn + 1 < N) bv.y = bias[gn + 1];
+    if (gn + 2 < N) bv.z = bias[gn + 2];
+    if (gn + 3 < N) bv.w = bias[gn + 3];
+  }
+  const bool full4 = c_vec && gn + 4 <= N;
+#pragma unroll 2
+  for (int row = r0; row < TBM; row += ROWS_PER_PASS) {
+    const int gm = m0 + row;
+    if (gm >= M) break;
+    float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
+    v.x = apply_act<ACT>(v.x + bv.x, act_param, inv_p) * out_scale;
+    v.y = apply_act<ACT>(v.y + bv.y, act_param, inv_p) * out_scale;
+    v.z = apply_act<ACT>(v.z + bv.z, act_param, inv_p) * out_scale;
+    v.w = apply_act<ACT>(v.w + bv.w, act_param, inv_p) * out_scale;
+    float* dst = C + (int64_t)gm * ldc + gn;
+    if (full4) {
+      *reinterpret_cast<float4*>(dst) = v;
+    } else {
+      dst[0] = v.x;
+      if (gn + 1 < N) dst[1] = v.y;
+      if (gn + 2 < N) dst[2] = v.z;
+      if (gn + 3 < N) dst[3] = v.w;
+    }
+  }
+}
+
+template <int T, bool FAST>
 __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ B, int64_t ldb,
                                                        const float* __restrict__ bias, float* __restrict__ C,
                                                        int64_t ldc, int M, int N, int K, int act,
                                                        float act_param, float out_scale, int nbm, int nbn,
-                                                       bool a_vec, bool b_vec) {
+                                                       bool a_vec, bool b_vec, bool c_vec) {
   constexpr int TBM = 64 * T, TBN = 64 * T;     // workgroup tile
   constexpr int WT = 32 * T;                    // wave tile edge
   constexpr int NLD = TBM * 8 / kBlk;           // float4 per thread per operand tile (4 or 2)
@@ -99,15 +152,35 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
 
   // staging map: TBM*8 float4 per operand tile; row = idx/8, c4 = idx%8
   float4 ra[NLD], rb[NLD];
+  const float* pa[NLD];
+  const float* pb[NLD];
+  if (FAST) {
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+      const int idx = tid + kBlk * r;
+      const int row = idx >> 3, c4 = idx & 7;
+      int gm = m0 + row, gn = n0 + row;
+      gm = gm < M ? gm : M - 1;                 // clamped rows are computed and never stored
+      gn = gn < N ? gn : N - 1;
+      pa[r] = A + (int64_t)gm * lda + c4 * 4;
+      pb[r] = B + (int64_t)gn * ldb + c4 * 4;
+    }
+  }
   auto gload = [&](int k0) {
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
       const int idx = tid + kBlk * r;
       const int row = idx >> 3, c4 = idx & 7;
       const int k = k0 + c4 * 4;
-      const int gm = m0 + row, gn = n0 + row;
-      ra[r] = (gm < M) ? load4_guard(A + (int64_t)gm * lda + k, K - k, a_vec) : make_float4(0, 0, 0, 0);
-      rb[r] = (gn < N) ? load4_guard(B + (int64_t)gn * ldb + k, K - k, b_vec) : make_float4(0, 0, 0, 0);
+      if (FAST) {
+        const bool in = k < K;                  // K % 4 == 0: a float4 is entirely inside or outside
+        ra[r] = in ? *reinterpret_cast<const float4*>(pa[r] + k0) : make_float4(0, 0, 0, 0);
+        rb[r] = in ? *reinterpret_cast<const float4*>(pb[r] + k0) : make_float4(0, 0, 0, 0);
+      } else {
+        const int gm = m0 + row, gn = n0 + row;
+        ra[r] = (gm < M) ? load4_guard(A + (int64_t)gm * lda + k, K - k, a_vec) : make_float4(0, 0, 0, 0);
+        rb[r] = (gn < N) ? load4_guard(B + (int64_t)gn * ldb + k, K - k, b_vec) : make_float4(0, 0, 0, 0);
+      }
     }
   };
   auto lstore = [&](int buf) {
@@ -152,20 +225,32 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
     __syncthreads();
   }
 
-  // epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // accumulators -> LDS: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  constexpr int LDC = TBN + 4;
+  float* Cs = smem;                        // [TBM][LDC] <= the operand buffers
 #pragma unroll
-  for (int ni = 0; ni < T; ++ni) {
-    const int gn = n0 + wn * WT + ni * 32 + (lane & 31);
-    if (gn >= N) continue;
-    const float bv = bias ? bias[gn] : 0.f;
+  for (int mi = 0; mi < T; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < T; ++mi) {
+    for (int ni = 0; ni < T; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int gm = m0 + wm * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (gm < M) C[(int64_t)gm * ldc + gn] = apply_act(acc[mi][ni][r] + bv, act, act_param) * out_scale;
+        const int row = wm * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = wn * WT + ni * 32 + (lane & 31);
+        Cs[row * LDC + col] = acc[mi][ni][r];
       }
-    }
+  __syncthreads();
+  switch (act) {
+    case RECMV_ACT_RELU:
+      nt_epilogue<T, RECMV_ACT_RELU>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      break;
+    case RECMV_ACT_SOFTPLUS:
+      nt_epilogue<T, RECMV_ACT_SOFTPLUS>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      break;
+    case RECMV_ACT_TANH:
+      nt_epilogue<T, RECMV_ACT_TANH>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      break;
+    default:
+      nt_epilogue<T, RECMV_ACT_NONE>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
   }
 }
 
@@ -327,6 +412,24 @@ int tn_splits(int64_t M, int64_t N, int64_t K) {
 
 using namespace recmv;
 
+template <int T, bool FAST>
+static int launch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
+                     int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
+                     bool a_vec, bool b_vec, bool c_vec, hipStream_t stream) {
+  constexpr int lds = kNtLds / (T == 2 ? 1 : 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, FAST>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int nbm = (int)ceil_div(M, 64 * T), nbn = (int)ceil_div(N, 64 * T);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, FAST>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds, stream, A, lda,
+                     B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, a_vec, b_vec,
+                     c_vec);
+  return check_launch("gemm_nt");
+}
+
 extern "C" int recmv_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
                              float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
                              float act_param, float out_scale, void* stream) {
@@ -336,27 +439,22 @@ extern "C" int recmv_gemm_nt(const float* A, int64_t lda, const float* B, int64_
   RECMV_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt: leading dimension too small");
   RECMV_REQUIRE(M < (1ll << 31) - BM && N < (1ll << 31) - BN && K < (1ll << 31) - BK, "gemm_nt: size overflow");
   RECMV_REQUIRE(act >= RECMV_ACT_NONE && act <= RECMV_ACT_TANH, "gemm_nt: unknown activation %d", act);
-  static bool attr_set = false;
-  if (!attr_set) {
-    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kNtLds));
-    attr_set = true;
-  }
   const bool a_vec = aligned16(A) && lda % 4 == 0, b_vec = aligned16(B) && ldb % 4 == 0;
+  const bool c_vec = aligned16(C) && ldc % 4 == 0;
+  const bool fast = a_vec && b_vec && K % 4 == 0 && K > 0;
+  hipStream_t s = (hipStream_t)stream;
   // tile choice: 128x128 tiles unless they would leave the 256 CUs under-filled (< 2 workgroups per CU)
   const int64_t big_blocks = ceil_div(M, BM) * ceil_div(N, BN);
   if (big_blocks >= 2 * kNumCU) {
-    const int nbm = (int)ceil_div(M, BM), nbn = (int)ceil_div(N, BN);
-    hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), kNtLds,
-                       (hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param,
-                       out_scale, nbm, nbn, a_vec, b_vec);
-  } else {
-    const int nbm = (int)ceil_div(M, 64), nbn = (int)ceil_div(N, 64);
-    hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), kNtLds / 2,
-                       (hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param,
-                       out_scale, nbm, nbn, a_vec, b_vec);
+    return fast ? launch_nt<2, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec, b_vec,
+                                     c_vec, s)
+                : launch_nt<2, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec, b_vec,
+                                      c_vec, s);
   }
-  return check_launch("gemm_nt");
+  return fast ? launch_nt<1, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec, b_vec,
+                                   c_vec, s)
+              : launch_nt<1, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec, b_vec,
+                                    c_vec, s);
 }
 
 extern "C" int64_t recmv_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {

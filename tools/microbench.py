@@ -138,6 +138,8 @@ def bench_gemm(quick):
         out = torch.empty(M, N, device=DEV)
         t, b = timeit(lambda: ops.gemm_nt(A, B, bias, ops.ACT_SOFTPLUS, 100.0, 1.0, out=out))
         report(f"gemm_nt+bias+softplus M={M} N={N} K={K}", t, b, flops=2.0 * M * N * K)
+        t, b = timeit(lambda: ops.gemm_nt(A, B, None, ops.ACT_NONE, 0.0, 1.0, out=out))
+        report(f"gemm_nt (no bias/act) M={M} N={N} K={K}", t, b, flops=2.0 * M * N * K)
         t, b = timeit(lambda: torch.nn.functional.softplus(torch.addmm(bias, A, B.t()), beta=100))
         report(f"  (torch addmm+softplus / rocBLAS, for scale) M={M} N={N} K={K}", t, b, flops=2.0 * M * N * K)
     for K, M, N in ([(153600, 512, 512)] if quick else [(460800, 512, 512), (153600, 512, 512), (6144, 512, 512),

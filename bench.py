@@ -50,26 +50,42 @@ HBM_PEAK = 8.0e12             # B/s
 
 
 class GemmProfiler:
-    """Collects (start, end) events + algorithmic FLOPs of every gemm_nt launch."""
+    """Collects (start, end) HIP events + algorithmic FLOPs of every gemm_nt launch, keyed by the kernel variant the
+    C launcher will pick (same rule as recmv_gemm_nt in csrc/gemm_f32.hip), so that the numbers can be compared with
+    the per-kernel averages of a rocprofv3 --kernel-trace of the same command.  The events are recorded on torch's
+    current stream, which is the stream the kernels are launched on."""
 
     def __init__(self):
-        self.records = []
+        self.records = {}
 
-    def launch(self, flops, fn):
+    def launch(self, key, flops, fn):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         out = fn()
         b.record()
-        self.records.append((a, b, flops))
+        self.records.setdefault(key, []).append((a, b, flops))
         return out
 
     def summary(self):
-        if not self.records:
-            return None
-        t = sum(a.elapsed_time(b) for a, b, _ in self.records) * 1e-3
-        fl = sum(f for _, _, f in self.records)
-        n = len(self.records)
-        return dict(launches=n, seconds=t, flops=fl, avg_us=t / n * 1e6, avg_flops=fl / n)
+        out = {}
+        for key, recs in self.records.items():
+            t = sum(a.elapsed_time(b) for a, b, _ in recs) * 1e-3
+            fl = sum(f for _, _, f in recs)
+            n = len(recs)
+            out[key] = dict(launches=n, seconds=t, flops=fl, avg_us=t / n * 1e6, avg_flops=fl / n)
+        return out
+
+
+def _nt_variant(A, B, out):
+    """Kernel variant chosen by recmv_gemm_nt (csrc/gemm_f32.hip): tile 128 (T=2) when >= 2 workgroups per CU."""
+    M, K = A.shape
+    N = B.shape[0]
+    big = -(-M // 128) * -(-N // 128) >= 512
+
+    def vec(t):
+        return t.data_ptr() % 16 == 0 and (t.shape[0] <= 1 or t.stride(0) % 4 == 0)
+    fast = vec(A) and vec(B) and K % 4 == 0 and K > 0
+    return "gemm_nt_kernel<%d, %s>" % (2 if big else 1, "true" if fast else "false")
 
 
 def install_gemm_profiler(prof):
@@ -78,7 +94,8 @@ def install_gemm_profiler(prof):
 
     def wrapped(A, B, bias=None, act=ops.ACT_NONE, act_param=0.0, out_scale=1.0, out=None):
         flops = 2.0 * A.shape[0] * B.shape[0] * A.shape[1]
-        return prof.launch(flops, lambda: orig(A, B, bias, act, act_param, out_scale, out))
+        A, B = ops._rowmajor(A), ops._rowmajor(B)
+        return prof.launch(_nt_variant(A, B, out), flops, lambda: orig(A, B, bias, act, act_param, out_scale, out))
 
     ops.gemm_nt = wrapped
     return lambda: setattr(ops, "gemm_nt", orig)
@@ -231,6 +248,8 @@ def main():
         log("warm-up step %d done" % it)
     prof = GemmProfiler()
     restore = install_gemm_profiler(prof)
+    if getattr(loop, "phase_ms", None):
+        loop.phase_ms = {}          # RECMV_TIMING=1: report the timed steps only
     rays = 0
     rdist.barrier()
     torch.cuda.synchronize()
@@ -283,16 +302,21 @@ def main():
             },
         }
         if gs:
-            ach = gs["flops"] / gs["seconds"]
-            line["roofline"] = {"kernel": "recmv::gemm_nt_kernel (fused f32-MFMA layer: GEMM+bias+activation)",
+            dom = max(gs, key=lambda k: gs[k]["seconds"])
+            g = gs[dom]
+            ach = g["flops"] / g["seconds"]
+            line["roofline"] = {"kernel": "recmv::" + dom + " (fused f32-MFMA layer: GEMM + bias + activation)",
                                 "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": MFMA_F32_PEAK / 1e12,
                                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), "traffic": None,
-                                "launches": gs["launches"], "avg_launch_us": round(gs["avg_us"], 2),
-                                "avg_launch_gflop": round(gs["avg_flops"] / 1e9, 3),
-                                "share_of_step": round(gs["seconds"] / elapsed, 3)}
+                                "launches": g["launches"], "avg_launch_us": round(g["avg_us"], 2),
+                                "avg_launch_gflop": round(g["avg_flops"] / 1e9, 3),
+                                "share_of_step": round(g["seconds"] / elapsed, 3),
+                                "other_variants": {k: {"launches": v["launches"], "avg_launch_us": round(v["avg_us"], 2),
+                                                       "achieved": round(v["flops"] / v["seconds"] / 1e12, 3)}
+                                                   for k, v in gs.items() if k != dom}}
         log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
         if getattr(loop, "phase_ms", None):
-            log("phase ms (RECMV_TIMING=1, incl. warm-up): " + json.dumps({k: round(v, 1) for k, v in loop.phase_ms.items()}))
+            log("phase ms (RECMV_TIMING=1, timed steps only): " + json.dumps({k: round(v, 1) for k, v in loop.phase_ms.items()}))
         if not args.no_mc:
             line.update(mc_extract_timing(device))
             log("MC extraction timing done")

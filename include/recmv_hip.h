@@ -196,6 +196,82 @@ int recmv_kinematic_chain_backward(const float* poses, const float* Js_host, con
                                    const float* init_pose, const float* gG, const float* gA, float* gposes,
                                    int64_t B, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Whole-MLP launch chains (csrc/mlp_chain.hip): ONE call enqueues every kernel of a graph-free pass through
+ * an MLP of the hot path — SDF net (model/network.py:98-133), offset MLP of the deformer
+ * (model/Deformer.py:141-206) — on the caller's stream.  Used by the surface root finder
+ * (utils/FindSurfacePs.py:273-353) and the no-grad grid queries of Seg3dLossless.
+ *
+ *   input   = [ gamma_L(x) | cond[cond_index[p]] ]                       (dims[0] = 3+6L+cond_dim)
+ *   layer l = hidden_act(h W[l]^T + bias[l]);  W[l] is [rows[l], dims[l]] row-major
+ *   layer l+1 == skip_layer: its input is [ layer l output | gamma_L(x) ] / sqrt(2)   (network.py:105-106)
+ *   last layer: no activation; only its first n_out rows are evaluated; residual: out = x + out (Deformer.py:201-206)
+ * Wt[l] = W[l]^T ([dims[l], rows[l]] row-major) is only read by recmv_mlp_vjp_input.
+ * pe_weights: the 2L annealing weights (utils/utils.py:40-46), ones when not annealed.
+ * ---------------------------------------------------------------------------------------------- */
+#define RECMV_MLP_MAX_LAYERS 12
+typedef struct recmv_mlp {
+  int32_t n_layers, multires, cond_dim, skip_layer /* -1: none */, hidden_act, residual;
+  float act_param;
+  int32_t dims[RECMV_MLP_MAX_LAYERS + 1];
+  int32_t rows[RECMV_MLP_MAX_LAYERS];
+  const float* W[RECMV_MLP_MAX_LAYERS];
+  const float* Wt[RECMV_MLP_MAX_LAYERS];
+  const float* bias[RECMV_MLP_MAX_LAYERS];
+  float pe_weights[32];
+} recmv_mlp;
+
+/* keep = 1 lays every layer's activation out separately (needed by recmv_mlp_vjp_input); keep = 0 ping-pongs. */
+int64_t recmv_mlp_workspace_bytes(const recmv_mlp* m, int64_t P, int keep);
+/* x [P,3]; cond [*, cond_dim] with row stride ld_cond, cond_index [P] (NULL: row 0 for every point); out [P,n_out]. */
+int recmv_mlp_forward(const recmv_mlp* m, const float* x, const float* cond, int64_t ld_cond,
+                      const int64_t* cond_index, int64_t P, int n_out, float* out, int64_t ldo,
+                      void* workspace, int64_t workspace_bytes, int keep, void* stream);
+/* gx [P,3] = J(x)^T g_out after recmv_mlp_forward(keep=1) on the same workspace.  g_out [P,n_out] (row stride
+ * ldg), or NULL = ones with n_out == 1 (gradient of the scalar output). */
+int recmv_mlp_vjp_input(const recmv_mlp* m, const float* x, int64_t P, int n_out, const float* g_out, int64_t ldg,
+                        float* gx, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Strided element-wise helpers of the chains:
+ *   recmv_act_grad_2d   : out[r,c] = out_scale * gy[r,c] * act'(z),  y = act(z) = y_scale * ybuf[r,c]; ldg may be 0
+ *   recmv_add_scaled_2d : out[r,c] = a[r,c] + s * b[r,c]                                                       */
+int recmv_act_grad_2d(const float* gy, int64_t ldg, const float* y, int64_t ldy, float* out, int64_t ldo,
+                      int64_t rows, int64_t cols, int act, float act_param, float y_scale, float out_scale,
+                      void* stream);
+int recmv_add_scaled_2d(const float* a, int64_t lda, const float* b, int64_t ldb, float s, float* out, int64_t ldo,
+                        int64_t rows, int64_t cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused linear-blend skinning on ray points and the root finder's per-ray step (csrc/lbs_fused.hip).
+ *   replaces LBSkinner.forward with batch_inds (model/Deformer.py:405-445) and its input gradient, and the
+ *   energy / update arithmetic of OptimizeGarmentSurfacePs (utils/FindSurfacePs.py:316-351), no autograd.
+ * grid: the skinning-weight volume, CHANNELS-LAST [D,H,W,24] f32 (the memory of a torch channels_last_3d
+ * [1,24,D,H,W] tensor), sampled trilinearly at (p - center) * scale (scale = 2 / bbox extent) with the
+ * GridSamplerMine semantics (border padding, align_corners=False).
+ *   recmv_lbs_forward   : d = (sum_j w_j A[frame,j]) [p;1] + trans[frame];  A [B,24,4,4], trans [B,3].
+ *                         With rays [P,3] and cam [3] (device): loss2 = |(d-c) x v| / |d-c|, angle (degrees) and
+ *                         g_d = d loss2 / d d.  rays == NULL skips those outputs.
+ *   recmv_lbs_vjp_input : g_p [P,3] = J_d(p)^T g_d.
+ *   recmv_rootfind_update: unfinished &= !(|f| < dthreshold && angle < athreshold); on unfinished rays (and
+ *                         do_update != 0) p -= E grad / |grad|^2 with E = w1|f| + w2 loss2,
+ *                         grad = w1 sign(f) gf + w2 gd; *counter += number of unfinished rays.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct recmv_lbs_grid {
+  const float* volume;
+  int64_t D, H, W;
+  float center[3];
+  float scale[3];
+} recmv_lbs_grid;
+
+int recmv_lbs_forward(const float* ps, const int64_t* frame, int64_t P, const float* A, const float* trans,
+                      int64_t B, const recmv_lbs_grid* grid, const float* cam, const float* rays, float* d,
+                      float* loss2, float* angle, float* g_d, void* stream);
+int recmv_lbs_vjp_input(const float* ps, const int64_t* frame, int64_t P, const float* A, int64_t B,
+                        const recmv_lbs_grid* grid, const float* g_d, float* g_p, void* stream);
+int recmv_rootfind_update(float* p, const float* f, const float* gf, const float* loss2, const float* angle,
+                          const float* gd, uint8_t* unfinished, int32_t* counter, int64_t P, float dthreshold,
+                          float athreshold, float w1, float w2, int do_update, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,78 +40,7 @@ inline Desc5 to_desc(const recmv_tensor5* t) {
   return d;
 }
 
-// All arithmetic un-contracted except the explicit fma() calls, so the result is a fixed sequence of
-// IEEE operations that the CPU oracle (oracle/recmv_oracle.c) reproduces bit for bit.
-#pragma clang fp contract(off)
-
-template <typename T>
-__device__ __forceinline__ T unnormalize(T x, int64_t size) {
-  // reference: ix = ((ix + 1.f) * inp_W - 1.) / 2.;   f32: product in f32, then double, then f32
-  T a = (x + (T)1.f) * (T)size;
-  return (T)(((double)a - 1.) / 2.);
-}
-
-template <typename T>
-__device__ __forceinline__ T clip_set_grad(T in, int64_t clip_limit, T* mult) {
-  if (in <= (T)0) {
-    *mult = (T)0;
-    return (T)0;
-  }
-  T mx = (T)(clip_limit - 1);
-  if (in >= mx) {
-    *mult = (T)0;
-    return mx;
-  }
-  *mult = (T)1;
-  return in;
-}
-
-template <typename T>
-__device__ __forceinline__ T safe_downgrade(T x) {
-  // GridSamplerMineKernel.cu:118-127
-  if (x > (T)(INT_MAX - 1) || x < (T)INT_MIN || !isfinite((double)x)) return (T)(-100.0);
-  return x;
-}
-
-// Per-point geometry shared by the three kernels.
-template <typename T>
-struct Cell {
-  int x0, y0, z0;      // floor corner
-  T fx[2], fy[2], fz[2];  // f*[0] = (c1 - c)  (weight of the low corner), f*[1] = (c - c0)
-  T mx, my, mz;        // clip gradient multipliers
-  bool in_x[2], in_y[2], in_z[2];
-};
-
-template <typename T>
-__device__ __forceinline__ Cell<T> make_cell(T gx, T gy, T gz, int64_t W, int64_t H, int64_t D) {
-  Cell<T> c;
-  T ix = unnormalize(gx, W), iy = unnormalize(gy, H), iz = unnormalize(gz, D);
-  ix = clip_set_grad(ix, W, &c.mx);
-  iy = clip_set_grad(iy, H, &c.my);
-  iz = clip_set_grad(iz, D, &c.mz);
-  ix = safe_downgrade(ix);
-  iy = safe_downgrade(iy);
-  iz = safe_downgrade(iz);
-  c.x0 = (int)floor(ix);
-  c.y0 = (int)floor(iy);
-  c.z0 = (int)floor(iz);
-  c.fx[0] = (T)(c.x0 + 1) - ix;
-  c.fx[1] = ix - (T)c.x0;
-  c.fy[0] = (T)(c.y0 + 1) - iy;
-  c.fy[1] = iy - (T)c.y0;
-  c.fz[0] = (T)(c.z0 + 1) - iz;
-  c.fz[1] = iz - (T)c.z0;
-  c.in_x[0] = c.x0 >= 0 && c.x0 < W;
-  c.in_x[1] = c.x0 + 1 >= 0 && c.x0 + 1 < W;
-  c.in_y[0] = c.y0 >= 0 && c.y0 < H;
-  c.in_y[1] = c.y0 + 1 >= 0 && c.y0 + 1 < H;
-  c.in_z[0] = c.z0 >= 0 && c.z0 < D;
-  c.in_z[1] = c.z0 + 1 >= 0 && c.z0 + 1 < D;
-  return c;
-}
-
-// corner k in the reference order tnw,tne,tsw,tse,bnw,bne,bsw,bse:  bx = k&1, by = (k>>1)&1, bz = k>>2
-#define RECMV_CORNER_BITS(k) const int bx = (k) & 1, by = ((k) >> 1) & 1, bz = (k) >> 2
+#include "gs3d_common.inc"
 
 template <typename T, int VEC>
 struct VecLoad;

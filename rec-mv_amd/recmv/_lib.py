@@ -24,6 +24,24 @@ class Tensor5(C.Structure):
     _fields_ = [("size", C.c_int64 * 5), ("stride", C.c_int64 * 5)]
 
 
+MLP_MAX_LAYERS = 12
+
+
+class Mlp(C.Structure):
+    """recmv_mlp of include/recmv_hip.h."""
+    _fields_ = [("n_layers", C.c_int32), ("multires", C.c_int32), ("cond_dim", C.c_int32), ("skip_layer", C.c_int32),
+                ("hidden_act", C.c_int32), ("residual", C.c_int32), ("act_param", C.c_float),
+                ("dims", C.c_int32 * (MLP_MAX_LAYERS + 1)), ("rows", C.c_int32 * MLP_MAX_LAYERS),
+                ("W", C.c_void_p * MLP_MAX_LAYERS), ("Wt", C.c_void_p * MLP_MAX_LAYERS),
+                ("bias", C.c_void_p * MLP_MAX_LAYERS), ("pe_weights", C.c_float * 32)]
+
+
+class LbsGrid(C.Structure):
+    """recmv_lbs_grid of include/recmv_hip.h."""
+    _fields_ = [("volume", C.c_void_p), ("D", C.c_int64), ("H", C.c_int64), ("W", C.c_int64),
+                ("center", C.c_float * 3), ("scale", C.c_float * 3)]
+
+
 _lib = None
 
 
@@ -68,6 +86,14 @@ def _declare(lib):
         "recmv_posenc_jvp": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i32, vp, vp]),
         "recmv_kinematic_chain_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp]),
         "recmv_kinematic_chain_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+        "recmv_mlp_workspace_bytes": (i64, [C.POINTER(Mlp), i64, i32]),
+        "recmv_mlp_forward": (C.c_int, [C.POINTER(Mlp), vp, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp]),
+        "recmv_mlp_vjp_input": (C.c_int, [C.POINTER(Mlp), vp, i64, i32, vp, i64, vp, vp, i64, vp]),
+        "recmv_act_grad_2d": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i32, f32, f32, f32, vp]),
+        "recmv_add_scaled_2d": (C.c_int, [vp, i64, vp, i64, f32, vp, i64, i64, i64, vp]),
+        "recmv_lbs_forward": (C.c_int, [vp, vp, i64, vp, vp, i64, C.POINTER(LbsGrid), vp, vp, vp, vp, vp, vp, vp]),
+        "recmv_lbs_vjp_input": (C.c_int, [vp, vp, i64, vp, i64, C.POINTER(LbsGrid), vp, vp, vp]),
+        "recmv_rootfind_update": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)       # AttributeError if the symbol is missing: fail loudly

@@ -107,6 +107,19 @@ class CompositeDeformer(nn.Module):
             g = deformer.backward_input(sv, g)
         return out, g
 
+    @torch.no_grad()
+    def ray_energy_and_vjp(self, ps, conds, batch_inds, cam, rays, **kwargs):
+        """For the root finder: E2 = |(d-c) x v| / |d-c| of d = deformer(ps), its angle (degrees) and
+        J_d(ps)^T dE2/dd — four C calls (offset-MLP chain, fused skinning + energy, skinning VJP, MLP chain VJP)."""
+        assert self.N == 2, "offset MLP followed by the LBS skinner (model/network.py:282-283)"
+        mlp, lbs = self.defs[0], self.defs[1]
+        mid, sv0 = mlp.forward_explicit(ps, conds[0], batch_inds, **kwargs)
+        d, sv1 = lbs.forward_explicit(mid, conds[1], batch_inds, cam=cam, rays=rays, **kwargs)
+        loss2, angle, g_d = sv1[3], sv1[4], sv1[5]
+        g = lbs.backward_input(sv1, g_d)
+        g = mlp.backward_input(sv0, g)
+        return d, loss2, angle, g
+
 
 class MLPTranslator(nn.Module):
     def __init__(self, feature_vector_size, multires, weight_norm=False):
@@ -159,45 +172,41 @@ class MLPTranslator(nn.Module):
             return ps[..., :3] + x.view(ps.shape[0], ps.shape[1], 3)
 
 
-def _translator_explicit(self, ps, conds, batch_inds, **kwargs):
-    """Explicit forward of MLPTranslator for 2-D `ps` with `batch_inds` (the ray path)."""
-    ratio = kwargs['ratio']['deformerRatio']
+def _translator_chain(self, ratio):
+    """MlpChain of the offset MLP for the annealing state `ratio` (cached on the parameters' versions)."""
+    from ..chains import MlpChain
     ws = None if ratio is None else ([0.] * (self.multires * 2) if ratio <= 0 else
                                      annealing_weights(self.multires, ratio))
     wl = None if ws is None else tuple(float(w) for w in ws)
-    P, dev = ps.shape[0], ps.device
-    ps = ps.detach().contiguous()
-    d_pe = 3 + 6 * self.multires
-    d_in = d_pe + self.feature_vector_size
-    d_inp = (d_in + 3) // 4 * 4
-    x = torch.zeros((P, d_inp), dtype=torch.float32, device=dev)
-    ops.posenc(ps, self.multires, wl, 1.0, out=x[:, :d_pe], ld_fill=d_pe)
-    x[:, d_pe:d_in] = conds.detach().index_select(0, batch_inds)
-    h = x[:, :d_in]
-    acts = []
     nl = self.num_layers - 1
-    for l in range(nl):
-        lin = getattr(self, "lin" + str(l))
-        h = ops.gemm_nt(h, lin.weight.detach(), lin.bias.detach(), ops.ACT_NONE if l == nl - 1 else ops.ACT_RELU)
-        acts.append(h)
-    off = acts[-1]
-    self.offset[kwargs.get('offset_type', None)] = off
-    return ps + off, (ps, acts, wl, d_pe)
+    lins = [getattr(self, "lin" + str(l)) for l in range(nl)]
+    key = (wl,) + tuple((lin.weight._version, lin.weight.data_ptr(), lin.bias._version) for lin in lins)
+    hit = self.__dict__.get('_chain_cache')
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    Ws = [lin.weight.detach().contiguous() for lin in lins]
+    bs = [lin.bias.detach() for lin in lins]
+    Wts = [_cached_t(self, l, lins[l].weight) for l in range(nl)]
+    dims = [Ws[0].shape[1]] + [W.shape[0] for W in Ws]
+    ch = MlpChain(Ws, bs, Wts, dims, [W.shape[0] for W in Ws], self.multires, cond_dim=self.feature_vector_size,
+                  skip_layer=-1, hidden_act=ops.ACT_RELU, act_param=0.0, residual=True, pe_weights=wl)
+    self.__dict__['_chain_cache'] = (key, ch)
+    return ch
+
+
+def _translator_explicit(self, ps, conds, batch_inds, **kwargs):
+    """Explicit forward of MLPTranslator for 2-D `ps` with `batch_inds` (the ray path): one C call.
+    (The `.offset` side effect of forward() is not reproduced on this path; the autograd passes that follow in
+    the iteration overwrite it anyway, model/Deformer.py:201-205.)"""
+    ch = _translator_chain(self, kwargs['ratio']['deformerRatio'])
+    ps = ps.detach().contiguous()
+    out = ch.forward(ps, cond=conds.detach(), cond_index=batch_inds.contiguous(), n_out=3, keep=True)
+    return out, (ch, ps)
 
 
 def _translator_backward_input(self, saved, g_out):
-    ps, acts, wl, d_pe = saved
-    nl = self.num_layers - 1
-    g = g_out.contiguous()
-    for l in range(nl - 1, -1, -1):
-        lin = getattr(self, "lin" + str(l))
-        if l < nl - 1:
-            g = ops.act_grad(g, acts[l], ops.ACT_RELU, 0.0)
-        Wt = _cached_t(self, l, lin.weight)
-        g = ops.gemm_nt(g, Wt)
-    g_pe = g[:, :d_pe].contiguous()
-    g_pe[:, :3] += g_out                              # the `ps[..., :3] + offset` residual path
-    return ops._pe_vjp(ps, g_pe, None, self.multires, wl)
+    ch, ps = saved
+    return ch.vjp_input(ps, g_out.contiguous())
 
 
 def _cached_t(module, l, W):
@@ -380,40 +389,44 @@ class LBSkinner(nn.Module):
             return v.view(batch_size, pnum, 3)
         return v
 
+    # -- graph-free passes on ray points: fused kernels (csrc/lbs_fused.hip) ----------------------------
+    def _lbs_grid(self):
+        from ..chains import lbs_grid
+        hit = self.__dict__.get('_grid_cache')
+        if hit is None or hit[0] != self.ws.data_ptr():
+            center = self.bbox_center.detach().cpu().view(-1).tolist()
+            scale = (2.0 / self.bbox_extend.detach().cpu().view(-1)).tolist()
+            hit = (self.ws.data_ptr(), lbs_grid(self.ws, center, scale))
+            self.__dict__['_grid_cache'] = hit
+        return hit[1]
+
     @torch.no_grad()
-    def forward_explicit(self, ps, conds, batch_inds, **kwargs):
-        """Explicit (graph-free) forward for 2-D `ps` with `batch_inds`; see CompositeDeformer.value_and_vjp."""
-        from .. import GridSamplerMine
-        poses, trans = conds
-        trans = trans.detach() + self.extra_trans
-        B = poses.shape[0]
+    def _posed(self, poses, trans):
+        """(A [B,24,4,4], trans + extra_trans) for this pose tensor; cached while the same tensor is passed again
+        (the root finder evaluates the deformer up to 21 times with the same per-frame parameters)."""
+        hit = self.__dict__.get('_posed_cache')
+        if hit is not None and hit[0] is poses and hit[1] == poses._version and hit[2] is trans \
+                and hit[3] == trans._version:
+            return hit[4], hit[5]
         _, A = self._chain_fused(poses.detach())
+        t = (trans.detach() + self.extra_trans).contiguous()
+        self.__dict__['_posed_cache'] = (poses, poses._version, trans, trans._version, A.contiguous(), t)
+        return A, t
+
+    @torch.no_grad()
+    def forward_explicit(self, ps, conds, batch_inds, cam=None, rays=None, **kwargs):
+        """Explicit (graph-free) forward for 2-D `ps` with `batch_inds`: one fused kernel.  With `rays` and `cam` it
+        also returns the ray energy, its angle and its gradient wrt the deformed point."""
+        from .. import chains
+        poses, trans = conds
+        A, t = self._posed(poses, trans)
         ps = ps.detach().contiguous()
-        P = ps.shape[0]
-        scale = 2.0 / self.bbox_extend.view(1, 3)
-        nps = ((ps - self.bbox_center.view(1, 3)) * scale).contiguous()
-        grid = nps.view(1, 1, 1, P, 3)
-        w = GridSamplerMine.forward(self.ws, grid, 0, 1).view(24, P).t().contiguous()       # [P,24]
-        Ball = A.reshape(B, 24, 16).permute(0, 2, 1).reshape(B * 16, 24).contiguous()
-        Tall = ops.gemm_nt(w, Ball).view(P, B, 16)
-        T = Tall.gather(1, batch_inds.view(-1, 1, 1).expand(-1, 1, 16)).view(P, 4, 4)
-        v = (T[:, :3, :3] * ps.unsqueeze(-2)).sum(-1) + T[:, :3, 3] + trans.index_select(0, batch_inds)
-        return v, (ps, grid, T, A, batch_inds, scale, B)
+        frame = batch_inds.contiguous()
+        d, loss2, angle, g_d = chains.lbs_forward(ps, frame, A, t, self._lbs_grid(), cam, rays)
+        return d, (ps, frame, A, loss2, angle, g_d)
 
     @torch.no_grad()
     def backward_input(self, saved, g_v):
-        from .. import GridSamplerMine
-        ps, grid, T, A, batch_inds, scale, B = saved
-        P = ps.shape[0]
-        g_p = (T[:, :3, :3] * g_v.unsqueeze(-1)).sum(-2)                                    # T33^T g
-        # g_w[p,j] = sum_{i<3,k} g_v[p,i] * A[b_p,j,i,k] * [ps;1][k]
-        ph = torch.cat([ps, torch.ones(P, 1, device=ps.device)], dim=1)
-        gT = torch.zeros((P, 4, 4), dtype=torch.float32, device=ps.device)
-        gT[:, :3, :] = g_v.unsqueeze(-1) * ph.unsqueeze(-2)
-        gTall = torch.zeros((P, B, 16), dtype=torch.float32, device=ps.device)
-        gTall.scatter_(1, batch_inds.view(-1, 1, 1).expand(-1, 1, 16), gT.view(P, 1, 16))
-        BallT = A.reshape(B, 24, 16).permute(1, 0, 2).reshape(24, B * 16).contiguous()
-        g_w = ops.gemm_nt(gTall.view(P, B * 16), BallT)                                     # [P,24]
-        go = g_w.t().contiguous().view(1, 24, 1, 1, P)
-        _, g_grid = GridSamplerMine.backward(self.ws, grid, go, 0, 1, need_grad_input=False)
-        return g_p + g_grid.view(P, 3) * scale
+        from .. import chains
+        ps, frame, A = saved[0], saved[1], saved[2]
+        return chains.lbs_vjp_input(ps, frame, A, self._lbs_grid(), g_v.contiguous())

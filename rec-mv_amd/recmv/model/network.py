@@ -119,80 +119,53 @@ class ImplicitNetwork(nn.Module):
             x = ops.linear_act(x, W, b, ops.ACT_NONE if last else ops.ACT_SOFTPLUS, 100.0)
         return x
 
+    # -- graph-free passes: one C call per pass (csrc/mlp_chain.hip) ----------------------------------
     @torch.no_grad()
-    def _forward_inference(self, input, ws):
-        """No-grad path: posenc kernel + one fused kernel per layer, activations in padded buffers."""
-        P = input.shape[0]
-        dev = input.device
-        d0 = self.dims[0]
-        d0p = (d0 + 3) // 4 * 4
-        pe = torch.empty((P, d0p), dtype=torch.float32, device=dev)
-        ops.posenc(input, self.multires, ws, 1.0, out=pe, ld_fill=d0p)
-        x = pe[:, :d0]
-        for l in range(0, self.num_layers - 1):
+    def chain(self, ws, need_t=False):
+        """MlpChain over the (cached) weight-normed weights for the annealing weights `ws`."""
+        from ..chains import MlpChain
+        nl = self.num_layers - 1
+        Ws, bs = [], []
+        for l in range(nl):
             W, b = self._weight(l)
-            last = l == self.num_layers - 2
-            act = ops.ACT_NONE if last else ops.ACT_SOFTPLUS
-            if l + 1 in self.skip_in:
-                # write act(..)/sqrt(2) into the left part of the next layer's input and PE/sqrt(2) to its right
-                nxt = torch.empty((P, self.dims[l + 1]), dtype=torch.float32, device=dev)
-                n_out = W.shape[0]
-                ops.gemm_nt(x, W, b, act, 100.0, 1.0 / _SQRT2, out=nxt[:, :n_out])
-                ops.posenc(input, self.multires, ws, 1.0 / _SQRT2, out=nxt[:, n_out:], ld_fill=d0)
-                x = nxt
-            else:
-                x = ops.gemm_nt(x, W, b, act, 100.0, 1.0)
-        return x
+            Ws.append(W)
+            bs.append(b.detach())
+        hit = self.__dict__.get('_chain_cache')
+        wl = None if ws is None else tuple(float(w) for w in ws)
+        if hit is not None and hit[0] == wl and len(hit[1]) == nl and all(a is b for a, b in zip(hit[1], Ws)) \
+                and (hit[3] or not need_t):
+            return hit[2]
+        assert len(self.skip_in) <= 1, "one skip connection (the reference uses skip_in=[4])"
+        Wts = [self._weight_t(l, Ws[l]) for l in range(nl)] if need_t else None
+        ch = MlpChain(Ws, bs, Wts, list(self.dims), [W.shape[0] for W in Ws], self.multires, cond_dim=0,
+                      skip_layer=(self.skip_in[0] if len(self.skip_in) else -1), hidden_act=ops.ACT_SOFTPLUS,
+                      act_param=100.0, residual=False, pe_weights=wl)
+        self.__dict__['_chain_cache'] = (wl, Ws, ch, need_t)
+        return ch
+
+    @torch.no_grad()
+    def _forward_inference(self, input, ws, chunk=1 << 19):
+        """No-grad path: posenc + one fused kernel per layer, the whole chain enqueued by one C call per chunk."""
+        ch = self.chain(ws)
+        x = input.contiguous()
+        P = x.shape[0]
+        if P <= chunk:
+            return ch.forward(x)
+        out = torch.empty((P, self.dims[-1]), dtype=torch.float32, device=x.device)
+        for s in range(0, P, chunk):
+            ch.forward(x[s:s + chunk], out=out[s:s + chunk])
+        return out
 
     @torch.no_grad()
     def value_and_grad(self, x, ratio=None):
         """(f(x) [P,1], grad_x f [P,3]) without building an autograd graph: the explicit layer chain forward
-        (one fused kernel per layer) and the chain backward to the INPUT only (no parameter gradients).
+        (one fused kernel per layer) and the chain backward to the INPUT only (no parameter gradients), two C calls.
         Used by the surface root finder, which needs exactly this pair at every step
-        (utils/FindSurfacePs.py:316-333).  Values are identical to forward()/gradient()."""
-        ws = self._pe_weights(ratio)
-        wl = None if ws is None else tuple(float(w) for w in ws)
-        P, dev = x.shape[0], x.device
+        (utils/FindSurfacePs.py:316-333).  Values match forward()/gradient() to f32 rounding."""
+        ch = self.chain(self._pe_weights(ratio), need_t=True)
         x = x.detach().contiguous()
-        d0 = self.dims[0]
-        d0p = (d0 + 3) // 4 * 4
-        pe = torch.empty((P, d0p), dtype=torch.float32, device=dev)
-        ops.posenc(x, self.multires, wl, 1.0, out=pe, ld_fill=d0p)
-        h = pe[:, :d0]
-        acts, Ws = [], []
-        nl = self.num_layers - 1
-        for l in range(nl):
-            W, b = self._weight(l)
-            Ws.append(W)
-            last = l == nl - 1
-            if last:                                      # only the SDF column is needed here
-                h = ops.gemm_nt(h, W[:self.d_out], b[:self.d_out], ops.ACT_NONE, 0.0, 1.0)
-            elif l + 1 in self.skip_in:
-                nxt = torch.empty((P, self.dims[l + 1]), dtype=torch.float32, device=dev)
-                n_out = W.shape[0]
-                ops.gemm_nt(h, W, b, ops.ACT_SOFTPLUS, 100.0, 1.0 / _SQRT2, out=nxt[:, :n_out])
-                ops.posenc(x, self.multires, wl, 1.0 / _SQRT2, out=nxt[:, n_out:], ld_fill=d0)
-                h = nxt
-            else:
-                h = ops.gemm_nt(h, W, b, ops.ACT_SOFTPLUS, 100.0, 1.0)
-            acts.append(h)
-        f = acts[-1]
-        # backward to the input: d f / d h_{last-1} is row 0 of the last weight for every point
-        g_pe = torch.zeros((P, d0p), dtype=torch.float32, device=dev)
-        g = Ws[nl - 1][0:1].expand(P, -1)
-        for l in range(nl - 2, -1, -1):
-            y = acts[l]
-            if l + 1 in self.skip_in:
-                # acts[l] = [softplus(z)/sqrt2 | pe/sqrt2]; split the incoming gradient
-                n_out = Ws[l].shape[0]
-                g_pe[:, :d0] += g[:, n_out:] * (1.0 / _SQRT2)
-                gz = ops.act_grad(g[:, :n_out].contiguous(), (y[:, :n_out] * _SQRT2).contiguous(), ops.ACT_SOFTPLUS,
-                                  100.0) * (1.0 / _SQRT2)
-            else:
-                gz = ops.act_grad(g.contiguous(), y, ops.ACT_SOFTPLUS, 100.0)
-            g = ops.gemm_nt(gz, self._weight_t(l, Ws[l]))
-        g_pe[:, :d0] += g
-        grad = ops._pe_vjp(x, g_pe, None, self.multires, wl)
+        f = ch.forward(x, n_out=self.d_out, keep=True)
+        grad = ch.vjp_input(x, None if self.d_out == 1 else torch.ones_like(f))
         return f, grad
 
     def _weight_t(self, l, W):

@@ -43,42 +43,42 @@ def _ray_angle_deg(direct, rays):
 @torch.no_grad()
 def _optimize_explicit(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds, smpl_conds, name,
                        dthreshold, athreshold, w1, w2, times):
-    """Same iteration as the autograd version below, evaluated with the graph-free value+gradient passes of the
-    networks (ImplicitNetwork.value_and_grad, CompositeDeformer.value_and_vjp).  All rays are carried through every
-    step (rows of the kernels are independent, so the active rays get bit-identical updates); finished rays are
-    simply not updated.  The post-update check of step i is the forward pass of step i+1, evaluated once."""
-    p = initTmpPs
-    c = cam_pos.view(1, 3)
+    """Same iteration as the autograd version below on the graph-free passes: per step two C calls for the SDF net
+    (value + input gradient), four for the deformer (offset MLP, fused skinning + ray energy, and their VJPs) and one
+    fused stopping-test / update kernel.  All rays are carried through every step (rows of the kernels are
+    independent, so the active rays get the same updates); finished rays are simply not updated.  The post-update
+    check of step i is the forward pass of step i+1, evaluated once.  The early exit reads the unfinished-ray count
+    of the PREVIOUS step (pinned host copy + event), so the host never waits on the step it has just enqueued; the
+    one extra evaluation this can cost changes nothing (no unfinished ray = no update)."""
+    from .. import chains
+    dev = initTmpPs.device
+    p = initTmpPs.detach().clone().contiguous()
+    P = p.shape[0]
+    cam = cam_pos.detach().reshape(3).contiguous().float()
+    rays = rays.detach().contiguous()
+    frame = batch_inds.contiguous()
     conds = [defconds, smpl_conds]
-    state = {}
-
-    def cot(d):                      # d loss2 / d d  with loss2 = |(d-c) x v| / |d-c|
-        direct = d - c
-        up = torch.linalg.cross(direct, rays, dim=1)
-        un = up.norm(dim=1, keepdim=True)
-        dn = direct.norm(dim=1, keepdim=True)
-        state['loss2'] = (un / dn).view(-1)
-        state['angle'] = torch.arcsin(un / dn).view(-1) * 180. / np.pi
-        g_up = up / (un * dn).clamp(min=1e-30)
-        g_direct = torch.linalg.cross(rays, g_up, dim=1) - direct * (un / dn.pow(3))
-        return g_direct
-
-    f, gf = tmpSdf.value_and_grad(p, ratio)
-    d, gd = deformer.value_and_vjp(p, conds, batch_inds, cot, ratio=ratio, offset_type=name)
-    unfinished = ~((f.view(-1).abs() < dthreshold) & (state['angle'] < athreshold))
-    for ind in range(times):
-        if not bool(unfinished.any()):
-            break
-        loss = w1 * f.view(-1).abs() + w2 * state['loss2']
-        grad = w1 * torch.sign(f) * gf + w2 * gd
-        t = -loss / (grad * grad).sum(1)
-        p_new = torch.where(unfinished.view(-1, 1), p + t.view(-1, 1) * grad, p)
-        p = p_new
-        f, gf = tmpSdf.value_and_grad(p, ratio)
-        d, gd = deformer.value_and_vjp(p, conds, batch_inds, cot, ratio=ratio, offset_type=name)
-        done = (f.view(-1).abs() < dthreshold) & (state['angle'] < athreshold)
-        unfinished = unfinished & ~done
-    return p, ~unfinished
+    unfinished = torch.ones(P, dtype=torch.uint8, device=dev)
+    counters = torch.zeros(times + 1, dtype=torch.int32, device=dev)
+    host = torch.zeros(times + 1, dtype=torch.int32).pin_memory()
+    events = []
+    sdf_chain = tmpSdf.chain(tmpSdf._pe_weights(ratio), need_t=True)
+    assert tmpSdf.d_out == 1
+    for it in range(times + 1):
+        f = sdf_chain.forward(p, n_out=1, keep=True)
+        gf = sdf_chain.vjp_input(p, None)
+        _, loss2, angle, gd = deformer.ray_energy_and_vjp(p, conds, frame, cam, rays, ratio=ratio, offset_type=name)
+        chains.rootfind_update(p, f, gf, loss2, angle, gd, unfinished, counters[it:it + 1], dthreshold, athreshold,
+                               w1, w2, it < times)
+        host[it:it + 1].copy_(counters[it:it + 1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        events.append(ev)
+        if it >= 1:
+            events[it - 1].synchronize()
+            if int(host[it - 1]) == 0:
+                break
+    return p, unfinished == 0
 
 
 def OptimizeGarmentSurfacePs(cam_pos, rays_list, initTmpPs_list, batch_inds_list, tmpSdf_nets, ratio, deformer,

@@ -272,6 +272,21 @@ int recmv_rootfind_update(float* p, const float* f, const float* gf, const float
                           const float* gd, uint8_t* unfinished, int32_t* counter, int64_t P, float dthreshold,
                           float athreshold, float w1, float w2, int do_update, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Backward of one fused layer y = act(x W^T + b) in one call (csrc/linear_bwd.hip) — autograd of nn.Linear +
+ * activation in the reference (model/network.py:98-111 etc.).  y, gy [M,N]; x [M,K]; Wt = W^T [K,N];
+ * outputs gx [M,K] = (gy . act') W, gW [N,K] = (gy . act')^T x, gb [N] = column sums; any output may be NULL.
+ * recmv_colsum: out[c] = sum_r g[r*ld + c], fixed summation order (deterministic).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t recmv_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int recmv_colsum(const float* g, int64_t ld, int64_t rows, int64_t cols, float* out, void* workspace,
+                 int64_t workspace_bytes, void* stream);
+int64_t recmv_linear_backward_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int recmv_linear_backward(const float* gy, int64_t ldgy, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                          const float* Wt, int64_t ldwt, int64_t M, int64_t N, int64_t K, int act, float act_param,
+                          float* gx, int64_t ldgx, float* gW, float* gb, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,47 @@ from . import _lib as L
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = L.ACT_NONE, L.ACT_RELU, L.ACT_SOFTPLUS, L.ACT_TANH
 
 _tn_ws = {}
+_lb_ws = {}
+
+
+def transposed(W):
+    """Contiguous W^T, cached on the tensor object for as long as its data is unchanged."""
+    hit = getattr(W, "_recmv_t", None)
+    if hit is not None and hit[0] == W._version:
+        return hit[1]
+    Wt = W.detach().t().contiguous()
+    try:
+        W._recmv_t = (W._version, Wt)
+    except Exception:
+        pass
+    return Wt
+
+
+def linear_backward(gy, y, x, W, act, act_param, need_gx=True, need_gW=True, need_gb=True):
+    """(gx, gW, gb) of y = act(x W^T + b) from ONE C call (recmv_linear_backward); no autograd."""
+    gy = _rowmajor(gy)
+    x = _rowmajor(x.detach())
+    M, N = gy.shape
+    K = x.shape[1]
+    dev = gy.device
+    lib = L.lib()
+    need = int(lib.recmv_linear_backward_workspace_bytes(M, N, K))
+    ws = _lb_ws.get(dev.index)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _lb_ws[dev.index] = ws
+    gx = torch.empty((M, K), dtype=torch.float32, device=dev) if need_gx else None
+    gW = torch.empty((N, K), dtype=torch.float32, device=dev) if need_gW else None
+    gb = torch.empty((N,), dtype=torch.float32, device=dev) if need_gb else None
+    Wt = transposed(W) if need_gx else None
+    yd = y.detach() if y is not None else None
+    with torch.cuda.device(dev):
+        L.check(lib.recmv_linear_backward(L.ptr(gy), gy.stride(0) if M > 1 else N, L.ptr(yd),
+                                          (yd.stride(0) if M > 1 else N) if yd is not None else 0, L.ptr(x),
+                                          x.stride(0) if M > 1 else K, L.ptr(Wt), N, M, N, K, act, float(act_param),
+                                          L.ptr(gx), K, L.ptr(gW), L.ptr(gb), L.ptr(ws), ws.numel(),
+                                          L.stream_ptr(dev)), "linear_backward")
+    return gx, gW, gb
 
 
 def _rowmajor(t: torch.Tensor) -> torch.Tensor:
@@ -123,6 +164,12 @@ class MatmulNT(torch.autograd.Function):
     def backward(ctx, gC):
         A, B = ctx.saved_tensors
         gA = gB = None
+        if not torch.is_grad_enabled():                        # first-order execution: raw kernels, no sub-graph
+            if ctx.needs_input_grad[0]:
+                gA = gemm_nt(gC, transposed(B))
+            if ctx.needs_input_grad[1]:
+                gB = gemm_tn(gC, A)
+            return gA, gB
         if ctx.needs_input_grad[0]:
             gA = MatmulNT.apply(gC, B.t().contiguous())        # gC [M,N] @ B [N,K]
         if ctx.needs_input_grad[1]:
@@ -142,6 +189,12 @@ class MatmulTN(torch.autograd.Function):
     def backward(ctx, gC):
         A, B = ctx.saved_tensors
         gA = gB = None
+        if not torch.is_grad_enabled():
+            if ctx.needs_input_grad[0]:
+                gA = gemm_nt(B, gC)
+            if ctx.needs_input_grad[1]:
+                gB = gemm_nt(A, gC.t().contiguous())
+            return gA, gB
         if ctx.needs_input_grad[0]:
             gA = MatmulNT.apply(B, gC)                         # B [K,N] @ gC^T [N,M]
         if ctx.needs_input_grad[1]:
@@ -213,6 +266,8 @@ class PosEnc(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
+        if not torch.is_grad_enabled():
+            return _pe_vjp(x.detach(), g, None, *ctx.cfg), None, None
         return PosEncVjp.apply(x, g, *ctx.cfg), None, None
 
 
@@ -228,6 +283,10 @@ class PosEncVjp(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ggx):
         x, g = ctx.saved_tensors
+        if not torch.is_grad_enabled():
+            gx = _pe_vjp(x.detach(), g.detach(), ggx, *ctx.cfg) if ctx.needs_input_grad[0] else None
+            gg = _pe_jvp(x.detach(), ggx, *ctx.cfg) if ctx.needs_input_grad[1] else None
+            return gx, gg, None, None
         gx = PosEncVjp2.apply(x, g, ggx, *ctx.cfg) if ctx.needs_input_grad[0] else None
         gg = PosEncJvp.apply(x, ggx, *ctx.cfg) if ctx.needs_input_grad[1] else None
         return gx, gg, None, None
@@ -245,6 +304,10 @@ class PosEncJvp(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         x, t = ctx.saved_tensors
+        if not torch.is_grad_enabled():
+            gx = _pe_vjp(x.detach(), go, t.detach(), *ctx.cfg) if ctx.needs_input_grad[0] else None
+            gt = _pe_vjp(x.detach(), go, None, *ctx.cfg) if ctx.needs_input_grad[1] else None
+            return gx, gt, None, None
         gx = PosEncVjp2.apply(x, go, t, *ctx.cfg) if ctx.needs_input_grad[0] else None
         gt = PosEncVjp.apply(x, go, *ctx.cfg) if ctx.needs_input_grad[1] else None
         return gx, gt, None, None
@@ -294,6 +357,12 @@ class ActGrad(torch.autograd.Function):
     def backward(ctx, ggz):
         gy, y = ctx.saved_tensors
         act, p = ctx.cfg
+        if not torch.is_grad_enabled():
+            g_gy = act_grad(ggz, y.detach(), act, p) if ctx.needs_input_grad[0] else None
+            g_y = None
+            if ctx.needs_input_grad[1] and act in (ACT_SOFTPLUS, ACT_TANH):
+                g_y = act_grad2(ggz, gy.detach(), y.detach(), act, p)
+            return g_gy, g_y, None, None
         g_gy = ActGrad.apply(ggz, y, act, p) if ctx.needs_input_grad[0] else None
         g_y = None
         if ctx.needs_input_grad[1] and act in (ACT_SOFTPLUS, ACT_TANH):
@@ -301,15 +370,20 @@ class ActGrad(torch.autograd.Function):
         return g_gy, g_y, None, None
 
 
+def act_grad2(a, b, y, act, act_param):
+    """a * b * d(act')/dy, no autograd."""
+    a_c, b_c, y_c = a.detach().contiguous(), b.detach().contiguous(), y.detach().contiguous()
+    out = torch.empty_like(a_c)
+    with torch.cuda.device(a.device):
+        L.check(L.lib().recmv_act_grad2(L.ptr(a_c), L.ptr(b_c), L.ptr(y_c), L.ptr(out), out.numel(), act,
+                                        float(act_param), L.stream_ptr(a.device)), "act_grad2")
+    return out
+
+
 class ActGrad2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, y, act, act_param):
-        a_c, b_c, y_c = a.detach().contiguous(), b.detach().contiguous(), y.detach().contiguous()
-        out = torch.empty_like(a_c)
-        with torch.cuda.device(a.device):
-            L.check(L.lib().recmv_act_grad2(L.ptr(a_c), L.ptr(b_c), L.ptr(y_c), L.ptr(out), out.numel(), act,
-                                            float(act_param), L.stream_ptr(a.device)), "act_grad2")
-        return out
+        return act_grad2(a, b, y, act, act_param)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -367,6 +441,10 @@ class LinearAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, W, y = ctx.saved_tensors
+        if not torch.is_grad_enabled():
+            gx, gW, gb = linear_backward(gy, y, x, W, ctx.act, ctx.act_param, ctx.needs_input_grad[0],
+                                         ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+            return gx, gW, gb, None, None
         gz = gy if ctx.act == ACT_NONE else ActGrad.apply(gy, y, ctx.act, ctx.act_param)
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:

@@ -43,22 +43,26 @@ class MlpChain:
         self.m = m
         self.n_layers = n
         self.rows_last = rows[-1]
-        self._ws = None
+        self._ws = {}
 
-    def _workspace(self, P, keep):
+    def _workspace(self, P, keep, slot=None):
+        """Activation workspace; `slot` separates concurrent users of one chain (e.g. two garments evaluated on two
+        streams through the same deformer MLP)."""
         need = int(L.lib().recmv_mlp_workspace_bytes(C.byref(self.m), P, keep))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
-        return self._ws
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+            self._ws[slot] = ws
+        return ws
 
-    def forward(self, x, cond=None, cond_index=None, n_out=None, keep=False, out=None):
+    def forward(self, x, cond=None, cond_index=None, n_out=None, keep=False, out=None, slot=None):
         """x [P,3] -> [P, n_out] (the first n_out outputs of the last layer)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 3 and x.is_contiguous()
         P = x.shape[0]
         n_out = self.rows_last if n_out is None else n_out
         if out is None:
             out = torch.empty((P, n_out), dtype=torch.float32, device=x.device)
-        ws = self._workspace(P, int(keep))
+        ws = self._workspace(P, int(keep), slot)
         ld_cond = 0
         if cond is not None:
             assert cond.dtype == torch.float32 and cond.stride(-1) == 1 and cond.dim() == 2
@@ -71,12 +75,12 @@ class MlpChain:
                                               int(keep), L.stream_ptr(x.device)), "mlp_forward")
         return out
 
-    def vjp_input(self, x, g_out=None, n_out=None):
+    def vjp_input(self, x, g_out=None, n_out=None, slot=None):
         """J(x)^T g_out -> [P,3]; call after forward(keep=True) with the same x.  g_out None = ones (n_out 1)."""
         P = x.shape[0]
         n_out = (1 if g_out is None else g_out.shape[1]) if n_out is None else n_out
         gx = torch.empty((P, 3), dtype=torch.float32, device=x.device)
-        ws = self._workspace(P, 1)
+        ws = self._workspace(P, 1, slot)
         ldg = 0
         if g_out is not None:
             assert g_out.dtype == torch.float32 and g_out.stride(1) == 1 and g_out.shape == (P, n_out)

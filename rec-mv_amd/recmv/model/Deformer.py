@@ -108,6 +108,14 @@ class CompositeDeformer(nn.Module):
         return out, g
 
     @torch.no_grad()
+    def prepare_explicit(self, conds, **kwargs):
+        """Build (on the current stream) the cached state the graph-free passes share between callers: the offset
+        MLP's chain descriptor with its transposed weights and the posed skeleton."""
+        for cond, deformer in zip(conds, self.defs):
+            if hasattr(deformer, 'prepare_explicit'):
+                deformer.prepare_explicit(cond, **kwargs)
+
+    @torch.no_grad()
     def ray_energy_and_vjp(self, ps, conds, batch_inds, cam, rays, **kwargs):
         """For the root finder: E2 = |(d-c) x v| / |d-c| of d = deformer(ps), its angle (degrees) and
         J_d(ps)^T dE2/dd — four C calls (offset-MLP chain, fused skinning + energy, skinning VJP, MLP chain VJP)."""
@@ -200,13 +208,14 @@ def _translator_explicit(self, ps, conds, batch_inds, **kwargs):
     the iteration overwrite it anyway, model/Deformer.py:201-205.)"""
     ch = _translator_chain(self, kwargs['ratio']['deformerRatio'])
     ps = ps.detach().contiguous()
-    out = ch.forward(ps, cond=conds.detach(), cond_index=batch_inds.contiguous(), n_out=3, keep=True)
-    return out, (ch, ps)
+    slot = kwargs.get('offset_type', None)
+    out = ch.forward(ps, cond=conds.detach(), cond_index=batch_inds.contiguous(), n_out=3, keep=True, slot=slot)
+    return out, (ch, ps, slot)
 
 
 def _translator_backward_input(self, saved, g_out):
-    ch, ps = saved
-    return ch.vjp_input(ps, g_out.contiguous())
+    ch, ps, slot = saved
+    return ch.vjp_input(ps, g_out.contiguous(), slot=slot)
 
 
 def _cached_t(module, l, W):
@@ -219,6 +228,7 @@ def _cached_t(module, l, W):
     return hit[1]
 
 
+MLPTranslator.prepare_explicit = lambda self, cond, **kwargs: _translator_chain(self, kwargs['ratio']['deformerRatio'])
 MLPTranslator.forward_explicit = _translator_explicit
 MLPTranslator.backward_input = _translator_backward_input
 
@@ -412,6 +422,11 @@ class LBSkinner(nn.Module):
         t = (trans.detach() + self.extra_trans).contiguous()
         self.__dict__['_posed_cache'] = (poses, poses._version, trans, trans._version, A.contiguous(), t)
         return A, t
+
+    @torch.no_grad()
+    def prepare_explicit(self, conds, **kwargs):
+        self._posed(conds[0], conds[1])
+        self._lbs_grid()
 
     @torch.no_grad()
     def forward_explicit(self, ps, conds, batch_inds, cam=None, rays=None, **kwargs):

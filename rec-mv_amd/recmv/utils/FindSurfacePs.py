@@ -9,6 +9,8 @@ The SDF / deformer evaluations inside run on the recmv kernels.  The active set 
 that shrinks on device; the loop exits early through a single count read per step (the reference does the
 same sync through `curPs.shape[0]==0` after boolean indexing, :311-313).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -40,62 +42,136 @@ def _ray_angle_deg(direct, rays):
     return torch.arcsin(up.norm(dim=1) / direct.norm(dim=1)) * 180. / np.pi
 
 
+_side_streams = {}
+
+
+def _streams(device, n):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _side_streams.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+class _RootState:
+    """One garment's root-finding iteration on the graph-free passes: per step two C calls for the SDF net (value +
+    input gradient), four for the deformer (offset MLP, fused skinning + ray energy, and their VJPs) and one fused
+    stopping-test / update kernel.  All rays are carried through every step (rows of the kernels are independent, so
+    the active rays get the same updates); finished rays are simply not updated.  The post-update check of step i is
+    the forward pass of step i+1, evaluated once.  The early exit reads the unfinished-ray count of the PREVIOUS step
+    (pinned host copy + event), so the host never waits on the step it has just enqueued; the one extra evaluation
+    this can cost changes nothing (no unfinished ray = no update)."""
+
+    def __init__(self, cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds, smpl_conds, name,
+                 dthreshold, athreshold, w1, w2, times, stream):
+        dev = initTmpPs.device
+        self.stream = stream
+        self.args = (dthreshold, athreshold, w1, w2)
+        self.times, self.it, self.finished = times, 0, False
+        self.tmpSdf, self.deformer, self.ratio, self.name = tmpSdf, deformer, ratio, name
+        self.conds = [defconds, smpl_conds]
+        with torch.cuda.stream(stream):
+            self.p = initTmpPs.detach().clone().contiguous()
+            P = self.p.shape[0]
+            self.cam = cam_pos.detach().reshape(3).contiguous().float()
+            self.rays = rays.detach().contiguous()
+            self.frame = batch_inds.contiguous()
+            self.unfinished = torch.ones(P, dtype=torch.uint8, device=dev)
+            self.counters = torch.zeros(times + 1, dtype=torch.int32, device=dev)
+        self.host = torch.zeros(times + 1, dtype=torch.int32).pin_memory()
+        self.events = []
+        self.sdf_chain = tmpSdf.chain(tmpSdf._pe_weights(ratio), need_t=True)
+        assert tmpSdf.d_out == 1
+
+    def step(self):
+        """Enqueue one iteration on this garment's stream; returns False once the iteration is over."""
+        from .. import chains
+        if self.finished:
+            return False
+        it = self.it
+        if it >= 2:                        # lagged early exit: the count of step it-2 has certainly been asked for
+            self.events[it - 2].synchronize()
+            if int(self.host[it - 2]) == 0:
+                self.finished = True
+                return False
+        if it > self.times:
+            self.finished = True
+            return False
+        dthr, athr, w1, w2 = self.args
+        with torch.cuda.stream(self.stream):
+            p = self.p
+            f = self.sdf_chain.forward(p, n_out=1, keep=True)
+            gf = self.sdf_chain.vjp_input(p, None)
+            _, loss2, angle, gd = self.deformer.ray_energy_and_vjp(p, self.conds, self.frame, self.cam, self.rays,
+                                                                   ratio=self.ratio, offset_type=self.name)
+            chains.rootfind_update(p, f, gf, loss2, angle, gd, self.unfinished, self.counters[it:it + 1], dthr, athr,
+                                   w1, w2, it < self.times)
+            self.host[it:it + 1].copy_(self.counters[it:it + 1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.events.append(ev)
+        self.it += 1
+        return True
+
+    def result(self):
+        return self.p, self.unfinished == 0
+
+
 @torch.no_grad()
-def _optimize_explicit(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds, smpl_conds, name,
-                       dthreshold, athreshold, w1, w2, times):
-    """Same iteration as the autograd version below on the graph-free passes: per step two C calls for the SDF net
-    (value + input gradient), four for the deformer (offset MLP, fused skinning + ray energy, and their VJPs) and one
-    fused stopping-test / update kernel.  All rays are carried through every step (rows of the kernels are
-    independent, so the active rays get the same updates); finished rays are simply not updated.  The post-update
-    check of step i is the forward pass of step i+1, evaluated once.  The early exit reads the unfinished-ray count
-    of the PREVIOUS step (pinned host copy + event), so the host never waits on the step it has just enqueued; the
-    one extra evaluation this can cost changes nothing (no unfinished ray = no update)."""
-    from .. import chains
-    dev = initTmpPs.device
-    p = initTmpPs.detach().clone().contiguous()
-    P = p.shape[0]
-    cam = cam_pos.detach().reshape(3).contiguous().float()
-    rays = rays.detach().contiguous()
-    frame = batch_inds.contiguous()
-    conds = [defconds, smpl_conds]
-    unfinished = torch.ones(P, dtype=torch.uint8, device=dev)
-    counters = torch.zeros(times + 1, dtype=torch.int32, device=dev)
-    host = torch.zeros(times + 1, dtype=torch.int32).pin_memory()
-    events = []
-    sdf_chain = tmpSdf.chain(tmpSdf._pe_weights(ratio), need_t=True)
-    assert tmpSdf.d_out == 1
-    for it in range(times + 1):
-        f = sdf_chain.forward(p, n_out=1, keep=True)
-        gf = sdf_chain.vjp_input(p, None)
-        _, loss2, angle, gd = deformer.ray_energy_and_vjp(p, conds, frame, cam, rays, ratio=ratio, offset_type=name)
-        chains.rootfind_update(p, f, gf, loss2, angle, gd, unfinished, counters[it:it + 1], dthreshold, athreshold,
-                               w1, w2, it < times)
-        host[it:it + 1].copy_(counters[it:it + 1], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        events.append(ev)
-        if it >= 1:
-            events[it - 1].synchronize()
-            if int(host[it - 1]) == 0:
-                break
-    return p, unfinished == 0
+def _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, tmpSdf_nets, ratio, deformer,
+                           defconds_list, smpl_conds, garment_names, dthreshold, athreshold, w1, w2, times):
+    """All garments at once, one HIP stream per garment: a garment's step is a train of ~60 small kernels on a few
+    thousand rays that cannot fill 256 CUs; the garments are independent, so their trains overlap."""
+    dev = initTmpPs_list[0].device
+    main = torch.cuda.current_stream(dev)
+    streams = _streams(dev, len(initTmpPs_list))
+    # everything the garments share (weight-normed weights and their transposes, posed skeleton, chain descriptors) is
+    # produced on the main stream BEFORE the side streams fork from it
+    for net in tmpSdf_nets[:len(initTmpPs_list)]:
+        net.chain(net._pe_weights(ratio), need_t=True)
+    deformer.prepare_explicit([None, smpl_conds], ratio=ratio)
+    states = []
+    for g, (initTmpPs, batch_inds, defconds, rays, name) in enumerate(
+            zip(initTmpPs_list, batch_inds_list, defconds_list, rays_list, garment_names)):
+        streams[g].wait_stream(main)
+        states.append(_RootState(cam_pos, rays, initTmpPs, batch_inds, tmpSdf_nets[g], ratio, deformer, defconds,
+                                 smpl_conds, name, dthreshold, athreshold, w1, w2, times, streams[g]))
+    live = True
+    while live:
+        live = False
+        for st in states:
+            live = st.step() or live
+    outs, oks = [], []
+    for st in states:
+        main.wait_stream(st.stream)
+        with torch.cuda.stream(st.stream):
+            p, ok = st.result()
+        main.wait_stream(st.stream)
+        p.record_stream(main)
+        ok.record_stream(main)
+        if os.environ.get('RECMV_ROOT_TRACE'):
+            torch.cuda.synchronize()
+            print('rootfind unfinished per step:', st.host[:len(st.events)].tolist(), flush=True)
+        outs.append(p)
+        oks.append(ok)
+    return outs, oks
 
 
 def OptimizeGarmentSurfacePs(cam_pos, rays_list, initTmpPs_list, batch_inds_list, tmpSdf_nets, ratio, deformer,
                              defconds_list, garment_names, dthreshold=5.e-5, athreshold=0.02, w1=3.05, w2=1.,
                              times=5):
     smpl_conds = defconds_list[1]
+    if (len(initTmpPs_list) > 0 and all(t.is_cuda for t in initTmpPs_list) and hasattr(deformer, 'ray_energy_and_vjp')
+            and all(hasattr(n, 'chain') for n in tmpSdf_nets)):
+        outs, oks = _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, tmpSdf_nets, ratio,
+                                           deformer, defconds_list[0], smpl_conds, garment_names, dthreshold,
+                                           athreshold, w1, w2, times)
+        return [o.detach() for o in outs], oks
     optimized_init_tmp_ps_list = []
     optimized_check_list = []
     for garment_idx, (initTmpPs, batch_inds, defconds, rays, garment_name) in enumerate(
             zip(initTmpPs_list, batch_inds_list, defconds_list[0], rays_list, garment_names)):
         tmpSdf = tmpSdf_nets[garment_idx]
-        if initTmpPs.is_cuda and hasattr(tmpSdf, 'value_and_grad') and hasattr(deformer, 'value_and_vjp'):
-            pts, ok = _optimize_explicit(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds,
-                                         smpl_conds, garment_name, dthreshold, athreshold, w1, w2, times)
-            optimized_init_tmp_ps_list.append(pts.detach())
-            optimized_check_list.append(ok)
-            continue
         with torch.no_grad():
             check1 = tmpSdf(initTmpPs, ratio).view(-1).abs() < dthreshold
             direct = deformer(initTmpPs, [defconds, smpl_conds], batch_inds, ratio=ratio,

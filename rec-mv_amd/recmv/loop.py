@@ -203,10 +203,12 @@ class HotLoop:
             return
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+            torch.cuda.nvtx.range_push('recmv:' + name)      # roctx range: rocprofv3 --marker-trace
         t0 = time.perf_counter()
         yield
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+            torch.cuda.nvtx.range_pop()
         acc = self.__dict__.setdefault('phase_ms', {})
         acc[name] = acc.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
 

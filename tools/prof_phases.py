@@ -1,0 +1,56 @@
+"""Per-phase GPU-busy breakdown from a rocprofv3 --kernel-trace --marker-trace run of bench.py with RECMV_TIMING=1
+(the phases of recmv/loop.py are roctx ranges bracketed by device syncs).
+
+    RECMV_TIMING=1 rocprofv3 --kernel-trace --marker-trace -d /tmp/p -o run -- python bench.py --steps 10 --warmup 2 ...
+    python tools/prof_phases.py /tmp/p [skip_first_n_occurrences] > profiles/<name>.txt
+"""
+import collections
+import glob
+import sqlite3
+import sys
+
+
+def main():
+    path = sys.argv[1]
+    skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if not path.endswith(".db"):
+        path = glob.glob(path + "/**/*.db", recursive=True)[0]
+    cur = sqlite3.connect(path).cursor()
+    regions = cur.execute("select name, start, end from regions where name like 'recmv:%' order by start").fetchall()
+    kernels = cur.execute("select name, start, end from kernels order by start").fetchall()
+    seen = collections.Counter()
+    agg = collections.OrderedDict()
+    ki = 0
+    for name, rs, re_ in regions:
+        seen[name] += 1
+        while ki < len(kernels) and kernels[ki][1] < rs:
+            ki += 1
+        kj = ki
+        busy, n = 0, 0
+        per = collections.Counter()
+        while kj < len(kernels) and kernels[kj][1] <= re_:
+            d = kernels[kj][2] - kernels[kj][1]
+            busy += d
+            n += 1
+            per[kernels[kj][0].split("(")[0][-60:]] += d
+            kj += 1
+        ki = kj
+        if seen[name] <= skip:
+            continue
+        a = agg.setdefault(name, dict(count=0, wall=0, busy=0, launches=0, per=collections.Counter()))
+        a["count"] += 1
+        a["wall"] += re_ - rs
+        a["busy"] += busy
+        a["launches"] += n
+        a["per"].update(per)
+    print(f"# {path}  (first {skip} occurrence(s) of every phase skipped)")
+    print(f"# {'phase':<22} {'n':>4} {'wall_ms/occ':>12} {'gpu_busy_ms/occ':>16} {'busy%':>6} {'launches/occ':>13}   top kernels (ms/occ)")
+    for name, a in agg.items():
+        c = a["count"]
+        top = ", ".join(f"{k.strip()}={v / c / 1e6:.2f}" for k, v in a["per"].most_common(6))
+        print(f"{name[6:]:<22} {c:>4d} {a['wall'] / c / 1e6:>12.2f} {a['busy'] / c / 1e6:>16.2f} "
+              f"{100.0 * a['busy'] / max(a['wall'], 1):>6.1f} {a['launches'] / c:>13.0f}   {top}")
+
+
+if __name__ == "__main__":
+    main()

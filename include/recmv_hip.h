@@ -287,6 +287,29 @@ int recmv_linear_backward(const float* gy, int64_t ldgy, const float* y, int64_t
                           float* gx, int64_t ldgx, float* gW, float* gb, void* workspace, int64_t workspace_bytes,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * MLP "jet" pass (csrc/mlp_jet.hip): value and input-Jacobian in one forward sweep (three tangent rows per point
+ * carried through the layers), with an explicit first-order reverse sweep.  Replaces autograd's double backward for
+ * the terms of the loss that differentiate grad_x SDF (model/network.py:121-133, OptimGarmentNetwork.py:1108-1119,
+ * :1169-1172) and the Jacobian of the offset MLP (utils/utils.py:133-156, OptimGarmentNetwork.py:1135-1155).
+ *   forward : y [P, rows_last] (residual nets: x + mlp), tang [3P, n_j] with tang[k*P + p, j] = d y_j / d x_k of the
+ *             MLP part (the residual's identity is NOT included).
+ *   backward: cotangents gy [P, rows_last] / gtang [3P, n_j] (NULL = zeros) -> gW[l] [rows[l], dims[l]], gb[l],
+ *             g_in [4P, pad4(dims[0])] (cotangent of the stacked layer-0 input; rows [0,P) x columns [3+6L, dims[0])
+ *             are the per-point cotangents of the gathered code) and gx [P,3]; each may be NULL.
+ * eye3: 9 floats on the device = the 3x3 identity.  The workspace carries the activations from forward to backward.
+ * recmv_gather_rows: out[r, 0:cols] = table[index[r] (or 0), 0:cols], columns [cols, fill) zeroed.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t recmv_mlp_jet_workspace_bytes(const recmv_mlp* m, int64_t P);
+int recmv_mlp_jet_forward(const recmv_mlp* m, const float* x, const float* cond, int64_t ld_cond,
+                          const int64_t* cond_index, const float* eye3, int64_t P, int n_j, float* y, int64_t ldy,
+                          float* tang, void* workspace, int64_t workspace_bytes, void* stream);
+int recmv_mlp_jet_backward(const recmv_mlp* m, const float* x, const float* eye3, int64_t P, int n_j, const float* gy,
+                           int64_t ldgy, const float* gtang, float* const* gW, float* const* gb, float* g_in,
+                           float* gx, void* workspace, int64_t workspace_bytes, void* stream);
+int recmv_gather_rows(const float* table, int64_t ldt, const int64_t* index, float* out, int64_t ldo, int64_t rows,
+                      int64_t cols, int64_t fill, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

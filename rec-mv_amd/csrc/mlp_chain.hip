@@ -147,6 +147,16 @@ extern "C" int recmv_add_scaled_2d(const float* a, int64_t lda, const float* b, 
   return check_launch("add_scaled_2d");
 }
 
+extern "C" int recmv_gather_rows(const float* table, int64_t ldt, const int64_t* index, float* out, int64_t ldo,
+                                 int64_t rows, int64_t cols, int64_t fill, void* stream) {
+  RECMV_REQUIRE(rows >= 0 && cols >= 0 && fill >= cols && fill < (1 << 30), "gather_rows: bad size");
+  if (rows == 0 || fill == 0) return RECMV_OK;
+  RECMV_REQUIRE(out && (cols == 0 || table), "gather_rows: NULL pointer");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(stream_grid(rows * fill, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, table,
+                     ldt, index, out, ldo, rows, (int)cols, (int)fill);
+  return check_launch("gather_rows");
+}
+
 extern "C" int64_t recmv_mlp_workspace_bytes(const recmv_mlp* m, int64_t P, int keep) {
   if (!m || P <= 0 || m->n_layers < 1 || m->n_layers > RECMV_MLP_MAX_LAYERS) return 0;
   return make_layout(m, P, keep).bytes;

@@ -87,7 +87,7 @@ extern "C" int recmv_posenc_vjp(const float* x, int64_t ldx, const float* g, int
                                 void* stream) {
   RECMV_REQUIRE(P >= 0 && L >= 0 && L <= 16, "posenc_vjp: bad size");
   if (P == 0) return RECMV_OK;
-  RECMV_REQUIRE(x && g && out && ldx >= 3 && ldg >= 3 + 6 * L && (!t || ldt >= 3), "posenc_vjp: bad argument");
+  RECMV_REQUIRE(x && g && out && ldx >= 3 && ldg >= 3 + 6 * L && (!t || ldt >= 3 || ldt == 0), "posenc_vjp: bad argument");
   PeW w;
   fill_w(&w, weights_host, L);
   hipLaunchKernelGGL(pe_vjp_kernel, dim3(stream_grid(P * 3, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, x, ldx, g, ldg,
@@ -99,7 +99,7 @@ extern "C" int recmv_posenc_jvp(const float* x, int64_t ldx, const float* t, int
                                 int64_t P, int L, const float* weights_host, void* stream) {
   RECMV_REQUIRE(P >= 0 && L >= 0 && L <= 16, "posenc_jvp: bad size");
   if (P == 0) return RECMV_OK;
-  RECMV_REQUIRE(x && t && out && ldx >= 3 && ldt >= 3 && ldo >= 3 + 6 * L, "posenc_jvp: bad argument");
+  RECMV_REQUIRE(x && t && out && ldx >= 3 && (ldt >= 3 || ldt == 0) && ldo >= 3 + 6 * L, "posenc_jvp: bad argument");
   PeW w;
   fill_w(&w, weights_host, L);
   hipLaunchKernelGGL(pe_jvp_kernel, dim3(stream_grid(P * (1 + 2 * L), kBlk)), dim3(kBlk), 0, (hipStream_t)stream, x,

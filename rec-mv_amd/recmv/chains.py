@@ -136,3 +136,116 @@ def rootfind_update(p, f, gf, loss2, angle, gd, unfinished, counter, dthreshold,
                                               L.ptr(unfinished), L.ptr(counter), p.shape[0], float(dthreshold),
                                               float(athreshold), float(w1), float(w2), int(do_update),
                                               L.stream_ptr(p.device)), "rootfind_update")
+
+
+# --------------------------------------------------------------------------------------------------
+# MLP jet: value + input Jacobian forward, explicit first-order reverse (csrc/mlp_jet.hip)
+# --------------------------------------------------------------------------------------------------
+_eye3 = {}
+
+
+def _eye(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _eye3.get(key)
+    if t is None:
+        t = torch.eye(3, dtype=torch.float32, device=device).contiguous()
+        _eye3[key] = t
+    return t
+
+
+class MlpJet(torch.autograd.Function):
+    """(y [P, rows_last], tang [3P, n_j]) = jet of an MLP at x; tang[k*P + p, j] = d mlp_j / d x_k.
+
+    forward : one C call (recmv_mlp_jet_forward); the activations stay in a per-call workspace tensor.
+    backward: one C call (recmv_mlp_jet_backward) -> gradients of x, the per-frame codes, every weight and bias.
+    Differentiable ONCE: the loss only needs first-order gradients of (y, tang) — the second-order terms of the
+    reference's autograd formulation are what the tangent rows carry."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, cond, *wb):
+        n = cfg['n_layers']
+        Ws, bs = list(wb[:n]), list(wb[n:])
+        dev = x.device
+        xd = x.detach().contiguous()
+        P = xd.shape[0]
+        Wd = [W.detach().contiguous() for W in Ws]
+        bd = [b.detach().contiguous() if b is not None else None for b in bs]
+        from .ops import transposed
+        Wt = [transposed(W) for W in Ws]           # cached on the parameter objects while their data is unchanged
+        ctx.set_materialize_grads(False)
+        ch = MlpChain(Wd, bd, Wt, cfg['dims'], [W.shape[0] for W in Wd], cfg['multires'], cond_dim=cfg['cond_dim'],
+                      skip_layer=cfg['skip_layer'], hidden_act=cfg['hidden_act'], act_param=cfg['act_param'],
+                      residual=cfg['residual'], pe_weights=cfg['pe_weights'])
+        n_j = cfg['n_j']
+        n_out = Wd[-1].shape[0]
+        lib = L.lib()
+        ws = torch.empty(int(lib.recmv_mlp_jet_workspace_bytes(C.byref(ch.m), P)), dtype=torch.uint8, device=dev)
+        y = torch.empty((P, n_out), dtype=torch.float32, device=dev)
+        tang = torch.empty((3 * P, n_j), dtype=torch.float32, device=dev)
+        cond_d = cond.detach() if cond is not None else None
+        cidx = cfg['cond_index']
+        ld_cond = cond_d.stride(0) if cond_d is not None else 0
+        if cond_d is not None:
+            assert cond_d.dim() == 2 and cond_d.stride(1) == 1 and cond_d.dtype == torch.float32
+        eye = _eye(dev)
+        with torch.cuda.device(dev):
+            L.check(lib.recmv_mlp_jet_forward(C.byref(ch.m), L.ptr(xd), L.ptr(cond_d), ld_cond, L.ptr(cidx), L.ptr(eye),
+                                              P, n_j, L.ptr(y), n_out, L.ptr(tang), L.ptr(ws), ws.numel(),
+                                              L.stream_ptr(dev)), "mlp_jet_forward")
+        ctx.cfg, ctx.chain, ctx.ws, ctx.xd = cfg, ch, ws, xd
+        ctx.cond_shape = None if cond is None else tuple(cond.shape)
+        ctx.n = n
+        ctx.has_bias = [b is not None for b in bs]
+        return y, tang
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy, gtang):
+        cfg, ch, ws, xd, n = ctx.cfg, ctx.chain, ctx.ws, ctx.xd, ctx.n
+        dev = xd.device
+        P = xd.shape[0]
+        n_j = cfg['n_j']
+        lib = L.lib()
+        need = ctx.needs_input_grad            # (cfg, x, cond, W..., b...)
+        gy = gy.contiguous() if gy is not None else None
+        gtang = gtang.contiguous() if gtang is not None else None
+        Wd = ch._keep[0]
+        gWs = [torch.empty_like(Wd[l]) if need[3 + l] else None for l in range(n)]
+        gbs = [torch.empty(Wd[l].shape[0], dtype=torch.float32, device=dev)
+               if (ctx.has_bias[l] and need[3 + n + l]) else None for l in range(n)]
+        gW_arr = (C.c_void_p * n)(*[g.data_ptr() if g is not None else None for g in gWs])
+        gb_arr = (C.c_void_p * n)(*[g.data_ptr() if g is not None else None for g in gbs])
+        want_cond = ctx.cond_shape is not None and need[2]
+        ld_in = (cfg['dims'][0] + 3) // 4 * 4
+        g_in = torch.empty((4 * P, ld_in), dtype=torch.float32, device=dev) if want_cond else None
+        gx = torch.empty((P, 3), dtype=torch.float32, device=dev) if need[1] else None
+        eye = _eye(dev)
+        with torch.cuda.device(dev):
+            L.check(lib.recmv_mlp_jet_backward(C.byref(ch.m), L.ptr(xd), L.ptr(eye), P, n_j, L.ptr(gy),
+                                               gy.stride(0) if gy is not None else 0, L.ptr(gtang),
+                                               C.cast(gW_arr, C.c_void_p), C.cast(gb_arr, C.c_void_p), L.ptr(g_in),
+                                               L.ptr(gx), L.ptr(ws), ws.numel(), L.stream_ptr(dev)), "mlp_jet_backward")
+        gcond = None
+        if want_cond:
+            d_pe = 3 + 6 * cfg['multires']
+            gc = g_in[:P, d_pe:d_pe + cfg['cond_dim']]
+            cidx = cfg['cond_index']
+            if cidx is None:
+                gcond = gc.sum(0, keepdim=True).expand(ctx.cond_shape) if ctx.cond_shape[0] == 1 else None
+                assert gcond is not None, "a per-point frame index is needed when there are several codes"
+            else:
+                gcond = torch.zeros(ctx.cond_shape, dtype=torch.float32, device=dev).index_add_(0, cidx, gc)
+        ctx.ws = None
+        return (None, gx, gcond) + tuple(gWs) + tuple(gbs)
+
+
+def mlp_jet(x, cond, cond_index, Ws, bs, dims, multires, pe_weights, cond_dim, skip_layer, hidden_act, act_param,
+            residual, n_j):
+    """(y [P, rows_last], J [P, n_j, 3]) with J[p, j, k] = d mlp_j / d x_k (the residual's identity NOT included)."""
+    cfg = dict(n_layers=len(Ws), dims=list(dims), multires=multires,
+               pe_weights=None if pe_weights is None else tuple(float(w) for w in pe_weights), cond_dim=cond_dim,
+               skip_layer=skip_layer, hidden_act=hidden_act, act_param=act_param, residual=residual, n_j=n_j,
+               cond_index=cond_index)
+    y, tang = MlpJet.apply(cfg, x, cond, *Ws, *bs)
+    P = x.shape[0]
+    return y, tang.view(3, P, n_j).permute(1, 2, 0)

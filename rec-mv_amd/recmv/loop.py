@@ -204,6 +204,9 @@ class HotLoop:
         if torch.cuda.is_available():
             torch.cuda.synchronize()
             torch.cuda.nvtx.range_push('recmv:' + name)      # roctx range: rocprofv3 --marker-trace
+            if os.environ.get('RECMV_PHASE_LOG'):            # range order, for tools/prof_phases.py
+                with open(os.environ['RECMV_PHASE_LOG'], 'a') as fh:
+                    fh.write(name + '\n')
         t0 = time.perf_counter()
         yield
         if torch.cuda.is_available():
@@ -349,7 +352,7 @@ class HotLoop:
             sel = torch.rand(V, device=dev) < float(surface_sample_points) / float(V)
             nonmnfld = utils.sample_points(torch.cat([init_ps, TmpVs[sel].detach()], dim=0), 1.8, 0.01)
             nonmnfld.requires_grad_()
-            pred = net(nonmnfld, ratio)
+            pred = net(nonmnfld, ratio, jet=True)
             grad = net.gradient(nonmnfld, pred)
             grad_loss = ((grad.norm(2, dim=-1) - 1) ** 2).mean()                           # eikonal :1118
             self.info['{}_grad_loss'.format(name)] = grad_loss.detach()
@@ -360,7 +363,7 @@ class HotLoop:
                 pts = torch.cat([init_ps, TmpVs[sel].detach()], dim=0)
                 pts = torch.cat([pts, utils.sample_points(pts, 1.8, 0.01, 0)], dim=0).view(1, -1, 3).expand(N, -1, 3)
                 pts = pts.contiguous().requires_grad_()
-                defVs = self.deformer.defs[0](pts, d_cond, ratio=ratio, offset_type=name)
+                defVs = self.deformer.defs[0](pts, d_cond, ratio=ratio, offset_type=name, jet=True)
                 Jacobs = utils.compute_Jacobian(pts, defVs, True, True)
                 s = torch.log(singular_values_3x3(Jacobs))
                 def_loss = utils.GMRobustError((s * s).sum(1), conf.get_float('def_regu.c'), True).mean()
@@ -376,9 +379,9 @@ class HotLoop:
                 self.col_inds[g_i] = col_inds[check]
                 self.row_inds[g_i] = row_inds[check]
                 p, b = self.TmpPs[g_i], self.batch_inds[g_i]
-                sdfs = net(p, ratio)
+                sdfs = net(p, ratio, jet=True)
                 rend_feat = net.rendcond
-                nx = torch.autograd.grad(sdfs, p, torch.ones_like(sdfs), retain_graph=True, create_graph=True)[0]
+                nx = net.gradient(p, sdfs)           # = autograd.grad(sdfs, p, ones, create_graph=True) (:1169-1172)
                 nx = nx / nx.norm(dim=1, keepdim=True)
                 defconds = [d_cond, [poses, trans]]
                 crays, defVs = utils.compute_cardinal_rays(self.deformer, p, self.rays[g_i], defconds, b, ratio,
@@ -404,7 +407,7 @@ class HotLoop:
                     gtnorms = gtn.norm(dim=1, keepdim=True)
                     valid_mask = (gtnorms > 0.0001)[..., 0]
                     gtn = torch.where(valid_mask.unsqueeze(-1), gtn / gtnorms.clamp(min=1e-12), gtn)
-                    ds = self.deformer(p, defconds, b, ratio=ratio, offset_type=name)
+                    ds = self.deformer(p, defconds, b, ratio=ratio, offset_type=name, jet=True)
                     grad_d_p = utils.compute_Jacobian(p, ds, True, True)
                     gtn = (grad_d_p.transpose(-2, -1) * gtn.unsqueeze(-2)).sum(-1)
                     normal_loss = (gtn - nx).norm(2, dim=1) * weights
@@ -476,9 +479,9 @@ class HotLoop:
             c = cameras.cam_pos()
             p = self.TmpPs[g_i]
             net = self.garment_nets[g_i]
-            f = net(p, ratio)
-            grad_f_p = torch.autograd.grad(f, p, torch.ones_like(f), retain_graph=False)[0]
-            d = self.deformer(p, defconds, self.batch_inds[g_i], ratio=ratio, offset_type=name)
+            f = net(p, ratio, jet=True)
+            grad_f_p = net.gradient(p, f).detach()
+            d = self.deformer(p, defconds, self.batch_inds[g_i], ratio=ratio, offset_type=name, jet=True)
             opt_defconds = [t for t in (defconds[0], defconds[1][0], defconds[1][1]) if t.requires_grad]
             grad_d_p = utils.compute_Jacobian(p, d, False, False)
             vd = v.detach()

@@ -86,10 +86,19 @@ class CompositeDeformer(nn.Module):
         self.defs = nn.ModuleList(deformers)
 
     def forward(self, ps, conds, batch_inds=None, **kwargs):
+        """`jet=True` (extension): the offset MLP carries its Jacobian forward (csrc/mlp_jet.hip);
+        utils.compute_Jacobian(ps, output, ...) then needs autograd only for the skinning stage."""
         assert (self.N == len(conds))
         out = ps
-        for cond, deformer in zip(conds, self.defs):
+        jac = None
+        for i, (cond, deformer) in enumerate(zip(conds, self.defs)):
+            prev = out
             out = deformer(out, cond, batch_inds, **kwargs)
+            if kwargs.get('jet', False):
+                if i == 0:
+                    jac = getattr(out, '_recmv_jac', None)
+                elif jac is not None:
+                    out._recmv_jac_lazy = (ps, prev, jac[1]) if i == 1 else None
         return out
 
     @torch.no_grad()
@@ -156,6 +165,9 @@ class MLPTranslator(nn.Module):
     def forward(self, ps, conds, batch_inds=None, **kwargs):
         ratio = kwargs['ratio']['deformerRatio']
         offset_type = kwargs.get('offset_type', None)
+        if (kwargs.get('jet', False) and ps.is_cuda and ps.dtype == torch.float32 and self.embed_fn is not None
+                and torch.is_grad_enabled()):
+            return self._forward_jet(ps, conds, batch_inds, ratio, offset_type)
         if self.embed_fn is not None:
             if ratio is None:
                 ps = self.embed_fn(ps)
@@ -178,6 +190,31 @@ class MLPTranslator(nn.Module):
         else:
             self.offset[offset_type] = x.view(ps.shape[0], ps.shape[1], 3)
             return ps[..., :3] + x.view(ps.shape[0], ps.shape[1], 3)
+
+
+def _translator_forward_jet(self, ps, conds, batch_inds, ratio, offset_type):
+    """forward() with the Jacobian d out / d ps carried along (one C call): out._recmv_jac = (ps, I + J_offset)."""
+    from ..chains import mlp_jet
+    ws = None if ratio is None else ([0.] * (self.multires * 2) if ratio <= 0 else
+                                     annealing_weights(self.multires, ratio))
+    flat = ps.reshape(-1, 3)
+    if batch_inds is not None:
+        cidx = batch_inds
+        cond2d = conds
+    else:
+        cond2d = conds.reshape(-1, self.feature_vector_size)
+        cidx = torch.arange(cond2d.shape[0], device=ps.device).repeat_interleave(ps.shape[1])
+    nl = self.num_layers - 1
+    lins = [getattr(self, "lin" + str(l)) for l in range(nl)]
+    Ws = [lin.weight for lin in lins]
+    bs = [lin.bias for lin in lins]
+    dims = [Ws[0].shape[1]] + [W.shape[0] for W in Ws]
+    y, J = mlp_jet(flat, cond2d, cidx.contiguous(), Ws, bs, dims, self.multires, ws, self.feature_vector_size, -1,
+                   ops.ACT_RELU, 0.0, True, 3)
+    out = y.view(ps.shape)
+    self.offset[offset_type] = out - ps[..., :3]
+    out._recmv_jac = (ps, J + torch.eye(3, device=ps.device, dtype=J.dtype).view(1, 3, 3))
+    return out
 
 
 def _translator_chain(self, ratio):
@@ -229,6 +266,7 @@ def _cached_t(module, l, W):
 
 
 MLPTranslator.prepare_explicit = lambda self, cond, **kwargs: _translator_chain(self, kwargs['ratio']['deformerRatio'])
+MLPTranslator._forward_jet = _translator_forward_jet
 MLPTranslator.forward_explicit = _translator_explicit
 MLPTranslator.backward_input = _translator_backward_input
 

@@ -91,13 +91,20 @@ class ImplicitNetwork(nn.Module):
         return annealing_weights(self.multires, ratio)
 
     # -- forward ---------------------------------------------------------------------------------
-    def forward(self, input, ratio=None):
+    def forward(self, input, ratio=None, jet=False):
+        """`jet=True` (extension over the reference's signature): also carry d f / d x forward through the layers
+        (csrc/mlp_jet.hip); a following `gradient(input, output)` then returns it without autograd's double
+        backward, and the whole term is differentiable to first order in the parameters and the input."""
         ws = self._pe_weights(ratio) if self.embed_fn is not None else None
         needs_grad = torch.is_grad_enabled() and (input.requires_grad or
                                                   any(p.requires_grad for p in self.parameters()))
-        if (not needs_grad and input.is_cuda and input.dtype == torch.float32 and input.dim() == 2
-                and self.embed_fn is not None):
+        fast = input.is_cuda and input.dtype == torch.float32 and input.dim() == 2 and self.embed_fn is not None
+        self.__dict__['_jet'] = None
+        J = None
+        if not needs_grad and fast:
             x = self._forward_inference(input, ws)
+        elif jet and fast and len(self.skip_in) <= 1:
+            x, J = self._forward_jet(input, ws)
         else:
             x = self._forward_autograd(input, ws)
         if x.shape[-1] > self.d_out:
@@ -105,7 +112,20 @@ class ImplicitNetwork(nn.Module):
             x = x[:, 0:self.d_out]
         else:
             self.rendcond = None
+        if J is not None:
+            self.__dict__['_jet'] = (input, x, J)
         return x
+
+    def _forward_jet(self, input, ws):
+        from ..chains import mlp_jet
+        nl = self.num_layers - 1
+        Ws, bs = [], []
+        for l in range(nl):
+            W, b = self._weight(l)
+            Ws.append(W)
+            bs.append(b)
+        return mlp_jet(input, None, None, Ws, bs, self.dims, self.multires, ws, 0,
+                       self.skip_in[0] if len(self.skip_in) else -1, ops.ACT_SOFTPLUS, 100.0, False, self.d_out)
 
     def _forward_autograd(self, input, ws):
         if self.embed_fn is not None:
@@ -178,6 +198,9 @@ class ImplicitNetwork(nn.Module):
         return hit[2]
 
     def gradient(self, x, y=None):
+        jet = self.__dict__.get('_jet')
+        if jet is not None and y is not None and jet[0] is x and jet[1] is y and self.d_out == 1:
+            return jet[2].reshape(-1, 3)           # d f / d x carried by the forward pass (forward(..., jet=True))
         x.requires_grad_(True)
         if y is None:
             y = self.forward(x)

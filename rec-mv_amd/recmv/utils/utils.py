@@ -80,6 +80,15 @@ def sample_points(pc_input, global_sigma, local_sigma, ratio=6):
 def compute_Jacobian(ps, ds, retain_graph, create_graph, allow_unused=False):
     """[P,3,3] Jacobian d(ds)/d(ps), row i = grad of ds[...,i]; relies on per-point independence
     (utils/utils.py:133-156)."""
+    jac = getattr(ds, '_recmv_jac', None)
+    if jac is not None and jac[0] is ps:                 # carried forward by the MLP jet pass (forward(..., jet=True))
+        return jac[1]
+    lazy = getattr(ds, '_recmv_jac_lazy', None)
+    if lazy is not None and lazy[0] is ps:
+        # composite deformer: J = J_skinning(q) . J_offsetMLP(ps); only the skinning stage goes through autograd
+        _, q, Jq = lazy
+        Jl = compute_Jacobian(q, ds, retain_graph, create_graph, allow_unused)
+        return (Jl.unsqueeze(-1) * Jq.unsqueeze(-3)).sum(-2)
     grad_d_p = []
     grad_outputs = torch.ones_like(ds[..., 0])
     outx = torch.autograd.grad(ds[..., 0], ps, grad_outputs, retain_graph=True, create_graph=create_graph,
@@ -133,7 +142,7 @@ def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, pha
 def compute_cardinal_rays(deformer, ps, rays, defconds, batch_inds, ratio, phase, offset_type=None):
     """Canonical-space ray J^-1 v, fallback v where J is singular (utils/utils.py:232-250)."""
     check = True if phase == 'train' or phase == 'Train' else False
-    ds = deformer(ps, defconds, batch_inds, ratio=ratio, offset_type=offset_type)
+    ds = deformer(ps, defconds, batch_inds, ratio=ratio, offset_type=offset_type, jet=True)
     grad_d_p = compute_Jacobian(ps, ds, check, check)
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
     crays = _bmv(grad_d_p_inv, rays.view(-1, 3))

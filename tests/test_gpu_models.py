@@ -10,6 +10,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -230,3 +231,88 @@ def test_seg3d_lossless_and_mc(nets):
                                     eng.spacing_z, eng.bx, eng.by, eng.bz, 0.0)
         assert torch.equal(faces.cpu(), g["faces"]), "MC triangle/vertex indexing bit-exact vs reference pipeline"
         close(verts, g["verts"], rtol=0, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------ jet passes
+def _grads(loss, params):
+    gs = torch.autograd.grad(loss, params, allow_unused=True)
+    return [g if g is not None else torch.zeros_like(p) for g, p in zip(gs, params)]
+
+
+def test_sdf_jet_equals_double_backward(nets):
+    """forward(jet=True) + gradient(): value, grad_x f and the parameter / input gradients of an eikonal + normal +
+    feature loss equal those of the autograd (double-backward) formulation (model/network.py:121-133)."""
+    sdf = nets["sdf"]
+    g = torch.Generator().manual_seed(3)
+    x0 = (torch.randn(700, 3, generator=g) * 0.5).to(DEV)
+    tgt = F.normalize(torch.randn(700, 3, generator=g), dim=1).to(DEV)
+    params = [p for p in sdf.parameters()]
+
+    def loss_of(jet):
+        x = x0.clone().requires_grad_(True)
+        y = sdf(x, RATIO, jet=jet)
+        feat = sdf.rendcond
+        gx = sdf.gradient(x, y)
+        n = gx / gx.norm(dim=1, keepdim=True)
+        loss = ((gx.norm(dim=1) - 1) ** 2).mean() + (n - tgt).norm(dim=1).mean() + y.abs().mean() + \
+            0.01 * feat.pow(2).mean()
+        return loss, y, gx, x
+
+    l1, y1, g1, x1 = loss_of(True)
+    assert sdf.__dict__['_jet'] is not None, "the jet path was not taken"
+    l0, y0, g0, xa = loss_of(False)
+    close(y1, y0, rtol=1e-5, atol=1e-6)
+    close(g1, g0, rtol=1e-4, atol=1e-5)
+    ga, gb = _grads(l1, params + [x1]), _grads(l0, params + [xa])
+    for a, b in zip(ga, gb):
+        close(a, b, rtol=2e-3, atol=2e-6 + 1e-3 * float(b.abs().max()))
+
+
+def test_translator_and_composite_jet_jacobian(nets):
+    """MLPTranslator / CompositeDeformer forward(jet=True): output, Jacobian (utils.compute_Jacobian) and the gradients
+    of a loss of both wrt MLP weights, per-frame codes, poses and the points equal the autograd formulation
+    (utils/utils.py:133-156 with create_graph=True)."""
+    from recmv.utils import compute_Jacobian
+    gt, gl = load("translator"), load("lbs")
+    comp = nets["comp"]
+    g = torch.Generator().manual_seed(5)
+    p0 = (torch.randn(600, 3, generator=g) * 0.4).to(DEV)
+    binds = torch.randint(0, 3, (600,), generator=g).to(DEV)
+    wj = torch.randn(600, 3, 3, generator=g).to(DEV)
+    wd = torch.randn(600, 3, generator=g).to(DEV)
+
+    def run(jet):
+        conds = gt["conds"].to(DEV).clone().requires_grad_(True)
+        poses = gl["poses"].to(DEV).clone().requires_grad_(True)
+        trans = gl["trans"].to(DEV).clone().requires_grad_(True)
+        p = p0.clone().requires_grad_(True)
+        d = comp(p, [conds, [poses, trans]], binds, ratio=RATIO, offset_type="upper", jet=jet)
+        J = compute_Jacobian(p, d, True, True)
+        loss = (J * wj).sum() / 600 + (d * wd).sum() / 600 + (J ** 2).mean()
+        leaves = [q for q in comp.parameters() if q.requires_grad] + [conds, poses, trans, p]
+        return d, J, _grads(loss, leaves)
+
+    d1, J1, g1 = run(True)
+    d0, J0, g0 = run(False)
+    close(d1, d0, rtol=1e-5, atol=2e-6)
+    close(J1, J0, rtol=1e-4, atol=1e-5)
+    for a, b in zip(g1, g0):
+        close(a, b, rtol=2e-3, atol=2e-6 + 1e-3 * float(b.abs().max()))
+    # offset MLP alone on a [N,P,3] batch with broadcast codes (the deformation regulariser's call)
+    mlp = comp.defs[0]
+    pts0 = (torch.randn(3, 200, 3, generator=g) * 0.4).to(DEV)
+
+    def run3(jet):
+        conds = gt["conds"].to(DEV).clone().requires_grad_(True)
+        pts = pts0.clone().requires_grad_(True)
+        out = mlp(pts, conds, ratio=RATIO, offset_type="upper", jet=jet)
+        J = compute_Jacobian(pts, out, True, True)
+        loss = (J ** 2).mean() + out.pow(2).mean()
+        return out, J, _grads(loss, [q for q in mlp.parameters()] + [conds, pts])
+
+    o1, Jm1, gm1 = run3(True)
+    o0, Jm0, gm0 = run3(False)
+    close(o1, o0, rtol=1e-5, atol=2e-6)
+    close(Jm1, Jm0, rtol=1e-4, atol=1e-5)
+    for a, b in zip(gm1, gm0):
+        close(a, b, rtol=2e-3, atol=2e-6 + 1e-3 * float(b.abs().max()))

@@ -149,6 +149,12 @@ int recmv_mc_emit(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float is
 int recmv_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
                   float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                   int act, float act_param, float out_scale, void* stream);
+/* C[M,N] = ( G (.) act'(z) * g_scale ) . B^T with act'(z) taken through y = act(z) = y_scale * Y[m,k]: the
+ * activation-gradient step of a layer's backward fused into the A-operand staging of the dX product.
+ * ldg may be 0 (one cotangent row shared by all points). */
+int recmv_gemm_nt_actgrad(const float* G, int64_t ldg, const float* Y, int64_t ldy, const float* B, int64_t ldb,
+                          float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param,
+                          float y_scale, float g_scale, void* stream);
 int64_t recmv_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb,
                   float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

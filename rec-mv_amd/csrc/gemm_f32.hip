@@ -57,6 +57,33 @@ __device__ __forceinline__ float apply_act(float z, float p, float inv_p) {
   return z;
 }
 
+// act'(z) expressed through y = act(z) (elementwise.hip has the same formulas)
+__device__ __forceinline__ float dact_y(float y, int act, float p) {
+  switch (act) {
+    case RECMV_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case RECMV_ACT_SOFTPLUS: return -expm1f(-p * y);
+    case RECMV_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+// Optional transform of the A operand while it is staged: A_eff = A (.) act'(y_scale * Y) * a_scale — the
+// dZ = dY (.) act'(Z) step of a layer's backward fused into the dX = dZ W product (no dZ round trip through HBM).
+struct AMul {
+  const float* Y;
+  int64_t ldy;
+  int act;
+  float param, y_scale, a_scale;
+};
+
+__device__ __forceinline__ float4 amul4(float4 a, float4 y, const AMul& m) {
+  a.x *= dact_y(y.x * m.y_scale, m.act, m.param) * m.a_scale;
+  a.y *= dact_y(y.y * m.y_scale, m.act, m.param) * m.a_scale;
+  a.z *= dact_y(y.z * m.y_scale, m.act, m.param) * m.a_scale;
+  a.w *= dact_y(y.w * m.y_scale, m.act, m.param) * m.a_scale;
+  return a;
+}
+
 // 4 consecutive floats of a row, zero-filled past `limit` (elements left in the row).
 __device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int64_t limit, bool vec_ok) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -123,13 +150,13 @@ __device__ __forceinline__ void nt_epilogue(const float* __restrict__ Cs, const 
   }
 }
 
-template <int T, bool FAST>
+template <int T, bool FAST, bool AMUL>
 __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ B, int64_t ldb,
                                                        const float* __restrict__ bias, float* __restrict__ C,
                                                        int64_t ldc, int M, int N, int K, int act,
                                                        float act_param, float out_scale, int nbm, int nbn,
-                                                       bool a_vec, bool b_vec, bool c_vec) {
+                                                       bool a_vec, bool b_vec, bool c_vec, AMul am) {
   constexpr int TBM = 64 * T, TBN = 64 * T;     // workgroup tile
   constexpr int WT = 32 * T;                    // wave tile edge
   constexpr int NLD = TBM * 8 / kBlk;           // float4 per thread per operand tile (4 or 2)
@@ -154,6 +181,7 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
   float4 ra[NLD], rb[NLD];
   const float* pa[NLD];
   const float* pb[NLD];
+  const float* py[NLD];
   if (FAST) {
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
@@ -164,6 +192,7 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
       gn = gn < N ? gn : N - 1;
       pa[r] = A + (int64_t)gm * lda + c4 * 4;
       pb[r] = B + (int64_t)gn * ldb + c4 * 4;
+      if (AMUL) py[r] = am.Y + (int64_t)gm * am.ldy + c4 * 4;
     }
   }
   auto gload = [&](int k0) {
@@ -176,10 +205,12 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
         const bool in = k < K;                  // K % 4 == 0: a float4 is entirely inside or outside
         ra[r] = in ? *reinterpret_cast<const float4*>(pa[r] + k0) : make_float4(0, 0, 0, 0);
         rb[r] = in ? *reinterpret_cast<const float4*>(pb[r] + k0) : make_float4(0, 0, 0, 0);
+        if (AMUL && in) ra[r] = amul4(ra[r], *reinterpret_cast<const float4*>(py[r] + k0), am);
       } else {
         const int gm = m0 + row, gn = n0 + row;
         ra[r] = (gm < M) ? load4_guard(A + (int64_t)gm * lda + k, K - k, a_vec) : make_float4(0, 0, 0, 0);
         rb[r] = (gn < N) ? load4_guard(B + (int64_t)gn * ldb + k, K - k, b_vec) : make_float4(0, 0, 0, 0);
+        if (AMUL && gm < M) ra[r] = amul4(ra[r], load4_guard(am.Y + (int64_t)gm * am.ldy + k, K - k, false), am);
       }
     }
   };
@@ -412,22 +443,44 @@ int tn_splits(int64_t M, int64_t N, int64_t K) {
 
 using namespace recmv;
 
-template <int T, bool FAST>
+template <int T, bool FAST, bool AMUL>
 static int launch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
                      int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
-                     bool a_vec, bool b_vec, bool c_vec, hipStream_t stream) {
+                     bool a_vec, bool b_vec, bool c_vec, const AMul& am, hipStream_t stream) {
   constexpr int lds = kNtLds / (T == 2 ? 1 : 2);
   static bool attr_set = false;
   if (!attr_set) {
-    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, FAST>,
+    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, FAST, AMUL>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   const int nbm = (int)ceil_div(M, 64 * T), nbn = (int)ceil_div(N, 64 * T);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, FAST>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds, stream, A, lda,
-                     B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, a_vec, b_vec,
-                     c_vec);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, FAST, AMUL>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds, stream, A,
+                     lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, a_vec,
+                     b_vec, c_vec, am);
   return check_launch("gemm_nt");
+}
+
+template <bool AMUL>
+static int dispatch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
+                       int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
+                       const AMul& am, hipStream_t s) {
+  const bool a_vec = aligned16(A) && lda % 4 == 0 && (!AMUL || (aligned16(am.Y) && am.ldy % 4 == 0));
+  const bool b_vec = aligned16(B) && ldb % 4 == 0;
+  const bool c_vec = aligned16(C) && ldc % 4 == 0;
+  const bool fast = a_vec && b_vec && K % 4 == 0 && K > 0;
+  // tile choice: 128x128 tiles unless they would leave the 256 CUs under-filled (< 2 workgroups per CU)
+  const int64_t big_blocks = ceil_div(M, BM) * ceil_div(N, BN);
+  if (big_blocks >= 2 * kNumCU) {
+    return fast ? launch_nt<2, true, AMUL>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec,
+                                           b_vec, c_vec, am, s)
+                : launch_nt<2, false, AMUL>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec,
+                                            b_vec, c_vec, am, s);
+  }
+  return fast ? launch_nt<1, true, AMUL>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec, b_vec,
+                                         c_vec, am, s)
+              : launch_nt<1, false, AMUL>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec,
+                                          b_vec, c_vec, am, s);
 }
 
 extern "C" int recmv_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
@@ -439,22 +492,24 @@ extern "C" int recmv_gemm_nt(const float* A, int64_t lda, const float* B, int64_
   RECMV_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt: leading dimension too small");
   RECMV_REQUIRE(M < (1ll << 31) - BM && N < (1ll << 31) - BN && K < (1ll << 31) - BK, "gemm_nt: size overflow");
   RECMV_REQUIRE(act >= RECMV_ACT_NONE && act <= RECMV_ACT_TANH, "gemm_nt: unknown activation %d", act);
-  const bool a_vec = aligned16(A) && lda % 4 == 0, b_vec = aligned16(B) && ldb % 4 == 0;
-  const bool c_vec = aligned16(C) && ldc % 4 == 0;
-  const bool fast = a_vec && b_vec && K % 4 == 0 && K > 0;
-  hipStream_t s = (hipStream_t)stream;
-  // tile choice: 128x128 tiles unless they would leave the 256 CUs under-filled (< 2 workgroups per CU)
-  const int64_t big_blocks = ceil_div(M, BM) * ceil_div(N, BN);
-  if (big_blocks >= 2 * kNumCU) {
-    return fast ? launch_nt<2, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec, b_vec,
-                                     c_vec, s)
-                : launch_nt<2, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec, b_vec,
-                                      c_vec, s);
-  }
-  return fast ? launch_nt<1, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec, b_vec,
-                                   c_vec, s)
-              : launch_nt<1, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec, b_vec,
-                                    c_vec, s);
+  AMul am = {nullptr, 0, RECMV_ACT_NONE, 0.f, 1.f, 1.f};
+  return dispatch_nt<false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, am, (hipStream_t)stream);
+}
+
+// C[M,N] = (G (.) act'(y_scale * Y) * g_scale) . B^T : the activation-gradient step fused into the product.
+// G's row stride ldg may be 0 (one cotangent row for every point).
+extern "C" int recmv_gemm_nt_actgrad(const float* G, int64_t ldg, const float* Y, int64_t ldy, const float* B,
+                                     int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
+                                     float act_param, float y_scale, float g_scale, void* stream) {
+  RECMV_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_nt_actgrad: negative size");
+  if (M == 0 || N == 0) return RECMV_OK;
+  RECMV_REQUIRE(G && Y && B && C, "gemm_nt_actgrad: NULL pointer");
+  RECMV_REQUIRE((ldg >= K || ldg == 0) && ldy >= K && ldb >= K && ldc >= N,
+                "gemm_nt_actgrad: leading dimension too small");
+  RECMV_REQUIRE(M < (1ll << 31) - BM && N < (1ll << 31) - BN && K < (1ll << 31) - BK, "gemm_nt_actgrad: size overflow");
+  RECMV_REQUIRE(act >= RECMV_ACT_NONE && act <= RECMV_ACT_TANH, "gemm_nt_actgrad: unknown activation %d", act);
+  AMul am = {Y, ldy, act, act_param, y_scale, g_scale};
+  return dispatch_nt<true>(G, ldg, B, ldb, nullptr, C, ldc, M, N, K, RECMV_ACT_NONE, 0.f, 1.f, am, (hipStream_t)stream);
 }
 
 extern "C" int64_t recmv_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {

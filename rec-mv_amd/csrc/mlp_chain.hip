@@ -251,30 +251,21 @@ extern "C" int recmv_mlp_vjp_input(const recmv_mlp* m, const float* x, int64_t P
   for (int l = n - 2; l >= 0; --l) {
     const float* y = base + L.off_act[l] / 4;
     const bool skip_next = l + 1 == m->skip_layer;
-    float* gz = gbuf[cur];
-    cur ^= 1;
-    if (skip_next) {
-      // y = [act(z)/sqrt2 | gamma/sqrt2]: left part through the activation, right part to the encoding
-      RECMV_TRY(recmv_act_grad_2d(g, ld, y, L.ld_act, gz, L.ld_act, P, m->rows[l], m->hidden_act, m->act_param, kSqrt2,
-                                  kInvSqrt2, stream));
-      skip_g = g + m->rows[l];
-      skip_ld = ld;
-    } else {
-      RECMV_TRY(recmv_act_grad_2d(g, ld, y, L.ld_act, gz, L.ld_act, P, m->rows[l], m->hidden_act, m->act_param, 1.f,
-                                  1.f, stream));
-    }
     float* gin = gbuf[cur];
-    // the skip gradient still lives in the buffer we are about to overwrite two steps later: park it
-    RECMV_TRY(recmv_gemm_nt(gz, L.ld_act, m->Wt[l], m->rows[l], nullptr, gin, L.ld_act, P, m->dims[l], m->rows[l],
-                            RECMV_ACT_NONE, 0.f, 1.f, stream));
     if (skip_next) {
-      // keep (1/sqrt2) * g[:, rows:] in the input-gradient slot of the workspace's input buffer region: the input
-      // buffer itself is no longer needed by the remaining (earlier) layers' activation gradients
+      // y = [act(z)/sqrt2 | gamma/sqrt2]: left part through the activation, right part to the encoding.  The
+      // right part is parked FIRST (the product below overwrites the buffer it may live in two steps later).
       float* park = base + L.off_in / 4;
-      RECMV_TRY(recmv_add_scaled_2d(skip_g, skip_ld, skip_g, skip_ld, kInvSqrt2 - 1.f, park, L.ld_in, P, d_pe, stream));
+      RECMV_TRY(recmv_add_scaled_2d(g + m->rows[l], ld, g + m->rows[l], ld, kInvSqrt2 - 1.f, park, L.ld_in, P, d_pe,
+                                    stream));
       skip_g = park;
       skip_ld = L.ld_in;
     }
+    // gin = (g (.) act'(z)) W  — activation gradient fused into the MFMA product's operand staging
+    RECMV_TRY(recmv_gemm_nt_actgrad(g, ld, y, L.ld_act, m->Wt[l], m->rows[l], gin, L.ld_act, P, m->dims[l], m->rows[l],
+                                    m->hidden_act, m->act_param, skip_next ? kSqrt2 : 1.f,
+                                    skip_next ? kInvSqrt2 : 1.f, stream));
+    cur ^= 1;
     g = gin;
     ld = L.ld_act;
   }

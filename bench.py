@@ -49,56 +49,31 @@ MFMA_F32_PEAK = 157.3e12      # FLOP/s, MI355X_MICROARCH.md (f32-input MFMA == f
 HBM_PEAK = 8.0e12             # B/s
 
 
-class GemmProfiler:
-    """Collects (start, end) HIP events + algorithmic FLOPs of every gemm_nt launch, keyed by the kernel variant the
-    C launcher will pick (same rule as recmv_gemm_nt in csrc/gemm_f32.hip), so that the numbers can be compared with
-    the per-kernel averages of a rocprofv3 --kernel-trace of the same command.  The events are recorded on torch's
-    current stream, which is the stream the kernels are launched on."""
+NT_VARIANTS = ["gemm_nt_kernel<%d, %s, %s>" % (1 + (v & 1), "true" if v & 2 else "false", "true" if v & 4 else "false")
+               for v in range(8)] + ["gemm_tn_kernel (+ splitk_reduce_kernel)"]
 
-    def __init__(self):
-        self.records = {}
 
-    def launch(self, key, flops, fn):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        out = fn()
-        b.record()
-        self.records.setdefault(key, []).append((a, b, flops))
-        return out
+class KernelEvents:
+    """HIP-event timing of every MFMA kernel launch in the timed region, recorded inside librecmv_hip.so on the stream
+    each kernel is launched on (recmv_profile_begin / recmv_profile_end, csrc/gemm_f32.hip) — launches made from the
+    C launch chains are covered as well as those made from Python.  The kernel names match the rocprofv3
+    --kernel-trace of the same command."""
 
-    def summary(self):
+    def begin(self):
+        from recmv import _lib as L
+        L.check(L.lib().recmv_profile_begin(), "profile_begin")
+
+    def end(self):
+        import ctypes as C
+        from recmv import _lib as L
+        buf = (C.c_double * 27)()
+        L.check(L.lib().recmv_profile_end(C.cast(buf, C.c_void_p), 9), "profile_end")
         out = {}
-        for key, recs in self.records.items():
-            t = sum(a.elapsed_time(b) for a, b, _ in recs) * 1e-3
-            fl = sum(f for _, _, f in recs)
-            n = len(recs)
-            out[key] = dict(launches=n, seconds=t, flops=fl, avg_us=t / n * 1e6, avg_flops=fl / n)
+        for v, name in enumerate(NT_VARIANTS):
+            n, sec, fl = buf[3 * v], buf[3 * v + 1], buf[3 * v + 2]
+            if n > 0:
+                out[name] = dict(launches=int(n), seconds=sec, flops=fl, avg_us=sec / n * 1e6, avg_flops=fl / n)
         return out
-
-
-def _nt_variant(A, B, out):
-    """Kernel variant chosen by recmv_gemm_nt (csrc/gemm_f32.hip): tile 128 (T=2) when >= 2 workgroups per CU."""
-    M, K = A.shape
-    N = B.shape[0]
-    big = -(-M // 128) * -(-N // 128) >= 512
-
-    def vec(t):
-        return t.data_ptr() % 16 == 0 and (t.shape[0] <= 1 or t.stride(0) % 4 == 0)
-    fast = vec(A) and vec(B) and K % 4 == 0 and K > 0
-    return "gemm_nt_kernel<%d, %s>" % (2 if big else 1, "true" if fast else "false")
-
-
-def install_gemm_profiler(prof):
-    from recmv import ops
-    orig = ops.gemm_nt
-
-    def wrapped(A, B, bias=None, act=ops.ACT_NONE, act_param=0.0, out_scale=1.0, out=None):
-        flops = 2.0 * A.shape[0] * B.shape[0] * A.shape[1]
-        A, B = ops._rowmajor(A), ops._rowmajor(B)
-        return prof.launch(_nt_variant(A, B, out), flops, lambda: orig(A, B, bias, act, act_param, out_scale, out))
-
-    ops.gemm_nt = wrapped
-    return lambda: setattr(ops, "gemm_nt", orig)
 
 
 def mc_extract_timing(device):
@@ -216,6 +191,8 @@ def main():
     ap.add_argument("--stage", default="coarse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket the MFMA kernel launches with HIP events (no roofline object)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--conf", default=str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
     args = ap.parse_args()
@@ -246,8 +223,9 @@ def main():
         it += 1
         torch.cuda.synchronize()
         log("warm-up step %d done" % it)
-    prof = GemmProfiler()
-    restore = install_gemm_profiler(prof)
+    prof = KernelEvents() if not args.no_kernel_events else None
+    if prof:
+        prof.begin()
     if getattr(loop, "phase_ms", None):
         loop.phase_ms = {}          # RECMV_TIMING=1: report the timed steps only
     rays = 0
@@ -263,7 +241,7 @@ def main():
     torch.cuda.synchronize()
     rdist.barrier()
     elapsed = time.perf_counter() - t0
-    restore()
+    gs = prof.end() if prof else {}
     if world > 1:
         t = torch.tensor([elapsed, float(rays)], device=device, dtype=torch.float64)
         tmax = t.clone()
@@ -273,7 +251,6 @@ def main():
         elapsed, rays = float(tmax[0]), int(tsum[1])
 
     if rank == 0:
-        gs = prof.summary()
         iters = args.steps * world
         line = {
             "metric": "optimiser iters/sec, female-3-casual-like 512x512 (synthetic frames)",
@@ -305,7 +282,7 @@ def main():
             dom = max(gs, key=lambda k: gs[k]["seconds"])
             g = gs[dom]
             ach = g["flops"] / g["seconds"]
-            line["roofline"] = {"kernel": "recmv::" + dom + " (fused f32-MFMA layer: GEMM + bias + activation)",
+            line["roofline"] = {"kernel": "recmv::" + dom + " (f32-MFMA layer: GEMM + bias + activation epilogue)",
                                 "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": MFMA_F32_PEAK / 1e12,
                                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), "traffic": None,
                                 "launches": g["launches"], "avg_launch_us": round(g["avg_us"], 2),

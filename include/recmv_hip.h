@@ -316,6 +316,16 @@ int recmv_mlp_jet_backward(const recmv_mlp* m, const float* x, const float* eye3
 int recmv_gather_rows(const float* table, int64_t ldt, const int64_t* index, float* out, int64_t ldo, int64_t rows,
                       int64_t cols, int64_t fill, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-launch HIP-event timing of the MFMA kernels, for the bench's roofline object.  Between
+ * recmv_profile_begin() and recmv_profile_end() every gemm_nt / gemm_tn launch (from Python or from inside the
+ * launch chains) is bracketed by events recorded on its launch stream.  recmv_profile_end fills, per kernel variant
+ * v (0..7: gemm_nt_kernel<T, FAST, AMUL>, v = (T-1) + 2*FAST + 4*AMUL; 8: gemm_tn_kernel + its split-K reduction):
+ * out[3v] = launches, out[3v+1] = summed duration [s], out[3v+2] = summed algorithmic FLOP (2 M N K).
+ * ---------------------------------------------------------------------------------------------- */
+int recmv_profile_begin(void);
+int recmv_profile_end(double* out, int n_variants);
+
 #ifdef __cplusplus
 }
 #endif

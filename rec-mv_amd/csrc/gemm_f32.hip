@@ -19,6 +19,8 @@
 //
 // FLOPs: 2*M*N*K.  With K=N=512 the arithmetic intensity is 128 FLOP/B >> 157e12/8e12, so every layer
 // is MFMA-bound, not HBM-bound.
+#include <mutex>
+#include <vector>
 #include "common.h"
 
 namespace recmv {
@@ -423,6 +425,56 @@ __global__ __launch_bounds__(kBlk) void posenc_kernel(const float* __restrict__ 
   }
 }
 
+// ---- optional per-launch HIP-event timing of the MFMA kernels (bench.py's roofline object) ----------------------
+// Events are recorded on the stream the kernel is launched on, immediately before and after the launch.
+struct LaunchRec {
+  hipEvent_t a, b;
+  int variant;
+  double flops;
+};
+struct Profiler {
+  bool on = false;
+  std::vector<LaunchRec> recs;
+  std::vector<hipEvent_t> pool;
+  std::mutex mu;        // autograd's backward thread launches too
+  hipEvent_t get() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+};
+Profiler g_prof;
+
+struct ScopedLaunchTimer {
+  LaunchRec r;
+  hipStream_t s;
+  bool active;
+  ScopedLaunchTimer(int variant, double flops, hipStream_t stream) : s(stream), active(g_prof.on) {
+    if (!active) return;
+    r.variant = variant;
+    r.flops = flops;
+    r.a = g_prof.get();
+    r.b = g_prof.get();
+    if (!r.a || !r.b) {
+      active = false;
+      return;
+    }
+    (void)hipEventRecord(r.a, s);
+  }
+  ~ScopedLaunchTimer() {
+    if (!active) return;
+    (void)hipEventRecord(r.b, s);
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.recs.push_back(r);
+  }
+};
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 constexpr int kNtLds = (2 * BM * LDK + 2 * BN * LDK) * 4;   // 73728 B (T=2); half of it for T=1
@@ -455,6 +507,7 @@ static int launch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, c
     attr_set = true;
   }
   const int nbm = (int)ceil_div(M, 64 * T), nbn = (int)ceil_div(N, 64 * T);
+  ScopedLaunchTimer timer((T - 1) + 2 * (FAST ? 1 : 0) + 4 * (AMUL ? 1 : 0), 2.0 * M * N * K, stream);
   hipLaunchKernelGGL((gemm_nt_kernel<T, FAST, AMUL>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds, stream, A,
                      lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, a_vec,
                      b_vec, c_vec, am);
@@ -545,6 +598,7 @@ extern "C" int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_
   const int nbm = (int)ceil_div(M, BM), nbn = (int)ceil_div(N, BN);
   int64_t kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
   const bool a_vec = aligned16(A) && lda % 4 == 0, b_vec = aligned16(B) && ldb % 4 == 0;
+  ScopedLaunchTimer timer(8, 2.0 * M * N * K, s);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(nbm * nbn * splits)), dim3(kBlk), kTnLds, s, A, lda, B, ldb,
                      (float*)workspace, (int)M, (int)N, K, nbm, nbn, kchunk, a_vec, b_vec);
   int rc = check_launch("gemm_tn");
@@ -568,4 +622,33 @@ extern "C" int recmv_posenc_forward(const float* x, int64_t ldx, float* out, int
   hipLaunchKernelGGL(posenc_kernel, dim3(stream_grid(P * (1 + 2 * L), kBlk)), dim3(kBlk), 0, s, x, ldx, out, ldo,
                      ldo_fill, P, L, hw, out_scale);
   return check_launch("posenc");
+}
+
+// Per-launch HIP-event timing of the MFMA kernels.  recmv_profile_begin() starts recording (events on the launch
+// stream around every gemm_nt / gemm_tn launch); recmv_profile_end() waits for the recorded events and returns, per
+// kernel variant v (0..7: gemm_nt_kernel<T, FAST, AMUL> with v = (T-1) + 2*FAST + 4*AMUL; 8: gemm_tn_kernel +
+// its split-K reduction), out[3*v + 0] = launches, out[3*v + 1] = summed duration in seconds,
+// out[3*v + 2] = summed algorithmic FLOP (2 M N K).
+extern "C" int recmv_profile_begin(void) {
+  g_prof.recs.clear();
+  g_prof.on = true;
+  return RECMV_OK;
+}
+
+extern "C" int recmv_profile_end(double* out, int n_variants) {
+  g_prof.on = false;
+  RECMV_REQUIRE(out && n_variants >= 9, "profile_end: need room for 9 variants");
+  for (int i = 0; i < 3 * n_variants; ++i) out[i] = 0.0;
+  for (auto& r : g_prof.recs) {
+    RECMV_HIP_TRY(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    RECMV_HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+    out[3 * r.variant + 0] += 1.0;
+    out[3 * r.variant + 1] += (double)ms * 1e-3;
+    out[3 * r.variant + 2] += r.flops;
+    g_prof.pool.push_back(r.a);
+    g_prof.pool.push_back(r.b);
+  }
+  g_prof.recs.clear();
+  return RECMV_OK;
 }

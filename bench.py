@@ -59,20 +59,25 @@ class KernelEvents:
     C launch chains are covered as well as those made from Python.  The kernel names match the rocprofv3
     --kernel-trace of the same command."""
 
+    MIN_FLOPS = 4.0e9     # launches below 4 GFLOP (the ray path's ~20 us kernels) are counted, not bracketed
+
     def begin(self):
         from recmv import _lib as L
-        L.check(L.lib().recmv_profile_begin(), "profile_begin")
+        L.check(L.lib().recmv_profile_begin(self.MIN_FLOPS), "profile_begin")
 
     def end(self):
         import ctypes as C
         from recmv import _lib as L
-        buf = (C.c_double * 27)()
+        buf = (C.c_double * 45)()
         L.check(L.lib().recmv_profile_end(C.cast(buf, C.c_void_p), 9), "profile_end")
-        out = {}
+        out, small = {}, {}
         for v, name in enumerate(NT_VARIANTS):
-            n, sec, fl = buf[3 * v], buf[3 * v + 1], buf[3 * v + 2]
+            n, sec, fl, un, ufl = buf[5 * v:5 * v + 5]
             if n > 0:
                 out[name] = dict(launches=int(n), seconds=sec, flops=fl, avg_us=sec / n * 1e6, avg_flops=fl / n)
+            if un > 0:
+                small[name] = dict(launches=int(un), gflop=round(ufl / 1e9, 1))
+        self.small = small
         return out
 
 
@@ -290,7 +295,8 @@ def main():
                                 "share_of_step": round(g["seconds"] / elapsed, 3),
                                 "other_variants": {k: {"launches": v["launches"], "avg_launch_us": round(v["avg_us"], 2),
                                                        "achieved": round(v["flops"] / v["seconds"] / 1e12, 3)}
-                                                   for k, v in gs.items() if k != dom}}
+                                                   for k, v in gs.items() if k != dom},
+                                "untimed_small_launches": prof.small}
         log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
         if getattr(loop, "phase_ms", None):
             log("phase ms (RECMV_TIMING=1, timed steps only): " + json.dumps({k: round(v, 1) for k, v in loop.phase_ms.items()}))

@@ -434,6 +434,8 @@ struct LaunchRec {
 };
 struct Profiler {
   bool on = false;
+  double min_flops = 0.0;          // launches below this are counted but not bracketed by events
+  double untimed[9][2] = {};       // [variant][launches, flops]
   std::vector<LaunchRec> recs;
   std::vector<hipEvent_t> pool;
   std::mutex mu;        // autograd's backward thread launches too
@@ -457,6 +459,13 @@ struct ScopedLaunchTimer {
   bool active;
   ScopedLaunchTimer(int variant, double flops, hipStream_t stream) : s(stream), active(g_prof.on) {
     if (!active) return;
+    if (flops < g_prof.min_flops) {
+      std::lock_guard<std::mutex> lk(g_prof.mu);
+      g_prof.untimed[variant][0] += 1.0;
+      g_prof.untimed[variant][1] += flops;
+      active = false;
+      return;
+    }
     r.variant = variant;
     r.flops = flops;
     r.a = g_prof.get();
@@ -627,10 +636,13 @@ extern "C" int recmv_posenc_forward(const float* x, int64_t ldx, float* out, int
 // Per-launch HIP-event timing of the MFMA kernels.  recmv_profile_begin() starts recording (events on the launch
 // stream around every gemm_nt / gemm_tn launch); recmv_profile_end() waits for the recorded events and returns, per
 // kernel variant v (0..7: gemm_nt_kernel<T, FAST, AMUL> with v = (T-1) + 2*FAST + 4*AMUL; 8: gemm_tn_kernel +
-// its split-K reduction), out[3*v + 0] = launches, out[3*v + 1] = summed duration in seconds,
-// out[3*v + 2] = summed algorithmic FLOP (2 M N K).
-extern "C" int recmv_profile_begin(void) {
+// its split-K reduction), out[5v] = timed launches, out[5v+1] = their summed duration in seconds, out[5v+2] = their
+// summed algorithmic FLOP (2 M N K), out[5v+3] / out[5v+4] = launches / FLOP of the launches below `min_flops`, which
+// are only counted (bracketing tens of thousands of ~20 us launches with events would perturb the run being timed).
+extern "C" int recmv_profile_begin(double min_flops) {
   g_prof.recs.clear();
+  for (auto& u : g_prof.untimed) u[0] = u[1] = 0.0;
+  g_prof.min_flops = min_flops;
   g_prof.on = true;
   return RECMV_OK;
 }
@@ -638,14 +650,18 @@ extern "C" int recmv_profile_begin(void) {
 extern "C" int recmv_profile_end(double* out, int n_variants) {
   g_prof.on = false;
   RECMV_REQUIRE(out && n_variants >= 9, "profile_end: need room for 9 variants");
-  for (int i = 0; i < 3 * n_variants; ++i) out[i] = 0.0;
+  for (int i = 0; i < 5 * n_variants; ++i) out[i] = 0.0;
+  for (int v = 0; v < 9; ++v) {
+    out[5 * v + 3] = g_prof.untimed[v][0];
+    out[5 * v + 4] = g_prof.untimed[v][1];
+  }
   for (auto& r : g_prof.recs) {
     RECMV_HIP_TRY(hipEventSynchronize(r.b));
     float ms = 0.f;
     RECMV_HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
-    out[3 * r.variant + 0] += 1.0;
-    out[3 * r.variant + 1] += (double)ms * 1e-3;
-    out[3 * r.variant + 2] += r.flops;
+    out[5 * r.variant + 0] += 1.0;
+    out[5 * r.variant + 1] += (double)ms * 1e-3;
+    out[5 * r.variant + 2] += r.flops;
     g_prof.pool.push_back(r.a);
     g_prof.pool.push_back(r.b);
   }

@@ -102,7 +102,7 @@ def _declare(lib):
         "recmv_mlp_jet_backward": (C.c_int, [C.POINTER(Mlp), vp, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, vp, i64,
                                              vp]),
         "recmv_gather_rows": (C.c_int, [vp, i64, vp, vp, i64, i64, i64, i64, vp]),
-        "recmv_profile_begin": (C.c_int, []),
+        "recmv_profile_begin": (C.c_int, [C.c_double]),
         "recmv_profile_end": (C.c_int, [vp, i32]),
         "recmv_lbs_forward": (C.c_int, [vp, vp, i64, vp, vp, i64, C.POINTER(LbsGrid), vp, vp, vp, vp, vp, vp, vp]),
         "recmv_lbs_vjp_input": (C.c_int, [vp, vp, i64, vp, i64, C.POINTER(LbsGrid), vp, vp, vp]),

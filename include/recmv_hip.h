@@ -274,6 +274,12 @@ int recmv_lbs_forward(const float* ps, const int64_t* frame, int64_t P, const fl
                       float* loss2, float* angle, float* g_d, void* stream);
 int recmv_lbs_vjp_input(const float* ps, const int64_t* frame, int64_t P, const float* A, int64_t B,
                         const recmv_lbs_grid* grid, const float* g_d, float* g_p, void* stream);
+/* Parameter side of the skinning VJP, staged for two fixed-order reductions: W [P,24] (sampled blend weights),
+ * Q [P, B*12] = g_d (x) [p;1] in the point's frame block (zeros elsewhere), Gs [P, B*3] = g_d likewise.  Then
+ * gA[b,j,i,k] = recmv_gemm_tn(W, Q)[j, b*12 + 4i + k] and gtrans[b,i] = recmv_colsum(Gs)[b*3 + i]. */
+int recmv_lbs_vjp_params_stage(const float* ps, const int64_t* frame, int64_t P, int64_t B,
+                               const recmv_lbs_grid* grid, const float* g_d, float* W, float* Q, float* Gs,
+                               void* stream);
 int recmv_rootfind_update(float* p, const float* f, const float* gf, const float* loss2, const float* angle,
                           const float* gd, uint8_t* unfinished, int32_t* counter, int64_t P, float dthreshold,
                           float athreshold, float w1, float w2, int do_update, void* stream);

@@ -63,7 +63,13 @@ __device__ __forceinline__ float apply_act(float z, float p, float inv_p) {
 __device__ __forceinline__ float dact_y(float y, int act, float p) {
   switch (act) {
     case RECMV_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-    case RECMV_ACT_SOFTPLUS: return -expm1f(-p * y);
+    case RECMV_ACT_SOFTPLUS: {
+      // sigmoid(beta z) = 1 - exp(-beta y).  This runs on the operand-staging path of an MFMA kernel, so it uses
+      // the hardware exp2 unit; below t = 1/64 the alternating series keeps the relative accuracy expm1 would give.
+      const float t = p * y;
+      const float series = t * (1.f - t * (0.5f - t * (0.16666667f - 0.041666668f * t)));
+      return t < 0.015625f ? series : 1.f - __expf(-t);
+    }
     case RECMV_ACT_TANH: return 1.f - y * y;
     default: return 1.f;
   }

@@ -178,6 +178,52 @@ __global__ __launch_bounds__(kBlk) void lbs_vjp_kernel(const float* __restrict__
   }
 }
 
+// Parameter side of the skinning VJP, staged for two deterministic reductions over the points:
+//   gA[b,j,i,k] = sum_{p in frame b} w_j(p) g_d[p,i] [p;1][k]  = (W^T Q)[j, b*12 + 4i + k]   (MFMA gemm_tn, K = P)
+//   gtrans[b,i] = sum_{p in frame b} g_d[p,i]                   = colsum(Gs)[b*3 + i]
+// with W [P,24] the sampled blend weights (one more gather of the corner records), Q [P, B*12] = g_d (x) [p;1]
+// written into the point's frame block (zeros elsewhere) and Gs [P, B*3] likewise.
+__global__ __launch_bounds__(kBlk) void lbs_vjp_params_stage_kernel(const float* __restrict__ ps,
+                                                                    const int64_t* __restrict__ frame, int B,
+                                                                    const float* __restrict__ vol, LbsGeom G, int64_t P,
+                                                                    const float* __restrict__ g_d,
+                                                                    float* __restrict__ Wout, float* __restrict__ Q,
+                                                                    float* __restrict__ Gs) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlk + threadIdx.x; i < P; i += (int64_t)gridDim.x * kBlk) {
+    const float px = ps[3 * i], py = ps[3 * i + 1], pz = ps[3 * i + 2];
+    const float g3[3] = {g_d[3 * i], g_d[3 * i + 1], g_d[3 * i + 2]};
+    const int b = (int)frame[i];
+    const Cell<float> c = make_cell<float>((px - G.cx) * G.sx, (py - G.cy) * G.sy, (pz - G.cz) * G.sz, G.W, G.H, G.D);
+    float w[kJ];
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) w[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      RECMV_CORNER_BITS(k);
+      if (c.in_x[bx] && c.in_y[by] && c.in_z[bz]) {
+        const float wk = c.fx[bx] * c.fy[by] * c.fz[bz];
+        float v[kJ];
+        load24(vol + (((int64_t)(c.z0 + bz) * G.H + (c.y0 + by)) * G.W + (c.x0 + bx)) * kJ, v);
+#pragma unroll
+        for (int j = 0; j < kJ; ++j) w[j] = fma(v[j], wk, w[j]);
+      }
+    }
+    float4* wo = reinterpret_cast<float4*>(Wout + i * kJ);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) wo[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    const float ph[4] = {px, py, pz, 1.f};
+    float* q = Q + i * (int64_t)(B * 12);
+    float* gs = Gs + i * (int64_t)(B * 3);
+    for (int bb = 0; bb < B; ++bb) {
+      const float on = bb == b ? 1.f : 0.f;
+#pragma unroll
+      for (int r = 0; r < 12; ++r) q[bb * 12 + r] = on * g3[r >> 2] * ph[r & 3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) gs[bb * 3 + r] = on * g3[r];
+    }
+  }
+}
+
 // One step of utils/FindSurfacePs.py:316-351 on all rays.
 __global__ __launch_bounds__(kBlk) void rootfind_update_kernel(float* __restrict__ p, const float* __restrict__ f,
                                                                const float* __restrict__ gf,
@@ -265,6 +311,23 @@ extern "C" int recmv_lbs_vjp_input(const float* ps, const int64_t* frame, int64_
   hipLaunchKernelGGL(lbs_vjp_kernel, dim3(stream_grid(P, kBlk)), dim3(kBlk), lds, (hipStream_t)stream, ps, frame, A,
                      (int)B, grid->volume, to_geom(grid), P, g_d, g_p);
   return check_launch("lbs_vjp_input");
+}
+
+// Stage the parameter side of the skinning VJP: W [P,24], Q [P, B*12], Gs [P, B*3] (see the kernel); the caller then
+// runs recmv_gemm_tn(W, Q) -> [24, B*12] and recmv_colsum(Gs) -> [B*3], both with a fixed summation order.
+extern "C" int recmv_lbs_vjp_params_stage(const float* ps, const int64_t* frame, int64_t P, int64_t B,
+                                          const recmv_lbs_grid* grid, const float* g_d, float* W, float* Q, float* Gs,
+                                          void* stream) {
+  RECMV_REQUIRE(P >= 0 && B >= 1 && B <= 128, "lbs_vjp_params_stage: bad size (P=%lld, B=%lld)", (long long)P,
+                (long long)B);
+  if (P == 0) return RECMV_OK;
+  int rc = check_geom(grid);
+  if (rc) return rc;
+  RECMV_REQUIRE(ps && frame && g_d && W && Q && Gs, "lbs_vjp_params_stage: NULL pointer");
+  RECMV_REQUIRE((reinterpret_cast<uintptr_t>(W) & 15) == 0, "lbs_vjp_params_stage: W must be 16-byte aligned");
+  hipLaunchKernelGGL(lbs_vjp_params_stage_kernel, dim3(stream_grid(P, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, ps,
+                     frame, (int)B, grid->volume, to_geom(grid), P, g_d, W, Q, Gs);
+  return check_launch("lbs_vjp_params_stage");
 }
 
 extern "C" int recmv_rootfind_update(float* p, const float* f, const float* gf, const float* loss2,

@@ -39,6 +39,46 @@ __global__ __launch_bounds__(kBlk) void colsum_partial_kernel(const float* __res
   }
 }
 
+__device__ __forceinline__ float dact_y(float y, int act, float p) {
+  switch (act) {
+    case RECMV_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case RECMV_ACT_SOFTPLUS: return -expm1f(-p * y);
+    case RECMV_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+// gz[r,c] = gy[r,c] * act'(z) (through y = act(z)), written out, AND partial[chunk][c] = column sums of gz over the
+// chunk's rows: the bias gradient comes out of the same pass over dY that produces dZ.
+__global__ __launch_bounds__(kBlk) void act_grad_colsum_kernel(const float* __restrict__ gy, int64_t ldg,
+                                                               const float* __restrict__ y, int64_t ldy,
+                                                               float* __restrict__ gz, int64_t ldz, int64_t rows,
+                                                               int cols, int64_t rows_per_chunk, int act, float p,
+                                                               float* __restrict__ partial) {
+  __shared__ float sh[kBlk / kColTile][kColTile];
+  const int ctile = blockIdx.x, chunk = blockIdx.y;
+  const int lane = threadIdx.x % kColTile, rgrp = threadIdx.x / kColTile;
+  const int c = ctile * kColTile + lane;
+  const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+  int64_t r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + rgrp; r < r1; r += kBlk / kColTile) {
+      const float v = gy[r * ldg + c] * dact_y(y[r * ldy + c], act, p);
+      gz[r * ldz + c] = v;
+      s += v;
+    }
+  sh[rgrp][lane] = s;
+  __syncthreads();
+  if (rgrp == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < kBlk / kColTile; ++q) t += sh[q][lane];
+    partial[(int64_t)chunk * cols + c] = t;
+  }
+}
+
 __global__ __launch_bounds__(kBlk) void colsum_final_kernel(const float* __restrict__ partial, int chunks, int cols,
                                                             float* __restrict__ out) {
   const int c = blockIdx.x * kBlk + threadIdx.x;
@@ -130,13 +170,30 @@ extern "C" int recmv_linear_backward(const float* gy, int64_t ldgy, const float*
   const float* gz = gy;
   int64_t ldgz = ldgy;
   int rc;
+  bool gb_done = false;
   if (act != RECMV_ACT_NONE && M > 0 && N > 0) {
-    rc = recmv_act_grad_2d(gy, ldgy, y, ldy, gzbuf, N, M, N, act, act_param, 1.f, 1.f, stream);
-    if (rc) return rc;
+    if (gb) {
+      // dZ and its column sums (the bias gradient) in one pass over dY
+      const int chunks = colsum_chunks(M);
+      const int64_t rpc = ceil_div(M, chunks);
+      hipLaunchKernelGGL(act_grad_colsum_kernel, dim3((unsigned)ceil_div(N, kColTile), (unsigned)chunks), dim3(kBlk), 0,
+                         (hipStream_t)stream, gy, ldgy, y, ldy, gzbuf, N, M, (int)N, rpc, act, act_param,
+                         (float*)cs_ws);
+      rc = check_launch("linear_backward/act_grad_colsum");
+      if (rc) return rc;
+      hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(N, kBlk)), dim3(kBlk), 0, (hipStream_t)stream,
+                         (const float*)cs_ws, chunks, (int)N, gb);
+      rc = check_launch("linear_backward/colsum_final");
+      if (rc) return rc;
+      gb_done = true;
+    } else {
+      rc = recmv_act_grad_2d(gy, ldgy, y, ldy, gzbuf, N, M, N, act, act_param, 1.f, 1.f, stream);
+      if (rc) return rc;
+    }
     gz = gzbuf;
     ldgz = N;
   }
-  if (gb) {
+  if (gb && !gb_done) {
     rc = recmv_colsum(gz, ldgz, M, N, gb, cs_ws, cs_bytes, stream);
     if (rc) return rc;
   }

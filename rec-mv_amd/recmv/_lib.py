@@ -106,6 +106,7 @@ def _declare(lib):
         "recmv_profile_end": (C.c_int, [vp, i32]),
         "recmv_lbs_forward": (C.c_int, [vp, vp, i64, vp, vp, i64, C.POINTER(LbsGrid), vp, vp, vp, vp, vp, vp, vp]),
         "recmv_lbs_vjp_input": (C.c_int, [vp, vp, i64, vp, i64, C.POINTER(LbsGrid), vp, vp, vp]),
+        "recmv_lbs_vjp_params_stage": (C.c_int, [vp, vp, i64, i64, C.POINTER(LbsGrid), vp, vp, vp, vp, vp]),
         "recmv_rootfind_update": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
     }
     for name, (res, args) in sigs.items():

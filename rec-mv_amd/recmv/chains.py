@@ -249,3 +249,65 @@ def mlp_jet(x, cond, cond_index, Ws, bs, dims, multires, pe_weights, cond_dim, s
     y, tang = MlpJet.apply(cfg, x, cond, *Ws, *bs)
     P = x.shape[0]
     return y, tang.view(3, P, n_j).permute(1, 2, 0)
+
+
+# --------------------------------------------------------------------------------------------------
+# Fused linear-blend skinning with first-order backward (csrc/lbs_fused.hip)
+# --------------------------------------------------------------------------------------------------
+def lbs_vjp_params(ps, frame, A_shape, grid, g_d):
+    """(gA [B,24,4,4], gtrans [B,3]) — staged kernel + MFMA gemm_tn + fixed-order column sum."""
+    from . import ops
+    P, B = ps.shape[0], A_shape[0]
+    dev = ps.device
+    W = torch.empty((P, 24), dtype=torch.float32, device=dev)
+    Q = torch.empty((P, B * 12), dtype=torch.float32, device=dev)
+    Gs = torch.empty((P, B * 3), dtype=torch.float32, device=dev)
+    lib = L.lib()
+    with torch.cuda.device(dev):
+        L.check(lib.recmv_lbs_vjp_params_stage(L.ptr(ps), L.ptr(frame), P, B, C.byref(grid), L.ptr(g_d), L.ptr(W),
+                                               L.ptr(Q), L.ptr(Gs), L.stream_ptr(dev)), "lbs_vjp_params_stage")
+        gAm = ops.gemm_tn(W, Q)                                            # [24, B*12]
+        need = int(lib.recmv_colsum_workspace_bytes(P, B * 3))
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        gt = torch.empty(B * 3, dtype=torch.float32, device=dev)
+        L.check(lib.recmv_colsum(L.ptr(Gs), B * 3, P, B * 3, L.ptr(gt), L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
+                "colsum")
+    gA = torch.zeros(A_shape, dtype=torch.float32, device=dev)
+    gA[:, :, :3, :] = gAm.view(24, B, 3, 4).permute(1, 0, 2, 3)
+    return gA, gt.view(B, 3)
+
+
+class LbsFused(torch.autograd.Function):
+    """d = (sum_j w_j(p) A[frame,j]) [p;1] + trans[frame] in one kernel; backward = the input VJP kernel plus the staged
+    parameter VJP.  When a graph is being built in backward (create_graph=True — the Jacobian terms of the loss), it
+    falls back to differentiating `classic`, the composition of differentiable ops (sampler with double backward)."""
+
+    @staticmethod
+    def forward(ctx, ps, A, trans, frame, grid, classic):
+        psd = ps.detach().contiguous()
+        Ad = A.detach().contiguous()
+        td = trans.detach().contiguous()
+        d = lbs_forward(psd, frame, Ad, td, grid)[0]
+        ctx.save_for_backward(ps, A, trans)
+        ctx.frame, ctx.grid, ctx.classic = frame, grid, classic
+        return d
+
+    @staticmethod
+    def backward(ctx, gd):
+        ps, A, trans = ctx.saved_tensors
+        frame, grid = ctx.frame, ctx.grid
+        need = ctx.needs_input_grad
+        if torch.is_grad_enabled():
+            with torch.enable_grad():
+                v = ctx.classic(ps, A, trans, frame)
+                ins = [t for t, n in zip((ps, A, trans), need[:3]) if n]
+                gs = list(torch.autograd.grad(v, ins, gd, create_graph=True, allow_unused=True))
+            out = [gs.pop(0) if n else None for n in need[:3]]
+            return out[0], out[1], out[2], None, None, None
+        gd = gd.contiguous()
+        psd = ps.detach().contiguous()
+        g_ps = lbs_vjp_input(psd, frame, A.detach().contiguous(), grid, gd) if need[0] else None
+        gA = gt = None
+        if need[1] or need[2]:
+            gA, gt = lbs_vjp_params(psd, frame, tuple(A.shape), grid, gd)
+        return g_ps, (gA if need[1] else None), (gt if need[2] else None), None, None, None

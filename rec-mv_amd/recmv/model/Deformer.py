@@ -416,8 +416,6 @@ class LBSkinner(nn.Module):
             A = results - init_bone
         else:
             A = _mm4(results, self.init_pose.view(1, 24, 4, 4).expand(batch_size, 24, 4, 4))
-        ps_ws = self.skinning_weights(tps)                                     # [P,24]
-
         if batch_inds is None:
             batch_size2, pnum, _ = ps.shape
             assert (batch_size == batch_size2)
@@ -427,15 +425,28 @@ class LBSkinner(nn.Module):
             flat = ps.reshape(-1, 3)
             assert (batch_inds.numel() == flat.shape[0])
             binds = batch_inds
+        fused = (tps is ps and flat.is_cuda and flat.dtype == torch.float32 and not kwargs.get('jet', False)
+                 and torch.is_grad_enabled() and A.shape[1:] == (24, 4, 4))
+        if fused:
+            # first-order path: one kernel forward, fused VJP kernels backward (csrc/lbs_fused.hip)
+            from ..chains import LbsFused
+            v = LbsFused.apply(flat, A, trans, binds.contiguous(), self._lbs_grid(), self._blend_classic)
+        else:
+            v = self._blend_classic(flat, A, trans, binds, tps=tps)
+        if batch_inds is None:
+            return v.view(batch_size, pnum, 3)
+        return v
+
+    def _blend_classic(self, flat, A, trans, binds, tps=None):
+        """v = T(p) [p;1] + trans with T = sum_j w_j A_j as a composition of differentiable ops (any order)."""
+        batch_size = A.shape[0]
+        ps_ws = self.skinning_weights(flat if tps is None else tps)             # [P,24]
         # T[p] = sum_j w[p,j] * A[b_p, j]  — one MFMA product against every frame, then gather by frame
         Ball = A.reshape(batch_size, 24, 16).permute(0, 2, 1).reshape(batch_size * 16, 24)
         Tall = ops.MatmulNT.apply(ps_ws, Ball).view(-1, batch_size, 16)
         T = Tall.gather(1, binds.view(-1, 1, 1).expand(-1, 1, 16)).view(-1, 4, 4)
         v = (T[:, :3, :3] * flat.unsqueeze(-2)).sum(-1) + T[:, :3, 3]
-        v = v + trans.index_select(0, binds)
-        if batch_inds is None:
-            return v.view(batch_size, pnum, 3)
-        return v
+        return v + trans.index_select(0, binds)
 
     # -- graph-free passes on ray points: fused kernels (csrc/lbs_fused.hip) ----------------------------
     def _lbs_grid(self):

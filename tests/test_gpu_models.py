@@ -316,3 +316,44 @@ def test_translator_and_composite_jet_jacobian(nets):
     close(Jm1, Jm0, rtol=1e-4, atol=1e-5)
     for a, b in zip(gm1, gm0):
         close(a, b, rtol=2e-3, atol=2e-6 + 1e-3 * float(b.abs().max()))
+
+
+def test_lbs_fused_first_order_equals_classic(nets):
+    """LBSkinner.forward's fused first-order path (csrc/lbs_fused.hip: one forward kernel, input-VJP kernel, staged
+    parameter VJP) gives the same output and the same gradients wrt points, poses and translations as the
+    composition of differentiable ops (sampler + blend, model/Deformer.py:405-445)."""
+    gl = load("lbs")
+    sk = nets["sk"]
+    g = torch.Generator().manual_seed(11)
+    p0 = (torch.randn(3, 500, 3, generator=g) * 0.4).to(DEV)
+    wd = torch.randn(3, 500, 3, generator=g).to(DEV)
+
+    def run(jet):
+        poses = gl["poses"].to(DEV).clone().requires_grad_(True)
+        trans = gl["trans"].to(DEV).clone().requires_grad_(True)
+        p = p0.clone().requires_grad_(True)
+        d = sk(p, [poses, trans], jet=jet)          # jet=True selects the classic composition
+        loss = (d * wd).sum() / 500 + d.pow(2).mean()
+        return d, _grads(loss, [p, poses, trans])
+
+    d1, g1 = run(False)
+    d0, g0 = run(True)
+    close(d1, d0, rtol=1e-5, atol=2e-6)
+    for a, b in zip(g1, g0):
+        close(a, b, rtol=1e-3, atol=2e-6 + 1e-4 * float(b.abs().max()))
+    # per-point frame ids in arbitrary order
+    binds = torch.randint(0, 3, (700,), generator=g).to(DEV)
+    q0 = (torch.randn(700, 3, generator=g) * 0.4).to(DEV)
+
+    def run2(jet):
+        poses = gl["poses"].to(DEV).clone().requires_grad_(True)
+        trans = gl["trans"].to(DEV).clone().requires_grad_(True)
+        p = q0.clone().requires_grad_(True)
+        d = sk(p, [poses, trans], binds, jet=jet)
+        return d, _grads(d.pow(2).sum(), [p, poses, trans])
+
+    e1, h1 = run2(False)
+    e0, h0 = run2(True)
+    close(e1, e0, rtol=1e-5, atol=2e-6)
+    for a, b in zip(h1, h0):
+        close(a, b, rtol=1e-3, atol=2e-6 + 1e-4 * float(b.abs().max()))

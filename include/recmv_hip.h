@@ -116,9 +116,11 @@ int recmv_interp2x_boundary3d_backward(const void* grad_output, void* grad_input
  * outside the grid has no vertex and is referenced as -1, as in the reference.
  *
  * Two-phase: recmv_mc_count classifies + scans and returns the sizes through `counts_host`
- * (2 x int32 {n_vertices, n_faces}, HOST pointer, written after an internal stream sync — the same
- * D2H round trip as the reference's cudaMemcpy at CudaKernels.cu:628).  The caller allocates
- * vertices [V,3] f32 and faces [F,3] i64 and calls recmv_mc_emit with the same workspace.
+ * (3 x int32 {n_vertices, n_faces, n_active_segments}, HOST pointer, written after an internal stream sync —
+ * the same D2H round trip as the reference's cudaMemcpy at CudaKernels.cu:628).  The caller allocates
+ * vertices [V,3] f32 and faces [F,3] i64 and calls recmv_mc_emit with the same workspace and n_active_segments
+ * (the number of 64-voxel segments that own a vertex or a triangle; recmv_mc_emit launches one wave per such
+ * segment from the compacted list the scan left in the workspace).
  * recmv_mc_workspace_bytes gives the workspace size for a volume.
  * ---------------------------------------------------------------------------------------------- */
 int64_t recmv_mc_workspace_bytes(int64_t nx, int64_t ny, int64_t nz);
@@ -126,7 +128,7 @@ int recmv_mc_count(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float i
                    void* workspace, int64_t workspace_bytes, int32_t* counts_host, void* stream);
 int recmv_mc_emit(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float iso,
                   float xstep, float ystep, float zstep, float xmin, float ymin, float zmin,
-                  const void* workspace, int64_t workspace_bytes,
+                  const void* workspace, int64_t workspace_bytes, int64_t n_active_segments,
                   float* vertices, int64_t* faces, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

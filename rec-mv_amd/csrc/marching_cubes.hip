@@ -46,7 +46,9 @@ struct McLayout {
   int64_t off_counts; // uint2  [nseg]   (nvert, ntri)
   int64_t off_offs;   // uint2  [nseg]   exclusive prefix
   int64_t off_runsum; // uint2  [nrun]
-  int64_t off_total;  // uint2  [1]
+  int64_t off_runact; // uint32 [nrun]   segments with work in the run
+  int64_t off_active; // int32  [nseg]   compacted list of the segments with work, in segment order
+  int64_t off_total;  // uint32 [3]      {vertices, faces, active segments}
   int64_t bytes;
 };
 
@@ -65,7 +67,9 @@ inline McLayout make_layout(int64_t nx, int64_t ny, int64_t nz) {
   L.off_counts = take(L.nseg * 8);
   L.off_offs = take(L.nseg * 8);
   L.off_runsum = take(L.nrun * 8);
-  L.off_total = take(8);
+  L.off_runact = take(L.nrun * 4);
+  L.off_active = take(L.nseg * 4);
+  L.off_total = take(16);
   L.bytes = o;
   return L;
 }
@@ -138,24 +142,32 @@ __global__ __launch_bounds__(kBlk) void mc_classify_kernel(const float* __restri
                                                            int NZ, float iso, int S, int64_t nseg,
                                                            int64_t nrun, unsigned long long* __restrict__ masks,
                                                            uint2* __restrict__ counts,
-                                                           uint2* __restrict__ runsum) {
+                                                           uint2* __restrict__ runsum,
+                                                           unsigned int* __restrict__ runact) {
   __shared__ unsigned long long tri_lds[256];
-  __shared__ unsigned int blk_v[kWavesPerBlk], blk_t[kWavesPerBlk];
+  __shared__ unsigned int blk_v[kWavesPerBlk], blk_t[kWavesPerBlk], blk_a[kWavesPerBlk];
   tri_lds[threadIdx.x] = kMcTriTable[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
   for (int64_t pb = blockIdx.x; pb < nrun; pb += gridDim.x) {
     const int64_t run = xcd_remap(pb, nrun);
-    unsigned int sum_v = 0, sum_t = 0;
-#pragma unroll 1
+    unsigned int sum_v = 0, sum_t = 0, sum_a = 0;
+    // the run's 4 segments of this wave are loaded back to back (16 coalesced row loads in flight per wave) before
+    // any of them is classified: the kernel is a pure stream over the volume and lives on memory-level parallelism
+    Corners cs[kRun / kWavesPerBlk];
+#pragma unroll
     for (int it = 0; it < kRun / kWavesPerBlk; ++it) {
       const int64_t seg = run * kRun + it * kWavesPerBlk + wave;
-      if (seg >= nseg) break;
-      const int s = (int)(seg % S);
-      const int64_t row = seg / S;
-      const int j = (int)(row % NY), i = (int)(row / NY);
-      const Corners c = load_corners(sdf, NX, NY, NZ, i, j, s * kWave, lane);
+      const int64_t segc = seg < nseg ? seg : nseg - 1;
+      const int64_t row = segc / S;
+      cs[it] = load_corners(sdf, NX, NY, NZ, (int)(row / NY), (int)(row % NY), (int)(segc % S) * kWave, lane);
+    }
+#pragma unroll
+    for (int it = 0; it < kRun / kWavesPerBlk; ++it) {
+      const int64_t seg = run * kRun + it * kWavesPerBlk + wave;
+      if (seg >= nseg) continue;
+      const Corners& c = cs[it];
       const int flag = c.valid ? cube_index(c, iso) : 0;
       const bool in0 = flag & 1;
       const bool ex = c.valid && (in0 != (bool)(flag & 2));    // edge 0: corners 0-1 (+x)
@@ -174,20 +186,24 @@ __global__ __launch_bounds__(kBlk) void mc_classify_kernel(const float* __restri
       }
       sum_v += nv;
       sum_t += ntw;
+      sum_a += (nv | ntw) ? 1u : 0u;
     }
     if (lane == 0) {
       blk_v[wave] = sum_v;
       blk_t[wave] = sum_t;
+      blk_a[wave] = sum_a;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      unsigned int a = 0, b = 0;
+      unsigned int a = 0, b = 0, c = 0;
 #pragma unroll
       for (int w = 0; w < kWavesPerBlk; ++w) {
         a += blk_v[w];
         b += blk_t[w];
+        c += blk_a[w];
       }
       runsum[run] = make_uint2(a, b);
+      runact[run] = c;
     }
     __syncthreads();
   }
@@ -196,83 +212,101 @@ __global__ __launch_bounds__(kBlk) void mc_classify_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------- K2
 // Block q scans segments [q*kScanChunk, (q+1)*kScanChunk).  Its base = sum of runsum[0 .. q*kScanChunk/kRun).
 __global__ __launch_bounds__(kScanBlk) void mc_scan_kernel(const uint2* __restrict__ counts,
-                                                           const uint2* __restrict__ runsum, int64_t nseg,
+                                                           const uint2* __restrict__ runsum,
+                                                           const unsigned int* __restrict__ runact, int64_t nseg,
                                                            int64_t nrun, uint2* __restrict__ offs,
-                                                           uint2* __restrict__ total) {
-  __shared__ unsigned int sh_v[kScanBlk / kWave], sh_t[kScanBlk / kWave];
-  __shared__ unsigned int base_v, base_t;
+                                                           int* __restrict__ active, unsigned int* __restrict__ total) {
+  __shared__ unsigned int sh_v[kScanBlk / kWave], sh_t[kScanBlk / kWave], sh_a[kScanBlk / kWave];
+  __shared__ unsigned int base_v, base_t, base_a;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const int64_t seg0 = (int64_t)blockIdx.x * kScanChunk;
   const int64_t runs_before = seg0 / kRun;  // kScanChunk % kRun == 0
   // (1) base offset: reduce the run sums before this chunk
-  unsigned int av = 0, at = 0;
+  unsigned int av = 0, at = 0, aa = 0;
   for (int64_t r = tid; r < runs_before; r += kScanBlk) {
     const uint2 x = runsum[r];
     av += x.x;
     at += x.y;
+    aa += runact[r];
   }
 #pragma unroll
   for (int o = kWave / 2; o > 0; o >>= 1) {
     av += __shfl_xor(av, o);
     at += __shfl_xor(at, o);
+    aa += __shfl_xor(aa, o);
   }
   if (lane == 0) {
     sh_v[wave] = av;
     sh_t[wave] = at;
+    sh_a[wave] = aa;
   }
   __syncthreads();
   if (tid == 0) {
-    unsigned int a = 0, b = 0;
+    unsigned int a = 0, b = 0, c = 0;
     for (int w = 0; w < kScanBlk / kWave; ++w) {
       a += sh_v[w];
       b += sh_t[w];
+      c += sh_a[w];
     }
     base_v = a;
     base_t = b;
+    base_a = c;
   }
   __syncthreads();
   // (2) scan the chunk: each thread owns 4 consecutive segments
   constexpr int kPer = kScanChunk / kScanBlk;
   uint2 loc[kPer];
-  unsigned int tv = 0, tt = 0;
+  unsigned int tv = 0, tt = 0, ta = 0;
 #pragma unroll
   for (int e = 0; e < kPer; ++e) {
     const int64_t seg = seg0 + (int64_t)tid * kPer + e;
     loc[e] = seg < nseg ? counts[seg] : make_uint2(0, 0);
     tv += loc[e].x;
     tt += loc[e].y;
+    ta += (loc[e].x | loc[e].y) ? 1u : 0u;
   }
-  // inclusive wave scan of (tv, tt)
-  unsigned int iv = tv, itt = tt;
+  // inclusive wave scan of (tv, tt, ta)
+  unsigned int iv = tv, itt = tt, ia = ta;
 #pragma unroll
   for (int o = 1; o < kWave; o <<= 1) {
-    const unsigned int pv = __shfl_up(iv, o), pt = __shfl_up(itt, o);
+    const unsigned int pv = __shfl_up(iv, o), pt = __shfl_up(itt, o), pa = __shfl_up(ia, o);
     if (lane >= o) {
       iv += pv;
       itt += pt;
+      ia += pa;
     }
   }
   __syncthreads();  // base_* consumed below; sh_* reused
   if (lane == kWave - 1) {
     sh_v[wave] = iv;
     sh_t[wave] = itt;
+    sh_a[wave] = ia;
   }
   __syncthreads();
-  unsigned int wv = 0, wt = 0;
+  unsigned int wv = 0, wt = 0, wa = 0;
   for (int w = 0; w < wave; ++w) {
     wv += sh_v[w];
     wt += sh_t[w];
+    wa += sh_a[w];
   }
-  unsigned int ev = base_v + wv + iv - tv, et = base_t + wt + itt - tt;  // exclusive prefix of this thread
+  // exclusive prefixes of this thread
+  unsigned int ev = base_v + wv + iv - tv, et = base_t + wt + itt - tt, ea = base_a + wa + ia - ta;
 #pragma unroll
   for (int e = 0; e < kPer; ++e) {
     const int64_t seg = seg0 + (int64_t)tid * kPer + e;
-    if (seg < nseg) offs[seg] = make_uint2(ev, et);
+    if (seg < nseg) {
+      offs[seg] = make_uint2(ev, et);
+      if (loc[e].x | loc[e].y) active[ea++] = (int)seg;     // compacted, in segment order
+    }
     ev += loc[e].x;
     et += loc[e].y;
   }
-  // (3) grand total from the last block
-  if (blockIdx.x == gridDim.x - 1 && tid == kScanBlk - 1) *total = make_uint2(ev, et);
+  // (3) grand totals from the last block
+  if (blockIdx.x == gridDim.x - 1 && tid == kScanBlk - 1) {
+    total[0] = ev;
+    total[1] = et;
+    total[2] = ea;
+  }
 }
 
 // ------------------------------------------------------------------------------------------- K3
@@ -315,23 +349,38 @@ __global__ __launch_bounds__(kBlk) void mc_emit_kernel(const float* __restrict__
                                                        const uint2* __restrict__ offs, float xstep,
                                                        float ystep, float zstep, float xmin, float ymin,
                                                        float zmin, float* __restrict__ vertices,
-                                                       long long* __restrict__ faces, int64_t nblk_seg) {
+                                                       long long* __restrict__ faces,
+                                                       const int* __restrict__ active, int64_t nactive) {
   __shared__ unsigned long long tri_lds[256];
   tri_lds[threadIdx.x] = kMcTriTable[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & (kWave - 1);
+  // one wave per segment that has work (compacted list built by the scan): no idle waves, no serial skipping
+  const int64_t nblk_seg = (nactive + kWavesPerBlk - 1) / kWavesPerBlk;
   for (int64_t pb = blockIdx.x; pb < nblk_seg; pb += gridDim.x) {
-    const int64_t seg = xcd_remap(pb, nblk_seg) * kWavesPerBlk + threadIdx.x / kWave;
-    if (seg >= nseg) continue;
-    const uint2 cnt = counts[seg];
-    if (cnt.x == 0 && cnt.y == 0) continue;  // wave-uniform
+    const int64_t slot = xcd_remap(pb, nblk_seg) * kWavesPerBlk + threadIdx.x / kWave;
+    if (slot >= nactive) continue;
+    const int64_t seg = active[slot];
     const int s = (int)(seg % S);
     const int64_t row = seg / S;
     const int j = (int)(row % NY), i = (int)(row / NY);
     const int k = s * kWave + lane;
+    // every load of this segment is issued up front (corners, counts, its own and the six neighbour records): they
+    // depend only on `seg`, and a wave that waits for them one after the other is latency-bound
+    const uint2 cnt = counts[seg];
+    const unsigned int toff = offs[seg].y;
     const Corners c = load_corners(sdf, NX, NY, NZ, i, j, s * kWave, lane);
-    const int flag = c.valid ? cube_index(c, iso) : 0;
     const SegRec self = load_rec(masks, offs, nseg, seg, true);
+    const bool i1 = i + 1 < NX, j1 = j + 1 < NY, s1 = s + 1 < S;
+    const int64_t seg10 = seg + (int64_t)NY * S, seg01 = seg + S, seg11 = seg + (int64_t)NY * S + S;
+    const SegRec r10 = load_rec(masks, offs, nseg, seg10, i1);
+    const SegRec r01 = load_rec(masks, offs, nseg, seg01, j1);
+    const SegRec r11 = load_rec(masks, offs, nseg, seg11, i1 && j1);
+    // k+1 of lane 63 lives in the next segment of the same row
+    const SegRec n00 = load_rec(masks, offs, nseg, seg + 1, s1);
+    const SegRec n10 = load_rec(masks, offs, nseg, seg10 + 1, s1 && i1);
+    const SegRec n01 = load_rec(masks, offs, nseg, seg01 + 1, s1 && j1);
+    const int flag = c.valid ? cube_index(c, iso) : 0;
     const unsigned long long bit = 1ull << lane;
 
     // ---- vertices owned by this lattice point (canonical order: dir 0,1,2)
@@ -371,17 +420,9 @@ __global__ __launch_bounds__(kBlk) void mc_emit_kernel(const float* __restrict__
       const int p = __shfl_up(incl, o);
       if (lane >= o) incl += p;
     }
-    long long f = (long long)offs[seg].y + (incl - nt);
-    // records of the lattice rows a triangle corner can live on: (di,dj) in {0,1}^2, segment s or s+1
-    const bool i1 = i + 1 < NX, j1 = j + 1 < NY, s1 = s + 1 < S;
-    const int64_t seg10 = seg + (int64_t)NY * S, seg01 = seg + S, seg11 = seg + (int64_t)NY * S + S;
-    const SegRec r10 = load_rec(masks, offs, nseg, seg10, i1);
-    const SegRec r01 = load_rec(masks, offs, nseg, seg01, j1);
-    const SegRec r11 = load_rec(masks, offs, nseg, seg11, i1 && j1);
-    // k+1 of lane 63 lives in the next segment of the same row
-    const SegRec n00 = load_rec(masks, offs, nseg, seg + 1, s1);
-    const SegRec n10 = load_rec(masks, offs, nseg, seg10 + 1, s1 && i1);
-    const SegRec n01 = load_rec(masks, offs, nseg, seg01 + 1, s1 && j1);
+    long long f = (long long)toff + (incl - nt);
+    // r10/r01/r11/n00/n10/n01: records of the lattice rows a triangle corner can live on, (di,dj) in {0,1}^2,
+    // segment s or s+1 (loaded above)
     if (nt > 0) {
       // edge id -> (di, dj, dk, dir)   (the if/else ladder at CudaKernels.cu:385-456)
       for (int t = 0; t < nt; ++t) {
@@ -447,49 +488,54 @@ extern "C" int recmv_mc_count(const float* sdf, int64_t nx, int64_t ny, int64_t 
   if (rc) return rc;
   RECMV_REQUIRE(counts_host, "mc_count: NULL counts_host");
   hipStream_t s = (hipStream_t)stream;
-  counts_host[0] = counts_host[1] = 0;
+  counts_host[0] = counts_host[1] = counts_host[2] = 0;
   if (L.nseg == 0) return RECMV_OK;
   char* ws = (char*)workspace;
   auto* masks = (unsigned long long*)(ws + L.off_masks);
   auto* counts = (uint2*)(ws + L.off_counts);
   auto* offs = (uint2*)(ws + L.off_offs);
   auto* runsum = (uint2*)(ws + L.off_runsum);
-  auto* total = (uint2*)(ws + L.off_total);
+  auto* runact = (unsigned int*)(ws + L.off_runact);
+  auto* active = (int*)(ws + L.off_active);
+  auto* total = (unsigned int*)(ws + L.off_total);
   const int g1 = (int)(L.nrun < 4096 ? L.nrun : 4096);
   hipLaunchKernelGGL(mc_classify_kernel, dim3(g1), dim3(kBlk), 0, s, sdf, (int)nx, (int)ny, (int)nz, iso,
-                     L.S, L.nseg, L.nrun, masks, counts, runsum);
+                     L.S, L.nseg, L.nrun, masks, counts, runsum, runact);
   rc = check_launch("mc_classify");
   if (rc) return rc;
   const int g2 = (int)ceil_div(L.nseg, kScanChunk);
-  hipLaunchKernelGGL(mc_scan_kernel, dim3(g2), dim3(kScanBlk), 0, s, counts, runsum, L.nseg, L.nrun, offs,
-                     total);
+  hipLaunchKernelGGL(mc_scan_kernel, dim3(g2), dim3(kScanBlk), 0, s, counts, runsum, runact, L.nseg, L.nrun, offs,
+                     active, total);
   rc = check_launch("mc_scan");
   if (rc) return rc;
-  uint32_t host[2] = {0, 0};
-  RECMV_HIP_TRY(hipMemcpyAsync(host, total, 8, hipMemcpyDeviceToHost, s));
+  uint32_t host[3] = {0, 0, 0};
+  RECMV_HIP_TRY(hipMemcpyAsync(host, total, 12, hipMemcpyDeviceToHost, s));
   RECMV_HIP_TRY(hipStreamSynchronize(s));
   counts_host[0] = (int32_t)host[0];
   counts_host[1] = (int32_t)host[1];
+  counts_host[2] = (int32_t)host[2];
   return RECMV_OK;
 }
 
 extern "C" int recmv_mc_emit(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float iso, float xstep,
                              float ystep, float zstep, float xmin, float ymin, float zmin,
-                             const void* workspace, int64_t workspace_bytes, float* vertices,
-                             int64_t* faces, void* stream) {
+                             const void* workspace, int64_t workspace_bytes, int64_t n_active_segments,
+                             float* vertices, int64_t* faces, void* stream) {
   McLayout L;
   int rc = mc_check("mc_emit", sdf, nx, ny, nz, workspace, workspace_bytes, &L);
   if (rc) return rc;
-  if (L.nseg == 0) return RECMV_OK;
+  if (L.nseg == 0 || n_active_segments <= 0) return RECMV_OK;
+  RECMV_REQUIRE(n_active_segments <= L.nseg, "mc_emit: n_active_segments out of range");
   hipStream_t s = (hipStream_t)stream;
   const char* ws = (const char*)workspace;
   auto* masks = (const unsigned long long*)(ws + L.off_masks);
   auto* counts = (const uint2*)(ws + L.off_counts);
   auto* offs = (const uint2*)(ws + L.off_offs);
-  const int64_t nblk_seg = ceil_div(L.nseg, kWavesPerBlk);
-  const int g3 = (int)(nblk_seg < 8192 ? nblk_seg : 8192);
+  auto* active = (const int*)(ws + L.off_active);
+  const int64_t nblk_seg = ceil_div(n_active_segments, kWavesPerBlk);
+  const int g3 = (int)(nblk_seg < 16384 ? nblk_seg : 16384);
   hipLaunchKernelGGL(mc_emit_kernel, dim3(g3), dim3(kBlk), 0, s, sdf, (int)nx, (int)ny, (int)nz, iso, L.S,
                      L.nseg, masks, counts, offs, xstep, ystep, zstep, xmin, ymin, zmin, vertices,
-                     (long long*)faces, nblk_seg);
+                     (long long*)faces, active, n_active_segments);
   return check_launch("mc_emit");
 }

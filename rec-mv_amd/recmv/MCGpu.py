@@ -42,7 +42,7 @@ def mc_gpu(sdfs, xstep=1.0, ystep=1.0, zstep=1.0, xmin=0.0, ymin=0.0, zmin=0.0, 
     with torch.cuda.device(sdfs.device):
         nbytes = lib.recmv_mc_workspace_bytes(nx, ny, nz)
         ws = _workspace(sdfs.device, max(int(nbytes), 256))
-        counts = (C.c_int32 * 2)(0, 0)
+        counts = (C.c_int32 * 3)(0, 0, 0)
         st = L.stream_ptr(sdfs.device)
         L.check(lib.recmv_mc_count(L.ptr(sdfs), nx, ny, nz, float(fTargetValue), L.ptr(ws), ws.numel(),
                                    C.cast(counts, C.c_void_p), st), "mc_gpu/count")
@@ -52,5 +52,5 @@ def mc_gpu(sdfs, xstep=1.0, ystep=1.0, zstep=1.0, xmin=0.0, ymin=0.0, zmin=0.0, 
         if V > 0 or F > 0:
             L.check(lib.recmv_mc_emit(L.ptr(sdfs), nx, ny, nz, float(fTargetValue), float(xstep), float(ystep),
                                       float(zstep), float(xmin), float(ymin), float(zmin), L.ptr(ws), ws.numel(),
-                                      L.ptr(vertices), L.ptr(faces), st), "mc_gpu/emit")
+                                      int(counts[2]), L.ptr(vertices), L.ptr(faces), st), "mc_gpu/emit")
     return [vertices, faces]

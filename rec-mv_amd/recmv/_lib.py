@@ -73,7 +73,7 @@ def _declare(lib):
         "recmv_interp2x_boundary3d_backward": (C.c_int, [vp, vp, i64, i64, i64, i64, i32, vp]),
         "recmv_mc_workspace_bytes": (i64, [i64, i64, i64]),
         "recmv_mc_count": (C.c_int, [vp, i64, i64, i64, f32, vp, i64, vp, vp]),
-        "recmv_mc_emit": (C.c_int, [vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, f32, vp, i64, vp, vp, vp]),
+        "recmv_mc_emit": (C.c_int, [vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, f32, vp, i64, i64, vp, vp, vp]),
         "recmv_gemm_nt": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, f32, f32, vp]),
         "recmv_gemm_nt_actgrad": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, f32, f32, f32, vp]),
         "recmv_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),

@@ -76,6 +76,16 @@ def bench_sampler(quick):
         ggG = torch.randn(1, 1, 1, P, 3, device=DEV)
         t, b = timeit(lambda: GridSamplerMine.dbackward(None, ggG, vol_cl, grid, go, 0, 1, need_grad_input=False))
         report(f"grid_sample_dbwd(ggI none) P={P}", t, b, nbytes=P * (12 + 12 + 4 * C + 12 + 4 * C) + touched)
+        # surface-coherent points (what the loop samples: MC vertices in lattice order): neighbours share corner records
+        n = int(round(P ** 0.5))
+        u, v = torch.meshgrid(torch.linspace(-0.9, 0.9, n, device=DEV), torch.linspace(-0.9, 0.9, n, device=DEV),
+                              indexing="ij")
+        surf = torch.stack([u, v, 0.3 * torch.sin(3 * u) * torch.cos(2 * v)], -1).view(1, 1, 1, -1, 3).contiguous()
+        Pc = surf.shape[3]
+        touched_c = min(4 * C * D * H * W, 32 * C * Pc)
+        t, b = timeit(lambda: GridSamplerMine.forward(vol_cl, surf, 0, 1))
+        report(f"grid_sample_fwd channels_last, surface-coherent P={Pc}", t, b, nbytes=Pc * (12 + 4 * C),
+               note="bytes = coordinates + output only (the touched records are shared between neighbours)")
         if P <= 153600:
             t, b = timeit(lambda: GridSamplerMine.backward(vol, grid, go, 0, 1, need_grad_input=True), iters=5)
             report(f"grid_sample_bwd(full, reference behaviour) P={P}", t, b,
@@ -113,7 +123,7 @@ def bench_mc(quick):
         # split: count phase (classify + scan + D2H) and emit phase
         lib = L.lib()
         ws = torch.empty(int(lib.recmv_mc_workspace_bytes(n, n, n)), dtype=torch.uint8, device=DEV)
-        counts = (C.c_int32 * 2)(0, 0)
+        counts = (C.c_int32 * 3)(0, 0, 0)
         st = L.stream_ptr(vol.device)
         t, b = timeit(lambda: lib.recmv_mc_count(L.ptr(vol), n, n, n, 0.0, L.ptr(ws), ws.numel(),
                                                  C.cast(counts, C.c_void_p), st))
@@ -121,7 +131,7 @@ def bench_mc(quick):
         verts = torch.empty(V, 3, device=DEV)
         faces = torch.empty(Fc, 3, dtype=torch.int64, device=DEV)
         t, b = timeit(lambda: lib.recmv_mc_emit(L.ptr(vol), n, n, n, 0.0, step, step, step, -1.0, -1.0, -1.0,
-                                                L.ptr(ws), ws.numel(), L.ptr(verts), L.ptr(faces), st))
+                                                L.ptr(ws), ws.numel(), int(counts[2]), L.ptr(verts), L.ptr(faces), st))
         report(f"mc_emit {n}^3", t, b, nbytes=12 * V + 24 * Fc)
 
 

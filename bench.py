@@ -196,6 +196,11 @@ def main():
     ap.add_argument("--stage", default="coarse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
+    ap.add_argument("--gemm-mode", choices=["f32", "bf16x6"], default="f32",
+                    help="matrix mode of the timed region: f32 = f32-input MFMA (exact f32 products, default); bf16x6 = "
+                         "3-way bf16 operand split, six bf16 MFMA products, f32 accumulate (same parity tolerances)")
+    ap.add_argument("--no-alt-mode", action="store_true",
+                    help="skip the short extra measurement in the other matrix mode (reported as `alt_mode`)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the MFMA kernel launches with HIP events (no roofline object)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -222,6 +227,9 @@ def main():
     allreduce = rdist.GradAllReduce(world) if world > 1 else None
 
     log("loop built")
+    from recmv import _lib as L
+    mode_id = {"f32": 0, "bf16x6": 1}
+    L.lib().recmv_set_gemm_mode(mode_id[args.gemm_mode])
     it = 0
     for _ in range(args.warmup):
         loop.step(it, allreduce)
@@ -247,6 +255,32 @@ def main():
     rdist.barrier()
     elapsed = time.perf_counter() - t0
     gs = prof.end() if prof else {}
+    alt = None
+    if not args.no_alt_mode:
+        # the same loop in the OTHER matrix mode, a short extra run outside the timed region (not part of `value`)
+        other = "bf16x6" if args.gemm_mode == "f32" else "f32"
+        L.lib().recmv_set_gemm_mode(mode_id[other])
+        n_alt = max(2, min(10, args.steps))
+        for _ in range(1):
+            loop.step(it, allreduce)
+            it += 1
+        rdist.barrier()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(n_alt):
+            loop.step(it, allreduce)
+            it += 1
+        torch.cuda.synchronize()
+        rdist.barrier()
+        alt_elapsed = time.perf_counter() - ta
+        L.lib().recmv_set_gemm_mode(mode_id[args.gemm_mode])
+        if world > 1:
+            ta_t = torch.tensor([alt_elapsed], device=device, dtype=torch.float64)
+            tdist.all_reduce(ta_t, op=tdist.ReduceOp.MAX)
+            alt_elapsed = float(ta_t[0])
+        alt = dict(gemm_mode=other, steps=n_alt, value=round(n_alt * world / alt_elapsed, 4), unit="iters/s",
+                   ms_per_step=round(alt_elapsed / n_alt * 1e3, 3),
+                   note="same loop, other matrix mode, short run after the timed region (no re-mesh inside)")
     if world > 1:
         t = torch.tensor([elapsed, float(rays)], device=device, dtype=torch.float64)
         tmax = t.clone()
@@ -269,6 +303,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "gemm_mode": args.gemm_mode + (" (f32-input MFMA: exact f32 products)" if args.gemm_mode == "f32" else
+                                           " (f32 operands split into 3 bf16 pieces, 6 bf16 MFMA products, f32 "
+                                           "accumulate; same parity tolerances as f32)"),
             "data": "synthetic",
             "rays_per_sec": round(rays / elapsed, 1),
             "config": {
@@ -287,7 +324,8 @@ def main():
             dom = max(gs, key=lambda k: gs[k]["seconds"])
             g = gs[dom]
             ach = g["flops"] / g["seconds"]
-            line["roofline"] = {"kernel": "recmv::" + dom + " (f32-MFMA layer: GEMM + bias + activation epilogue)",
+            line["roofline"] = {"kernel": "recmv::" + dom + " (MFMA layer: GEMM + bias + activation epilogue; matrix mode " +
+                                          args.gemm_mode + ")",
                                 "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": MFMA_F32_PEAK / 1e12,
                                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), "traffic": None,
                                 "launches": g["launches"], "avg_launch_us": round(g["avg_us"], 2),
@@ -297,6 +335,8 @@ def main():
                                                        "achieved": round(v["flops"] / v["seconds"] / 1e12, 3)}
                                                    for k, v in gs.items() if k != dom},
                                 "untimed_small_launches": prof.small}
+        if alt:
+            line["alt_mode"] = alt
         log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
         if getattr(loop, "phase_ms", None):
             log("phase ms (RECMV_TIMING=1, timed steps only): " + json.dumps({k: round(v, 1) for k, v in loop.phase_ms.items()}))

@@ -27,6 +27,40 @@ namespace recmv {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- 3-way bf16 split of f32 operands (optional matrix mode "bf16x6") ------------------------------------------
+// x = h + m + l exactly, each piece a bf16 (round-to-nearest at every step: |m| <= 2^-9 |x|, |l| <= 2^-17 |x|).
+// A product x*y is then formed from the six piece products of weight >= 2^-18 (hh, hm, mh, hl, lh, mm) on the bf16
+// matrix pipe (16x the f32 matrix rate) with f32 accumulation; the dropped products are <= 2^-25 relative, below
+// f32 rounding.  Each piece product is exact in f32, so the result differs from the f32 MFMA only by the order of
+// the f32 accumulation.
+struct Pieces {
+  bf16x8 h, m, l;
+};
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const f32x2 v = {x0, x1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 r = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u)};
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  const f32x2 q = {r.x - __uint_as_float(m << 16), r.y - __uint_as_float(m & 0xffff0000u)};
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
+}
+__device__ __forceinline__ Pieces split8(float4 a, float4 b) {
+  unsigned h[4], m[4], l[4];
+  split2(a.x, a.y, h[0], m[0], l[0]);
+  split2(a.z, a.w, h[1], m[1], l[1]);
+  split2(b.x, b.y, h[2], m[2], l[2]);
+  split2(b.z, b.w, h[3], m[3], l[3]);
+  Pieces p;
+  p.h = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
+  p.m = __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]});
+  p.l = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+  return p;
+}
 
 constexpr int BM = 128, BN = 128, BK = 32;   // large tile (and the TN kernel's tile)
 constexpr int kBlk = 256;
@@ -158,7 +192,7 @@ __device__ __forceinline__ void nt_epilogue(const float* __restrict__ Cs, const 
   }
 }
 
-template <int T, bool FAST, bool AMUL>
+template <int T, bool FAST, bool AMUL, bool BF3>
 __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ B, int64_t ldb,
                                                        const float* __restrict__ bias, float* __restrict__ C,
@@ -240,6 +274,34 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
+    if (BF3) {
+      // bf16x6: per 16-column step every lane converts its 8 consecutive k of each operand row into three bf16
+      // pieces (registers only; LDS still holds f32) and issues six bf16 MFMAs per 32x32 tile, small terms first
+      const float* as = As + (buf * TBM + arow) * LDK + 2 * khalf;
+      const float* bs = Bs + (buf * TBN + brow) * LDK + 2 * khalf;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        Pieces pa[T], pb[T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+          const float* ap = as + i * 32 * LDK + ks * 16;
+          const float* bp = bs + i * 32 * LDK + ks * 16;
+          pa[i] = split8(*reinterpret_cast<const float4*>(ap), *reinterpret_cast<const float4*>(ap + 4));
+          pb[i] = split8(*reinterpret_cast<const float4*>(bp), *reinterpret_cast<const float4*>(bp + 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < T; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < T; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].h, pb[ni].l, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].l, pb[ni].h, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].m, pb[ni].m, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].h, pb[ni].m, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].m, pb[ni].h, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].h, pb[ni].h, acc[mi][ni], 0, 0, 0);
+          }
+      }
+    } else {
     const float* as = As + (buf * TBM + arow) * LDK + khalf;
     const float* bs = Bs + (buf * TBN + brow) * LDK + khalf;
 #pragma unroll
@@ -259,6 +321,7 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
         }
+    }
     }
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
@@ -295,6 +358,7 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------ TN
 // partial[split][M][N] = sum over k in the split's range of A[k][m]*B[k][n]
+template <bool BF3>
 __global__ __launch_bounds__(kBlk) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ B, int64_t ldb,
                                                        float* __restrict__ P, int M, int N, int64_t K, int nbm,
@@ -353,6 +417,35 @@ __global__ __launch_bounds__(kBlk) void gemm_tn_kernel(const float* __restrict__
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload(kbeg + (int64_t)(kt + 1) * BK);
+    if (BF3) {
+      // bf16x6 (see split2): a lane's 8 consecutive k of column m are 8 rows of the k-major LDS tile
+      const float* as = As + (buf * BK + 8 * kh) * LDM + acol;
+      const float* bs = Bs + (buf * BK + 8 * kh) * LDM + bcol;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        Pieces pa[2], pb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float* ap = as + ks * 16 * LDM + 32 * i;
+          const float* bp = bs + ks * 16 * LDM + 32 * i;
+          pa[i] = split8(make_float4(ap[0], ap[LDM], ap[2 * LDM], ap[3 * LDM]),
+                         make_float4(ap[4 * LDM], ap[5 * LDM], ap[6 * LDM], ap[7 * LDM]));
+          pb[i] = split8(make_float4(bp[0], bp[LDM], bp[2 * LDM], bp[3 * LDM]),
+                         make_float4(bp[4 * LDM], bp[5 * LDM], bp[6 * LDM], bp[7 * LDM]));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].h, pb[ni].l, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].l, pb[ni].h, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].m, pb[ni].m, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].h, pb[ni].m, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].m, pb[ni].h, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[mi].h, pb[ni].h, acc[mi][ni], 0, 0, 0);
+          }
+      }
+    } else {
     const float* as = As + (buf * BK + kh) * LDM + acol;
     const float* bs = Bs + (buf * BK + kh) * LDM + bcol;
 #pragma unroll
@@ -363,6 +456,7 @@ __global__ __launch_bounds__(kBlk) void gemm_tn_kernel(const float* __restrict__
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
     }
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
@@ -510,20 +604,22 @@ int tn_splits(int64_t M, int64_t N, int64_t K) {
 
 using namespace recmv;
 
-template <int T, bool FAST, bool AMUL>
+int g_gemm_mode = 0;     // 0: f32 MFMA (exact f32 products), 1: bf16x6 (3-way bf16 split, six bf16 MFMA products)
+
+template <int T, bool FAST, bool AMUL, bool BF3>
 static int launch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
                      int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
                      bool a_vec, bool b_vec, bool c_vec, const AMul& am, hipStream_t stream) {
   constexpr int lds = kNtLds / (T == 2 ? 1 : 2);
   static bool attr_set = false;
   if (!attr_set) {
-    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, FAST, AMUL>,
+    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<T, FAST, AMUL, BF3>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   const int nbm = (int)ceil_div(M, 64 * T), nbn = (int)ceil_div(N, 64 * T);
   ScopedLaunchTimer timer((T - 1) + 2 * (FAST ? 1 : 0) + 4 * (AMUL ? 1 : 0), 2.0 * M * N * K, stream);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, FAST, AMUL>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds, stream, A,
+  hipLaunchKernelGGL((gemm_nt_kernel<T, FAST, AMUL, BF3>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds, stream, A,
                      lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, a_vec,
                      b_vec, c_vec, am);
   return check_launch("gemm_nt");
@@ -539,16 +635,23 @@ static int dispatch_nt(const float* A, int64_t lda, const float* B, int64_t ldb,
   const bool fast = a_vec && b_vec && K % 4 == 0 && K > 0;
   // tile choice: 128x128 tiles unless they would leave the 256 CUs under-filled (< 2 workgroups per CU)
   const int64_t big_blocks = ceil_div(M, BM) * ceil_div(N, BN);
-  if (big_blocks >= 2 * kNumCU) {
-    return fast ? launch_nt<2, true, AMUL>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec,
-                                           b_vec, c_vec, am, s)
-                : launch_nt<2, false, AMUL>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec,
-                                            b_vec, c_vec, am, s);
-  }
-  return fast ? launch_nt<1, true, AMUL>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec, b_vec,
-                                         c_vec, am, s)
-              : launch_nt<1, false, AMUL>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, a_vec,
-                                          b_vec, c_vec, am, s);
+#define RECMV_NT(TT, FF)                                                                                          \
+  (g_gemm_mode == 1 ? launch_nt<TT, FF, AMUL, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, \
+                                                    a_vec, b_vec, c_vec, am, s)                                    \
+                    : launch_nt<TT, FF, AMUL, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param,        \
+                                                     out_scale, a_vec, b_vec, c_vec, am, s))
+  if (big_blocks >= 2 * kNumCU) return fast ? RECMV_NT(2, true) : RECMV_NT(2, false);
+  return fast ? RECMV_NT(1, true) : RECMV_NT(1, false);
+#undef RECMV_NT
+}
+
+// Matrix mode of recmv_gemm_nt: 0 = f32-input MFMA (default; bit-for-bit an f32 fma chain), 1 = "bf16x6" (each f32
+// operand split into three bf16 pieces in registers, six bf16 MFMA products per tile step, f32 accumulation: f32-level
+// accuracy at up to 2.7x the f32 matrix rate).  Returns the previous mode.
+extern "C" int recmv_set_gemm_mode(int mode) {
+  const int prev = g_gemm_mode;
+  if (mode == 0 || mode == 1) g_gemm_mode = mode;
+  return prev;
 }
 
 extern "C" int recmv_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
@@ -606,7 +709,9 @@ extern "C" int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_
   }
   static bool attr_set = false;
   if (!attr_set) {
-    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kTnLds));
+    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kTnLds));
     attr_set = true;
   }
@@ -614,8 +719,12 @@ extern "C" int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_
   int64_t kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
   const bool a_vec = aligned16(A) && lda % 4 == 0, b_vec = aligned16(B) && ldb % 4 == 0;
   ScopedLaunchTimer timer(8, 2.0 * M * N * K, s);
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(nbm * nbn * splits)), dim3(kBlk), kTnLds, s, A, lda, B, ldb,
-                     (float*)workspace, (int)M, (int)N, K, nbm, nbn, kchunk, a_vec, b_vec);
+  if (g_gemm_mode == 1)
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)(nbm * nbn * splits)), dim3(kBlk), kTnLds, s, A, lda, B,
+                       ldb, (float*)workspace, (int)M, (int)N, K, nbm, nbn, kchunk, a_vec, b_vec);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3((unsigned)(nbm * nbn * splits)), dim3(kBlk), kTnLds, s, A, lda, B,
+                       ldb, (float*)workspace, (int)M, (int)N, K, nbm, nbn, kchunk, a_vec, b_vec);
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stream_grid(M * N, kBlk)), dim3(kBlk), 0, s,

@@ -76,6 +76,7 @@ def _declare(lib):
         "recmv_mc_emit": (C.c_int, [vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, f32, vp, i64, i64, vp, vp, vp]),
         "recmv_gemm_nt": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, f32, f32, vp]),
         "recmv_gemm_nt_actgrad": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, f32, f32, f32, vp]),
+        "recmv_set_gemm_mode": (C.c_int, [i32]),
         "recmv_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),
         "recmv_gemm_tn": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
         "recmv_posenc_forward": (C.c_int, [vp, i64, vp, i64, i64, i64, i32, vp, f32, vp]),
@@ -127,6 +128,8 @@ def lib():
                               "the recmv ops have no CPU fallback")
         l = C.CDLL(str(LIB_PATH))
         _declare(l)
+        if os.environ.get("RECMV_GEMM_MODE"):
+            l.recmv_set_gemm_mode(int(os.environ["RECMV_GEMM_MODE"]))
         _lib = l
     return _lib
 

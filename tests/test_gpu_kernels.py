@@ -421,3 +421,42 @@ def test_singular_values_closed_form():
     s = singular_values_3x3(J)
     ref = torch.linalg.svdvals(J.cpu().double()).float()
     torch.testing.assert_close(s.cpu(), ref, rtol=2e-3, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------ matrix mode bf16x6
+@pytest.fixture
+def bf16x6_mode():
+    """Switch librecmv_hip.so to the 3-way-bf16-split matrix mode for one test (recmv_set_gemm_mode)."""
+    from recmv import _lib as L
+    prev = L.lib().recmv_set_gemm_mode(1)
+    try:
+        yield
+    finally:
+        L.lib().recmv_set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 3, 39), (300, 473, 512), (4096, 512, 512), (129, 130, 167), (20000, 512, 512)])
+def test_gemm_nt_bf16x6_same_bound_as_f32(bf16x6_mode, M, N, K):
+    """The six-product bf16 split meets the SAME error bound vs fp64 as the exact-f32 MFMA path."""
+    from recmv import ops
+    g = torch.Generator().manual_seed(M + 3 * N)
+    A = torch.randn(M, K, generator=g) * torch.logspace(-3, 2, M).view(-1, 1)      # rows over 5 decades
+    B = torch.randn(N, K, generator=g) / np.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ B.double().t() + bias.double()
+    out = ops.gemm_nt(gpu(A), gpu(B), gpu(bias))
+    bound = 4e-7 * (A.abs().double() @ B.abs().double().t()) + 1e-6
+    assert ((out.cpu().double() - ref).abs() <= bound).all()
+
+
+@pytest.mark.parametrize("K,M,N", [(33, 5, 3), (5000, 473, 512), (150000, 512, 512)])
+def test_gemm_tn_bf16x6_same_bound_as_f32(bf16x6_mode, K, M, N):
+    from recmv import ops
+    g = torch.Generator().manual_seed(K + M)
+    A = torch.randn(K, M, generator=g)
+    B = torch.randn(K, N, generator=g)
+    ref = A.double().t() @ B.double()
+    out = ops.gemm_tn(gpu(A), gpu(B))
+    bound = 4e-7 * (A.abs().double().t() @ B.abs().double()) + 1e-6
+    assert ((out.cpu().double() - ref).abs() <= bound).all()
+    assert torch.equal(out, ops.gemm_tn(gpu(A), gpu(B)))

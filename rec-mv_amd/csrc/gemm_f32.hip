@@ -356,6 +356,181 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------ NT, narrow tile
+// 64x32 workgroup tile for launches too small to give every CU three 64x64 workgroups (the ray path: M = 3072 rows
+// against N = 512 is 384 tiles of 64x64 — 1.5 per CU, so half the CUs carry twice the work of the others — but 768
+// tiles of 64x32 = 3 per CU).  The 4 waves are 2 (row halves) x 2 (halves of every K-tile): each wave owns one 32x32
+// MFMA tile over half of K, the two K-halves are summed through LDS before the epilogue.
+template <bool FAST, bool AMUL, bool BF3>
+__global__ __launch_bounds__(kBlk) void gemm_nt_narrow_kernel(const float* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ B, int64_t ldb,
+                                                              const float* __restrict__ bias, float* __restrict__ C,
+                                                              int64_t ldc, int M, int N, int K, int act,
+                                                              float act_param, float out_scale, int nbm, int nbn,
+                                                              bool a_vec, bool b_vec, bool c_vec, AMul am) {
+  constexpr int TBM = 64, TBN = 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                        // [2][64][LDK]
+  float* Bs = smem + 2 * TBM * LDK;        // [2][32][LDK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wk = wave >> 1;
+  const int64_t logical = xcd_remap(blockIdx.x, (int64_t)nbm * nbn);
+  const int tile_m = (int)(logical / nbn), tile_n = (int)(logical % nbn);
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // staging: A 64 rows x 8 float4 (2 per thread), B 32 rows x 8 float4 (1 per thread)
+  float4 ra[2], rb;
+  const float* pa[2];
+  const float* pb;
+  const float* py[2];
+  const int brow_s = tid >> 3, c4s = tid & 7;
+  if (FAST) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      int gm = m0 + brow_s + 32 * r;
+      gm = gm < M ? gm : M - 1;
+      pa[r] = A + (int64_t)gm * lda + c4s * 4;
+      if (AMUL) py[r] = am.Y + (int64_t)gm * am.ldy + c4s * 4;
+    }
+    int gn = n0 + brow_s;
+    gn = gn < N ? gn : N - 1;
+    pb = B + (int64_t)gn * ldb + c4s * 4;
+  }
+  auto gload = [&](int k0) {
+    const int k = k0 + c4s * 4;
+    if (FAST) {
+      const bool in = k < K;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        ra[r] = in ? *reinterpret_cast<const float4*>(pa[r] + k0) : make_float4(0, 0, 0, 0);
+        if (AMUL && in) ra[r] = amul4(ra[r], *reinterpret_cast<const float4*>(py[r] + k0), am);
+      }
+      rb = in ? *reinterpret_cast<const float4*>(pb + k0) : make_float4(0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int gm = m0 + brow_s + 32 * r;
+        ra[r] = (gm < M) ? load4_guard(A + (int64_t)gm * lda + k, K - k, a_vec) : make_float4(0, 0, 0, 0);
+        if (AMUL && gm < M) ra[r] = amul4(ra[r], load4_guard(am.Y + (int64_t)gm * am.ldy + k, K - k, false), am);
+      }
+      const int gn = n0 + brow_s;
+      rb = (gn < N) ? load4_guard(B + (int64_t)gn * ldb + k, K - k, b_vec) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      *reinterpret_cast<float4*>(As + (buf * TBM + brow_s + 32 * r) * LDK + c4s * 4) = ra[r];
+    *reinterpret_cast<float4*>(Bs + (buf * TBN + brow_s) * LDK + c4s * 4) = rb;
+  };
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int arow = wm * 32 + (lane & 31), brow = lane & 31, khalf = (lane >> 5) * 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if (BF3) {
+      const float* ap = As + (buf * TBM + arow) * LDK + 2 * khalf + wk * 16;
+      const float* bp = Bs + (buf * TBN + brow) * LDK + 2 * khalf + wk * 16;
+      const Pieces a = split8(*reinterpret_cast<const float4*>(ap), *reinterpret_cast<const float4*>(ap + 4));
+      const Pieces b = split8(*reinterpret_cast<const float4*>(bp), *reinterpret_cast<const float4*>(bp + 4));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+    } else {
+      const float* as = As + (buf * TBM + arow) * LDK + khalf + wk * 16;
+      const float* bs = Bs + (buf * TBN + brow) * LDK + khalf + wk * 16;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const float4 a = *reinterpret_cast<const float4*>(as + kk * 8);
+        const float4 b = *reinterpret_cast<const float4*>(bs + kk * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // the two K-halves -> two LDS planes [64][LDC]; the epilogue adds them
+  constexpr int LDC = TBN + 4;
+  float* Cs = smem;                        // [2][64][LDC] = 18.4 KB <= the operand buffers
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    Cs[(wk * TBM + row) * LDC + (lane & 31)] = acc[r];
+  }
+  __syncthreads();
+  const int c4 = tid & 7, r0 = tid >> 3;   // 8 float4 strips per row, 32 rows per pass
+  const int gn = n0 + c4 * 4;
+  if (gn >= N) return;
+  const float inv_p = act_param != 0.f ? 1.f / act_param : 0.f;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) {
+    bv.x = bias[gn];
+    if (gn + 1 < N) bv.y = bias[gn + 1];
+    if (gn + 2 < N) bv.z = bias[gn + 2];
+    if (gn + 3 < N) bv.w = bias[gn + 3];
+  }
+  const bool full4 = c_vec && gn + 4 <= N;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int row = r0 + 32 * pass;
+    const int gm = m0 + row;
+    if (gm >= M) break;
+    const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
+    const float4 v1 = *reinterpret_cast<const float4*>(Cs + (TBM + row) * LDC + c4 * 4);
+    float4 v = make_float4(v0.x + v1.x + bv.x, v0.y + v1.y + bv.y, v0.z + v1.z + bv.z, v0.w + v1.w + bv.w);
+    switch (act) {
+      case RECMV_ACT_RELU:
+        v.x = apply_act<RECMV_ACT_RELU>(v.x, act_param, inv_p);
+        v.y = apply_act<RECMV_ACT_RELU>(v.y, act_param, inv_p);
+        v.z = apply_act<RECMV_ACT_RELU>(v.z, act_param, inv_p);
+        v.w = apply_act<RECMV_ACT_RELU>(v.w, act_param, inv_p);
+        break;
+      case RECMV_ACT_SOFTPLUS:
+        v.x = apply_act<RECMV_ACT_SOFTPLUS>(v.x, act_param, inv_p);
+        v.y = apply_act<RECMV_ACT_SOFTPLUS>(v.y, act_param, inv_p);
+        v.z = apply_act<RECMV_ACT_SOFTPLUS>(v.z, act_param, inv_p);
+        v.w = apply_act<RECMV_ACT_SOFTPLUS>(v.w, act_param, inv_p);
+        break;
+      case RECMV_ACT_TANH:
+        v.x = apply_act<RECMV_ACT_TANH>(v.x, act_param, inv_p);
+        v.y = apply_act<RECMV_ACT_TANH>(v.y, act_param, inv_p);
+        v.z = apply_act<RECMV_ACT_TANH>(v.z, act_param, inv_p);
+        v.w = apply_act<RECMV_ACT_TANH>(v.w, act_param, inv_p);
+        break;
+      default:
+        break;
+    }
+    v.x *= out_scale;
+    v.y *= out_scale;
+    v.z *= out_scale;
+    v.w *= out_scale;
+    float* dst = C + (int64_t)gm * ldc + gn;
+    if (full4) {
+      *reinterpret_cast<float4*>(dst) = v;
+    } else {
+      dst[0] = v.x;
+      if (gn + 1 < N) dst[1] = v.y;
+      if (gn + 2 < N) dst[2] = v.z;
+      if (gn + 3 < N) dst[3] = v.w;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ TN
 // partial[split][M][N] = sum over k in the split's range of A[k][m]*B[k][n]
 template <bool BF3>
@@ -625,6 +800,20 @@ static int launch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, c
   return check_launch("gemm_nt");
 }
 
+constexpr int kNarrowLds = 2 * (64 + 32) * LDK * 4;   // 27648 B
+
+template <bool FAST, bool AMUL, bool BF3>
+static int launch_nt_narrow(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
+                            int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
+                            bool a_vec, bool b_vec, bool c_vec, const AMul& am, hipStream_t stream) {
+  const int nbm = (int)ceil_div(M, 64), nbn = (int)ceil_div(N, 32);
+  ScopedLaunchTimer timer(2 * (FAST ? 1 : 0) + 4 * (AMUL ? 1 : 0), 2.0 * M * N * K, stream);
+  hipLaunchKernelGGL((gemm_nt_narrow_kernel<FAST, AMUL, BF3>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk),
+                     kNarrowLds, stream, A, lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale,
+                     nbm, nbn, a_vec, b_vec, c_vec, am);
+  return check_launch("gemm_nt(narrow)");
+}
+
 template <bool AMUL>
 static int dispatch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
                        int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
@@ -641,6 +830,17 @@ static int dispatch_nt(const float* A, int64_t lda, const float* B, int64_t ldb,
                     : launch_nt<TT, FF, AMUL, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param,        \
                                                      out_scale, a_vec, b_vec, c_vec, am, s))
   if (big_blocks >= 2 * kNumCU) return fast ? RECMV_NT(2, true) : RECMV_NT(2, false);
+  // 64x64 tiles unless they would give the CUs fewer than ~2.5 workgroups each: then 64x32 tiles (twice as many)
+  const int64_t mid_blocks = ceil_div(M, 64) * ceil_div(N, 64);
+  if (mid_blocks < (5 * kNumCU) / 2) {
+#define RECMV_NTN(FF)                                                                                                  \
+  (g_gemm_mode == 1 ? launch_nt_narrow<FF, AMUL, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, \
+                                                       a_vec, b_vec, c_vec, am, s)                                     \
+                    : launch_nt_narrow<FF, AMUL, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param,          \
+                                                        out_scale, a_vec, b_vec, c_vec, am, s))
+    return fast ? RECMV_NTN(true) : RECMV_NTN(false);
+#undef RECMV_NTN
+  }
   return fast ? RECMV_NT(1, true) : RECMV_NT(1, false);
 #undef RECMV_NT
 }

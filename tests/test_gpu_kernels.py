@@ -237,7 +237,8 @@ def test_mc_full_size_257_properties():
 
 # ------------------------------------------------------------------------------------------ GEMM / PE
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 3, 39), (257, 512, 39), (300, 473, 512), (1000, 257, 512),
-                                   (129, 130, 167), (4096, 512, 512), (77, 3, 512), (640, 512, 289)])
+                                   (129, 130, 167), (4096, 512, 512), (77, 3, 512), (640, 512, 289), (6144, 512, 512),
+                                   (3072, 512, 473), (20000, 512, 512)])
 def test_gemm_nt_vs_fp64(M, N, K):
     from recmv import ops
     g = torch.Generator().manual_seed(M * 7 + N)

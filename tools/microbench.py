@@ -137,10 +137,10 @@ def bench_mc(quick):
 
 def bench_gemm(quick):
     from recmv import ops
-    shapes = [(460800, 512, 512), (153600, 512, 512), (6144, 512, 512), (153600, 512, 39), (153600, 257, 512),
+    shapes = [(460800, 512, 512), (153600, 512, 512), (6144, 512, 512), (3072, 512, 512), (153600, 512, 39), (153600, 257, 512),
               (153600, 473, 512), (460800, 512, 167)]
     if quick:
-        shapes = shapes[:3]
+        shapes = shapes[:4]
     for M, N, K in shapes:
         A = torch.randn(M, K, device=DEV)
         B = torch.randn(N, K, device=DEV) / K ** 0.5

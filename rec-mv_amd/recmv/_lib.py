@@ -16,6 +16,7 @@ _PKG = Path(__file__).resolve().parent.parent          # rec-mv_amd/
 LIB_PATH = _PKG / "lib" / "librecmv_hip.so"
 
 RECMV_OK = 0
+ABI_VERSION = 2          # include/recmv_hip.h; bumped when a signature changes (v2: recmv_mc_count / recmv_mc_emit)
 F32, F64 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = 0, 1, 2, 3
 
@@ -128,6 +129,9 @@ def lib():
                               "the recmv ops have no CPU fallback")
         l = C.CDLL(str(LIB_PATH))
         _declare(l)
+        if l.recmv_abi_version() != ABI_VERSION:
+            raise ImportError(f"librecmv_hip.so has ABI version {l.recmv_abi_version()}, this package needs "
+                              f"{ABI_VERSION}: rebuild with `python rec-mv_amd/build.py --force`")
         if os.environ.get("RECMV_GEMM_MODE"):
             l.recmv_set_gemm_mode(int(os.environ["RECMV_GEMM_MODE"]))
         _lib = l

@@ -183,7 +183,11 @@ class MLPTranslator(nn.Module):
         for l in range(0, self.num_layers - 1):
             lin = getattr(self, "lin" + str(l))
             last = l == self.num_layers - 2
-            x = ops.linear_act(x, lin.weight, lin.bias, ops.ACT_NONE if last else ops.ACT_RELU, 0.0)
+            W = lin.weight
+            pad = (-x.shape[1]) % 4
+            if pad and x.is_cuda:      # K = 167 -> 168: 16-byte aligned rows for the MFMA kernel's vector loader
+                x, W = F.pad(x, (0, pad)), F.pad(W, (0, pad))
+            x = ops.linear_act(x, W, lin.bias, ops.ACT_NONE if last else ops.ACT_RELU, 0.0)
         if batch_inds is not None:
             self.offset[offset_type] = x
             return ps[..., :3] + x

@@ -10,6 +10,7 @@ import warnings
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 from ..utils.utils import annealing_weights
@@ -136,6 +137,11 @@ class ImplicitNetwork(nn.Module):
                 x = torch.cat([x, input], 1) / np.sqrt(2)                           # network.py:105-106
             W, b = self._weight(l)
             last = l == self.num_layers - 2
+            pad = (-x.shape[1]) % 4
+            if pad and x.is_cuda:
+                # K = 39 -> 40 with a zero column on both operands: 16-byte aligned rows for the MFMA kernel's
+                # vector loader (same product; the padded column's gradient is sliced away by autograd)
+                x, W = F.pad(x, (0, pad)), F.pad(W, (0, pad))
             x = ops.linear_act(x, W, b, ops.ACT_NONE if last else ops.ACT_SOFTPLUS, 100.0)
         return x
 

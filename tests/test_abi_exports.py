@@ -14,7 +14,7 @@ def test_library_builds_and_exports_all_declared_symbols():
     assert len(names) >= 16
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in recmv_hip.h but not exported: {missing}"
-    assert _lib.lib().recmv_abi_version() == 1
+    assert _lib.lib().recmv_abi_version() == _lib.ABI_VERSION
 
 
 def test_argument_errors_do_not_need_a_gpu():

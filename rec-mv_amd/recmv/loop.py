@@ -106,6 +106,10 @@ class SyntheticFrames:
         # camera-to-world convention of the reference: x and y flipped (OptimGarmentNetwork.py:1041-1045)
         self.R = torch.diag(torch.tensor([-1.0, -1.0, 1.0])).view(1, 3, 3).to(device)
         self.T = torch.tensor([[0.0, 0.0, 3.0]], device=device, requires_grad=True)
+        # the reference stores the camera rotation as a quaternion (dataset/dataset.py:232-235); (0,0,0,1) is R above
+        self.quat = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=device)
+        self.shape = torch.zeros(1, 10, device=device)                      # SMPL betas: not used by the loop
+        self.frame_num = n_frames
         # images: smooth random colour / normal fields in [-1,1], shared by a few image slots to bound memory
         k = image_frames or min(n_frames, 8)
         low = torch.randn(k, 6, 16, 16, generator=g)
@@ -113,6 +117,26 @@ class SyntheticFrames:
         self.img = img[..., :3].contiguous().to(device)
         self.normal = F.normalize(img[..., 3:], dim=-1).contiguous().to(device)
         self.n_img = k
+
+    # -- the attribute names utils.save_model / load_model of the reference read and write (utils/utils.py:350-420)
+    @property
+    def camera_params(self):
+        return {'focal_length': self.focal, 'princeple_points': self.pp, 'cam2world_coord_quat': self.quat,
+                'world2cam_coord_trans': self.T}
+
+    @camera_params.setter
+    def camera_params(self, d):
+        self.focal, self.pp = d['focal_length'], d['princeple_points']
+        self.quat, self.T = d['cam2world_coord_quat'], d['world2cam_coord_trans']
+        from .utils import quat2mat
+        self.R = quat2mat(self.quat.detach().view(1, 4)).view(1, 3, 3)
+
+    @property
+    def conds(self):
+        return _CondPair(self)
+
+    def __len__(self):
+        return self.F
 
     def get_grad_parameters(self, frame_ids, device):
         return self.poses[frame_ids], self.trans[frame_ids], self.d_cond[frame_ids], self.rendcond[frame_ids]
@@ -133,6 +157,19 @@ class SyntheticFrames:
     def images(self, frame_ids):
         sl = frame_ids % self.n_img
         return self.img[sl], self.normal[sl]
+
+
+class _CondPair:
+    """dataset.conds[0] / [1] = the per-frame deformer / colour codes, assignable (utils/utils.py:386-387)."""
+
+    def __init__(self, ds):
+        self.ds = ds
+
+    def __getitem__(self, i):
+        return (self.ds.d_cond, self.ds.rendcond)[i]
+
+    def __setitem__(self, i, v):
+        setattr(self.ds, ('d_cond', 'rendcond')[i], v)
 
 
 class HotLoop:
@@ -193,6 +230,55 @@ class HotLoop:
                                           lr=conf.get_float('train.learning_rate'))
         cams = self._cameras()
         self.angThred = cams.angThreshold(0.5)                                   # OptimNetwork.py:65
+
+    # ------------------------------------------------------------------------------------------ stages / state
+    def set_stage(self, stage, resolutions=None):
+        """utils.set_hierarchical_config (utils/utils.py:330-348): next stage's loss weights, batch size, re-mesh period
+        and Seg3dLossless pyramid (same box)."""
+        conf = self.conf_all
+        self.stage = stage
+        self.conf = conf.get_config('loss_' + stage)
+        self.remesh_intersect = conf.get_int(f'train.{stage}.point_render.remesh_intersect')
+        self.batch_size = conf.get_int(f'train.{stage}.point_render.batch_size')
+        old = self.engine
+        self.engine = Seg3dLossless(query_func=None, b_min=old.b_min.view(-1).tolist(), b_max=old.b_max.view(-1).tolist(),
+                                    resolutions=resolutions if resolutions is not None else RESOLUTIONS[stage],
+                                    align_corners=False, balance_value=0.0, use_cuda_impl=True,
+                                    faster=False).to(self.device)
+        self.forward_time = 0                      # forces a re-mesh at the new resolution on the next iteration
+
+    def _modules(self):
+        return {'sdf': self.sdf, 'garment_nets': self.garment_nets, 'deformer': self.deformer,
+                'netRender': self.netRender, 'engine': self.engine}
+
+    def state_dict(self):
+        """Keys as `optNet.state_dict()` of the reference names them (getOptNet, model/network.py:182-361): `sdf.*`,
+        `garment_nets.{i}.*`, `deformer.defs.0.*` (offset MLP), `deformer.defs.1.*` (skinner buffers), `netRender.*`,
+        `engine.*`."""
+        out = {}
+        for prefix, mod in self._modules().items():
+            for k, v in mod.state_dict().items():
+                out[prefix + '.' + k] = v
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        missing, unexpected = [], set(sd.keys())
+        for prefix, mod in self._modules().items():
+            sub = {k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + '.')}
+            unexpected -= {prefix + '.' + k for k in sub}
+            res = mod.load_state_dict(sub, strict=False)
+            missing += [prefix + '.' + k for k in res.missing_keys]
+            unexpected |= {prefix + '.' + k for k in res.unexpected_keys}
+        if strict and (missing or unexpected):
+            raise RuntimeError(f'load_state_dict: missing {missing}, unexpected {sorted(unexpected)}')
+        return missing, sorted(unexpected)
+
+    def to(self, device):
+        return self
+
+    def parameters(self):
+        for mod in (self.garment_nets, self.deformer, self.netRender):
+            yield from mod.parameters()
 
     # ------------------------------------------------------------------------------------------ helpers
     @contextlib.contextmanager
@@ -523,20 +609,32 @@ class HotLoop:
             loss.backward()
 
     # ------------------------------------------------------------------------------------------ one step
-    def frame_batch(self, it):
-        """Frames of this rank for iteration `it`: a seeded permutation of all frames dealt round-robin over ranks
-        (the reference's RandomSampler, dataset/dataset.py:1135-1157, sharded — SURVEY.md §8e)."""
+    def iters_per_epoch(self):
+        return max(self.dataset.F // (self.batch_size * self.world_size), 1)
+
+    def frame_batch_at(self, epoch, pos):
+        """Frames of this rank for position `pos` of `epoch`: a seeded permutation of all frames dealt round-robin over
+        ranks (the reference's RandomSampler, dataset/dataset.py:1135-1157, sharded — SURVEY.md §8e)."""
         per_it = self.batch_size * self.world_size
-        iters_per_epoch = max(self.dataset.F // per_it, 1)
-        epoch, pos = divmod(it, iters_per_epoch)
         perm = torch.randperm(self.dataset.F, generator=torch.Generator().manual_seed(1234 + epoch))
         ids = perm[pos * per_it:(pos + 1) * per_it]
         return ids[self.rank::self.world_size][:self.batch_size].to(self.device)
 
-    def step(self, it, allreduce=None):
+    def frame_batch(self, it):
+        return self.frame_batch_at(*divmod(it, self.iters_per_epoch()))
+
+    def rebuild_optimizer(self, lr=None):
+        """New Adam over the dataset's learnable tensors and the networks (train.py:213, :229-231 after a resume)."""
+        params = [p for p in self.netRender.parameters()] + [p for p in self.deformer.parameters()] + \
+                 [p for p in self.garment_nets.parameters()]
+        lr = self.conf_all.get_float('train.learning_rate') if lr is None else lr
+        self.optimizer = torch.optim.Adam(self.dataset.learnable_weights() + params, lr=lr)
+        return self.optimizer
+
+    def step(self, it, allreduce=None, frame_ids=None):
         """train.py:317-328.  `allreduce(list_of_tensors)` is called on the gradients before each optimizer step
         when frames are sharded over ranks."""
-        frame_ids = self.frame_batch(it)
+        frame_ids = self.frame_batch(it) if frame_ids is None else frame_ids
         ratio = {'sdfRatio': 1., 'deformerRatio': self.opt_times / 2500. + 0.5, 'renderRatio': 1.}
         self._allreduce = allreduce
         loss = self.forward(frame_ids, ratio)

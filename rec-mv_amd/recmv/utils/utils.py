@@ -16,7 +16,7 @@ from torch.autograd import Function
 
 from ..FastMinv import Fast3x3Minv, Fast3x3Minv_backward
 
-__all__ = ["FastDiff3x3MinvFunction", "quat2mat", "annealing_weights", "GMRobustError", "sample_points",
+__all__ = ["save_model", "load_model", "FastDiff3x3MinvFunction", "quat2mat", "annealing_weights", "GMRobustError", "sample_points",
            "compute_Jacobian", "batch_compute_Jacobian", "compute_deformed_normals", "compute_cardinal_rays",
            "compute_netRender_color", "scatter_mean"]
 
@@ -168,3 +168,50 @@ def scatter_mean(src, index, dim_size):
     out = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, src)
     cnt = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, torch.ones_like(src))
     return out / cnt.clamp(min=1)
+
+
+def save_model(name, epoch, optNet, dataset):
+    """Checkpoint with the reference's layout (utils/utils.py:350-357): epoch, model_state_dict, the camera parameters
+    under their dataset names, poses / trans / shape and the per-frame codes dcond / rcond.  Optimiser state is not
+    saved (the reference does not either)."""
+    outdic = {"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in optNet.state_dict().items()}}
+    outdic.update({k: v.detach().cpu() for k, v in dataset.camera_params.items()})
+    outdic.update({'poses': dataset.poses.detach().cpu(), 'trans': dataset.trans.detach().cpu(),
+                   'shape': dataset.shape.detach().cpu(), 'dcond': dataset.conds[0].detach().cpu(),
+                   'rcond': dataset.conds[1].detach().cpu()})
+    torch.save(outdic, name)
+
+
+def load_model(name, optNet, dataset, device, subsdfmodel=None, model_rm_prefix=None):
+    """utils/utils.py:359-420: drops `engine.*` and the skinner's `ws` volume, optional prefix removal and SDF
+    substitution, `alpha_curve` -> `inter_free_curve`, non-strict load; restores the per-frame tensors and camera
+    parameters keeping each tensor's requires_grad; returns (optNet, dataset, epoch)."""
+    saved = torch.load(name, map_location='cpu')
+    state = {k: v for k, v in saved["model_state_dict"].items() if 'engine.' not in k}
+    if model_rm_prefix:
+        state = {k: v for k, v in state.items() if not any(k[:len(p)] == p for p in model_rm_prefix)}
+    if subsdfmodel is not None:
+        sdf_model = torch.load(subsdfmodel, map_location='cpu')
+        state = {k: v for k, v in state.items() if 'sdf.' not in k}
+        state.update({'sdf.' + k: v for k, v in sdf_model.items()})
+    state = {k: v for k, v in state.items() if 'deformer.defs.1.ws' not in k}
+    for key in list(state.keys()):
+        if 'alpha_curve' in key:
+            state[key.replace('alpha_curve', 'inter_free_curve')] = state.pop(key)
+    optNet.load_state_dict(state, strict=False)
+    optNet = optNet.to(device)
+
+    def restore(old, new):
+        return new.to(device).requires_grad_(old.requires_grad)
+
+    if 'dcond' in saved:
+        dataset.conds[0] = restore(dataset.conds[0], saved['dcond'])
+    if 'rcond' in saved:
+        dataset.conds[1] = restore(dataset.conds[1], saved['rcond'])
+    dataset.poses = restore(dataset.poses, saved['poses'])
+    assert dataset.frame_num <= dataset.poses.shape[0]
+    dataset.trans = restore(dataset.trans, saved['trans'])
+    assert dataset.frame_num <= dataset.trans.shape[0]
+    dataset.shape = restore(dataset.shape, saved['shape'])
+    dataset.camera_params = {k: restore(v, saved[k]) for k, v in dataset.camera_params.items()}
+    return optNet, dataset, saved['epoch']

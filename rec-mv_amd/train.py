@@ -1,0 +1,150 @@
+"""train.py — the reference's training driver (train.py:21-356) on the MI355X hot loop.
+
+Same command line (`--gpu-ids --conf --data --model-rm-prefix --sdf-model --save-folder --project_name --exp_name
+--data_type --a_pose --curve_sampling --resume`), same HOCON schema, same schedule: coarse -> medium -> fine stages
+switched at `train.<stage>.start_epoch` (Seg3dLossless pyramid, batch size, re-mesh period, loss weights), Adam +
+MultiStepLR, `coarse.pth` / `medium.pth` at the stage switches and `latest.pth` every epoch in the reference's
+checkpoint layout (recmv.utils.save_model / load_model), resume with the scheduler fast-forwarded and `opt_times`
+recomputed (train.py:232-260).
+
+What differs: the dataset loaders, the SDF / feature-curve initialisers and wandb are outside this tier,
+so the frames are synthetic (`recmv.loop.SyntheticFrames`; `--frames` sets their number) and `--data` is only the
+root under which `--save-folder` is created.  One process per GPU: under
+`python -m torch.distributed.run --nproc-per-node N train.py ...` the frames of every mini-batch are sharded over the
+ranks and the shared gradients all-reduced with RCCL (recmv.dist); `--gpu-ids` picks the device of a single process.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import os.path as osp
+import sys
+import time
+
+sys.path.insert(0, osp.dirname(osp.abspath(__file__)))
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='neu video body rec')
+    parser.add_argument('--gpu-ids', nargs='+', type=int, metavar='IDs', default=[0], help='gpu ids')
+    parser.add_argument('--conf', default=None, metavar='M', help='config file')
+    parser.add_argument('--data', default=None, metavar='M', help='data root')
+    parser.add_argument('--model-rm-prefix', nargs='+', type=str, metavar='rm prefix', help='rm model prefix')
+    parser.add_argument('--sdf-model', default=None, metavar='M', help='substitute sdf model')
+    parser.add_argument('--save-folder', default=None, metavar='M', help='save folder')
+    parser.add_argument('--project_name', type=str, default='recmv', help='exp name show by wandb (unused: no wandb)')
+    parser.add_argument('--exp_name', type=str, default='run', help='exp name show by wandb (unused: no wandb)')
+    parser.add_argument('--data_type', type=str, default='synthetic', help='the type of dataset')
+    parser.add_argument('--a_pose', action='store_true', help='the type of dataset')
+    parser.add_argument('--curve_sampling', type=int, default=1, help='the type of dataset')
+    parser.add_argument('--resume', default=None, metavar='M', help='pretrained scene model')
+    # extensions
+    parser.add_argument('--frames', type=int, default=64, help='number of synthetic frames')
+    parser.add_argument('--max-iters', type=int, default=-1, help='stop after this many optimiser iterations (smoke runs)')
+    return parser
+
+
+def stage_of_epoch(config, epoch):
+    """'coarse' | 'medium' | 'fine' for an epoch (train.py:233-244, :300-314)."""
+    fine, medium = config.get_int('train.fine.start_epoch'), config.get_int('train.medium.start_epoch')
+    if fine >= 0 and epoch >= fine:
+        return 'fine'
+    if medium >= 0 and epoch >= medium:
+        return 'medium'
+    return 'coarse'
+
+
+def resumed_opt_times(config, n_frames, start_epoch):
+    """Optimiser iterations already done when resuming after `start_epoch` (train.py:250-260, formulas kept)."""
+    coarse_epoch = config.get_int('train.coarse.start_epoch')
+    medium_epoch = config.get_int('train.medium.start_epoch')
+    fine_epoch = config.get_int('train.fine.start_epoch')
+    bs = {s: config.get_int(f'train.{s}.point_render.batch_size') for s in ('coarse', 'medium', 'fine')}
+    coarse_time = math.ceil(n_frames / bs['coarse']) * (medium_epoch - coarse_epoch)
+    medium_time = math.ceil(n_frames / bs['medium']) * (fine_epoch - medium_epoch)
+    fine_time = math.ceil(n_frames / bs['fine']) * (start_epoch - medium_epoch + 1)
+    return float(coarse_time + medium_time + fine_time)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    import torch
+    from recmv import dist as rdist, utils
+    from recmv.hocon import ConfigFactory
+    from recmv.loop import HotLoop
+
+    config = ConfigFactory.parse_file(args.conf)
+    rank, local_rank, world = rdist.init_distributed()
+    assert torch.cuda.is_available(), "train.py needs a GPU (librecmv_hip.so has no CPU fallback)"
+    device = torch.device('cuda', local_rank if world > 1 else (args.gpu_ids[0] if args.gpu_ids else 0))
+    torch.cuda.set_device(device)
+    if args.save_folder is None:
+        print('please set save-folder...')
+        assert (False)
+    save_root = osp.join(args.data or '.', args.save_folder)
+    if rank == 0:
+        os.makedirs(osp.join(save_root, 'debug'), exist_ok=True)
+
+    loop = HotLoop(config, device, n_frames=args.frames, H=512, W=512, stage='coarse', world_size=world, rank=rank)
+    rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters()))
+    allreduce = rdist.GradAllReduce(world) if world > 1 else None
+    dataset = loop.dataset
+    start_epoch = 0
+    optimizer = loop.optimizer
+    milestones = config.get_list('train.scheduler.milestones')
+    gamma = config.get_float('train.scheduler.factor')
+    scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma=gamma)
+    stage = 'coarse'
+
+    if args.resume is not None and osp.isfile(args.resume):
+        print('load model: ' + args.resume)
+        loop, dataset, start_epoch = utils.load_model(args.resume, loop, dataset, device, args.sdf_model,
+                                                      args.model_rm_prefix)
+        stage = stage_of_epoch(config, start_epoch)
+        if stage != 'coarse':
+            loop.set_stage(stage)
+            print('enable %s hierarchical' % stage)
+        optimizer = loop.rebuild_optimizer()
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma=gamma)
+        for __ in range(start_epoch + 1):
+            scheduler.step()
+        loop.opt_times += resumed_opt_times(config, len(dataset), start_epoch)
+        start_epoch += 1
+
+    nepochs = config.get_int('train.nepoch')
+    done = 0
+    for epoch in range(start_epoch, nepochs):
+        new_stage = stage_of_epoch(config, epoch)
+        if new_stage != stage:
+            if rank == 0:
+                utils.save_model(osp.join(save_root, stage + ".pth"), epoch, loop, dataset)   # coarse.pth / medium.pth
+            loop.set_stage(new_stage)
+            stage = new_stage
+            torch.cuda.empty_cache()
+            print('enable %s hierarchical' % stage)
+        for data_index in range(loop.iters_per_epoch()):
+            t0 = time.perf_counter()
+            frame_ids = loop.frame_batch_at(epoch, data_index)
+            loss, rays = loop.step(int(loop.opt_times), allreduce, frame_ids=frame_ids)
+            if rank == 0:
+                lr = optimizer.param_groups[0]['lr']
+                info = loop.info
+                msg = '(%d/%d) loss = %.5f lr = %.2e rays = %d' % (epoch, data_index, float(loss), lr, int(rays))
+                for name in loop.garment_names:
+                    msg += ' | %s: eik %.4f pc_sdf %.5f' % (name, float(info.get(name + '_grad_loss', 0.)),
+                                                           float(info.get('pc_%s_loss_sdf' % name, 0.)))
+                print(msg + ' (%.0f ms)' % ((time.perf_counter() - t0) * 1e3), flush=True)
+            done += 1
+            if 0 <= args.max_iters <= done:
+                break
+        if rank == 0:
+            utils.save_model(osp.join(save_root, "latest.pth"), epoch, loop, dataset)
+        scheduler.step()
+        if 0 <= args.max_iters <= done:
+            break
+    rdist.barrier()
+
+
+if __name__ == '__main__':
+    main()

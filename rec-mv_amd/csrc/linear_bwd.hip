@@ -50,32 +50,58 @@ __device__ __forceinline__ float dact_y(float y, int act, float p) {
 
 // gz[r,c] = gy[r,c] * act'(z) (through y = act(z)), written out, AND partial[chunk][c] = column sums of gz over the
 // chunk's rows: the bias gradient comes out of the same pass over dY that produces dZ.
+// VEC = 4: 16-byte accesses (16 threads span the 64-column tile, 16 rows in flight per block pass); VEC = 1: scalar.
+template <int VEC>
 __global__ __launch_bounds__(kBlk) void act_grad_colsum_kernel(const float* __restrict__ gy, int64_t ldg,
                                                                const float* __restrict__ y, int64_t ldy,
                                                                float* __restrict__ gz, int64_t ldz, int64_t rows,
                                                                int cols, int64_t rows_per_chunk, int act, float p,
                                                                float* __restrict__ partial) {
-  __shared__ float sh[kBlk / kColTile][kColTile];
+  constexpr int CT = kColTile / VEC;          // threads across the column tile
+  constexpr int RG = kBlk / CT;               // rows in flight
+  __shared__ float sh[RG][kColTile];
   const int ctile = blockIdx.x, chunk = blockIdx.y;
-  const int lane = threadIdx.x % kColTile, rgrp = threadIdx.x / kColTile;
-  const int c = ctile * kColTile + lane;
+  const int cl = threadIdx.x % CT, rgrp = threadIdx.x / CT;
+  const int c = ctile * kColTile + cl * VEC;
   const int64_t r0 = (int64_t)chunk * rows_per_chunk;
   int64_t r1 = r0 + rows_per_chunk;
   if (r1 > rows) r1 = rows;
-  float s = 0.f;
-  if (c < cols)
-    for (int64_t r = r0 + rgrp; r < r1; r += kBlk / kColTile) {
-      const float v = gy[r * ldg + c] * dact_y(y[r * ldy + c], act, p);
-      gz[r * ldz + c] = v;
-      s += v;
-    }
-  sh[rgrp][lane] = s;
-  __syncthreads();
-  if (rgrp == 0 && c < cols) {
-    float t = 0.f;
+  float s[VEC];
 #pragma unroll
-    for (int q = 0; q < kBlk / kColTile; ++q) t += sh[q][lane];
-    partial[(int64_t)chunk * cols + c] = t;
+  for (int v = 0; v < VEC; ++v) s[v] = 0.f;
+  if (c < cols) {
+    for (int64_t r = r0 + rgrp; r < r1; r += RG) {
+      if (VEC == 4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gy + r * ldg + c);
+        const float4 y4 = *reinterpret_cast<const float4*>(y + r * ldy + c);
+        float4 o;
+        o.x = g4.x * dact_y(y4.x, act, p);
+        o.y = g4.y * dact_y(y4.y, act, p);
+        o.z = g4.z * dact_y(y4.z, act, p);
+        o.w = g4.w * dact_y(y4.w, act, p);
+        *reinterpret_cast<float4*>(gz + r * ldz + c) = o;
+        s[0] += o.x;
+        s[VEC > 1 ? 1 : 0] += o.y;
+        s[VEC > 2 ? 2 : 0] += o.z;
+        s[VEC > 3 ? 3 : 0] += o.w;
+      } else {
+        const float v = gy[r * ldg + c] * dact_y(y[r * ldy + c], act, p);
+        gz[r * ldz + c] = v;
+        s[0] += v;
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) sh[rgrp][cl * VEC + v] = s[v];
+  __syncthreads();
+  if (threadIdx.x < kColTile) {
+    const int cc = ctile * kColTile + threadIdx.x;
+    if (cc < cols) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < RG; ++q) t += sh[q][threadIdx.x];
+      partial[(int64_t)chunk * cols + cc] = t;
+    }
   }
 }
 
@@ -176,9 +202,16 @@ extern "C" int recmv_linear_backward(const float* gy, int64_t ldgy, const float*
       // dZ and its column sums (the bias gradient) in one pass over dY
       const int chunks = colsum_chunks(M);
       const int64_t rpc = ceil_div(M, chunks);
-      hipLaunchKernelGGL(act_grad_colsum_kernel, dim3((unsigned)ceil_div(N, kColTile), (unsigned)chunks), dim3(kBlk), 0,
-                         (hipStream_t)stream, gy, ldgy, y, ldy, gzbuf, N, M, (int)N, rpc, act, act_param,
-                         (float*)cs_ws);
+      const bool vec = N % 4 == 0 && ldgy % 4 == 0 && ldy % 4 == 0 &&
+                       ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+      if (vec)
+        hipLaunchKernelGGL(act_grad_colsum_kernel<4>, dim3((unsigned)ceil_div(N, kColTile), (unsigned)chunks), dim3(kBlk),
+                           0, (hipStream_t)stream, gy, ldgy, y, ldy, gzbuf, N, M, (int)N, rpc, act, act_param,
+                           (float*)cs_ws);
+      else
+        hipLaunchKernelGGL(act_grad_colsum_kernel<1>, dim3((unsigned)ceil_div(N, kColTile), (unsigned)chunks), dim3(kBlk),
+                           0, (hipStream_t)stream, gy, ldgy, y, ldy, gzbuf, N, M, (int)N, rpc, act, act_param,
+                           (float*)cs_ws);
       rc = check_launch("linear_backward/act_grad_colsum");
       if (rc) return rc;
       hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)ceil_div(N, kBlk)), dim3(kBlk), 0, (hipStream_t)stream,

@@ -233,6 +233,10 @@ class MlpJet(torch.autograd.Function):
             if cidx is None:
                 gcond = gc.sum(0, keepdim=True).expand(ctx.cond_shape) if ctx.cond_shape[0] == 1 else None
                 assert gcond is not None, "a per-point frame index is needed when there are several codes"
+            elif cfg.get('cond_blocks'):
+                # frame-major blocks of equal length: a fixed-order sum per frame instead of atomics
+                nb = cfg['cond_blocks']
+                gcond = gc.reshape(nb, P // nb, gc.shape[1]).sum(1)
             else:
                 gcond = torch.zeros(ctx.cond_shape, dtype=torch.float32, device=dev).index_add_(0, cidx, gc)
         ctx.ws = None
@@ -240,12 +244,12 @@ class MlpJet(torch.autograd.Function):
 
 
 def mlp_jet(x, cond, cond_index, Ws, bs, dims, multires, pe_weights, cond_dim, skip_layer, hidden_act, act_param,
-            residual, n_j):
+            residual, n_j, cond_blocks=0):
     """(y [P, rows_last], J [P, n_j, 3]) with J[p, j, k] = d mlp_j / d x_k (the residual's identity NOT included)."""
     cfg = dict(n_layers=len(Ws), dims=list(dims), multires=multires,
                pe_weights=None if pe_weights is None else tuple(float(w) for w in pe_weights), cond_dim=cond_dim,
                skip_layer=skip_layer, hidden_act=hidden_act, act_param=act_param, residual=residual, n_j=n_j,
-               cond_index=cond_index)
+               cond_index=cond_index, cond_blocks=cond_blocks)
     y, tang = MlpJet.apply(cfg, x, cond, *Ws, *bs)
     P = x.shape[0]
     return y, tang.view(3, P, n_j).permute(1, 2, 0)

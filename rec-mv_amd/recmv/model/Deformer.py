@@ -202,19 +202,21 @@ def _translator_forward_jet(self, ps, conds, batch_inds, ratio, offset_type):
     ws = None if ratio is None else ([0.] * (self.multires * 2) if ratio <= 0 else
                                      annealing_weights(self.multires, ratio))
     flat = ps.reshape(-1, 3)
+    blocks = 0
     if batch_inds is not None:
         cidx = batch_inds
         cond2d = conds
     else:
         cond2d = conds.reshape(-1, self.feature_vector_size)
         cidx = torch.arange(cond2d.shape[0], device=ps.device).repeat_interleave(ps.shape[1])
+        blocks = cond2d.shape[0]              # frame-major blocks of ps.shape[1] points each
     nl = self.num_layers - 1
     lins = [getattr(self, "lin" + str(l)) for l in range(nl)]
     Ws = [lin.weight for lin in lins]
     bs = [lin.bias for lin in lins]
     dims = [Ws[0].shape[1]] + [W.shape[0] for W in Ws]
     y, J = mlp_jet(flat, cond2d, cidx.contiguous(), Ws, bs, dims, self.multires, ws, self.feature_vector_size, -1,
-                   ops.ACT_RELU, 0.0, True, 3)
+                   ops.ACT_RELU, 0.0, True, 3, cond_blocks=blocks)
     out = y.view(ps.shape)
     self.offset[offset_type] = out - ps[..., :3]
     out._recmv_jac = (ps, J + torch.eye(3, device=ps.device, dtype=J.dtype).view(1, 3, 3))

@@ -582,31 +582,35 @@ class HotLoop:
             self.info['{}_invInfo'.format(name)] = (check.numel(), check.sum())
             rhs_1 = (btb_inv.unsqueeze(-1) * b.permute(0, 2, 1).unsqueeze(-3)).sum(-2)       # [P,3,4]
             rhs_1 = (grad_l_p.view(-1, 3, 1) * rhs_1).sum(1, keepdim=True)                  # [P,1,4]
-            loss = 0.
+            # The reference injects these gradients with `loss += (param * grad).sum(); loss.backward()` (:2269-2313).
+            # d/dparam of that sum IS `grad`, so the leaves are accumulated directly (one multi-tensor add) and the
+            # non-leaf targets (per-frame codes gathered by frame id, rays, camera centre) get one backward call.
+            targets, grads = [], []
             params = [q for q in net.parameters() if q.requires_grad]
             pg = torch.autograd.grad(net(p, ratio), params, -rhs_1[:, :, 0])
-            for q, gq in zip(params, pg):
-                loss = loss + (q * gq).sum()
+            targets += params
+            grads += list(pg)
             params = [q for q in self.deformer.parameters() if q.requires_grad]
             d = self.deformer(p, defconds, self.batch_inds[g_i], ratio=ratio, offset_type=name)
             temp = -(rhs_1[:, :, -3:].transpose(1, 2) * v_cross).sum(1)                      # rhs[1:4] @ (-[v]_x)
             pg = torch.autograd.grad(d, params, temp, retain_graph=len(opt_defconds) > 0)
-            for q, gq in zip(params, pg):
-                loss = loss + (q * gq).sum()
+            targets += params
+            grads += list(pg)
             if len(opt_defconds):
                 pg = torch.autograd.grad(d, opt_defconds, temp, retain_graph=False)
-                for q, gq in zip(opt_defconds, pg):
-                    loss = loss + (q * gq).sum()
+                targets += opt_defconds
+                grads += list(pg)
             if v.requires_grad:
                 dc = d.detach() - c.detach().view(1, 3)
                 dc_cross = torch.stack([torch.stack([zeros, -dc[:, 2], dc[:, 1]], -1),
                                         torch.stack([dc[:, 2], zeros, -dc[:, 0]], -1),
                                         torch.stack([-dc[:, 1], dc[:, 0], zeros], -1)], dim=1)
-                grad = (rhs_1[:, :, -3:].transpose(1, 2) * dc_cross).sum(1)
-                loss = loss + (v * grad).sum()
+                targets.append(v)
+                grads.append((rhs_1[:, :, -3:].transpose(1, 2) * dc_cross).sum(1))
             if c.requires_grad:
-                loss = loss + (c * (-temp.sum(0))).sum()
-            loss.backward()
+                targets.append(c)
+                grads.append((-temp.sum(0)).view_as(c))
+            _inject_gradients(targets, grads)
 
     # ------------------------------------------------------------------------------------------ one step
     def iters_per_epoch(self):
@@ -648,6 +652,31 @@ class HotLoop:
             self.optimizer.step()
         self.opt_times += 1.
         return loss.detach(), self.info['rays_total']
+
+
+def _inject_gradients(targets, grads):
+    """target.grad += grad for leaves (one multi-tensor add), one backward call for the non-leaf targets."""
+    leaf_t, leaf_g, new_t, nl_t, nl_g = [], [], [], [], []
+    for t, g in zip(targets, grads):
+        if g is None:
+            continue
+        g = g.detach()
+        if t.is_leaf:
+            if t.grad is None:
+                new_t.append((t, g))
+            else:
+                leaf_t.append(t.grad)
+                leaf_g.append(g.reshape(t.grad.shape))
+        else:
+            nl_t.append(t)
+            nl_g.append(g.reshape(t.shape))
+    with torch.no_grad():
+        if leaf_t:
+            torch._foreach_add_(leaf_t, leaf_g)
+        for t, g in new_t:
+            t.grad = g.reshape(t.shape).clone()
+    if nl_t:
+        torch.autograd.backward(nl_t, nl_g)
 
 
 @torch.no_grad()

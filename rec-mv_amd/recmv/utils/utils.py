@@ -128,13 +128,9 @@ def compute_deformed_normals(sdf, deformer, ps, defconds, batch_inds, ratio, pha
     grad_d_p = compute_Jacobian(ps, ds, check, check)
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
     nx = _bmv(grad_d_p_inv.transpose(-2, -1), onx.view(-1, 3))
-    n_inv_mask = ~inv_mask
-    if n_inv_mask.sum().item() > 0:
-        print('unwished error n_inv_mask:(%d:%d)' % (n_inv_mask.sum().item(), n_inv_mask.numel()))
-        nnx = torch.zeros_like(nx)
-        nnx[inv_mask] = nx[inv_mask]
-        nnx[n_inv_mask] = _bmv(grad_d_p[n_inv_mask], onx[n_inv_mask])
-        nx = nnx
+    # rows with a singular Jacobian fall back to J grad f (:221-227).  The reference tests `n_inv_mask.sum().item()`
+    # on the host (a device sync per call) before scattering; selecting per row gives the same tensor without it.
+    nx = torch.where(inv_mask.view(-1, 1), nx, _bmv(grad_d_p, onx.view(-1, 3)))
     nx = nx / nx.norm(dim=1, keepdim=True)
     return nx, ds
 
@@ -146,13 +142,9 @@ def compute_cardinal_rays(deformer, ps, rays, defconds, batch_inds, ratio, phase
     grad_d_p = compute_Jacobian(ps, ds, check, check)
     grad_d_p_inv, inv_mask = FastDiff3x3MinvFunction.apply(grad_d_p)
     crays = _bmv(grad_d_p_inv, rays.view(-1, 3))
-    n_inv_mask = ~inv_mask
-    if n_inv_mask.sum().item() > 0:
-        print('unwished error n_inv_mask:(%d:%d)' % (n_inv_mask.sum().item(), n_inv_mask.numel()))
-        ncrays = torch.zeros_like(crays)
-        ncrays[inv_mask] = crays[inv_mask]
-        ncrays[n_inv_mask] = rays[n_inv_mask].detach()
-        crays = ncrays
+    # rows with a singular Jacobian fall back to the (detached) ray itself (:241-247), selected per row without the
+    # reference's host-side `.sum().item()` test
+    crays = torch.where(inv_mask.view(-1, 1), crays, rays.view(-1, 3).detach())
     crays = crays / crays.norm(dim=1, keepdim=True)
     return crays, ds
 

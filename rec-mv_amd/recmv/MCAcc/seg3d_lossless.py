@@ -101,7 +101,11 @@ class Seg3dLossless(nn.Module):
     def _forward(self, **kwargs):
         calculated = self.calculated.clone()
         occupancys = None
-        coords_accum = None
+        # The reference carries the already-evaluated voxels as a coordinate list (`coords_accum`) that it doubles per
+        # level and de-duplicates with `unique(dim=1)` — a lexicographic sort of up to 10^5-10^6 rows, twice per level.
+        # The same SET is kept here as a boolean volume of the current level (`done`): doubling = writing it to the
+        # even lattice of the next level, union = a scatter of True.  Same voxels are queried, no sort.
+        done = None
         for resolution in self.resolutions:
             W, H, D = [int(v) for v in resolution]
             stride = (self.resolutions[-1] - 1) // (resolution - 1)
@@ -109,16 +113,19 @@ class Seg3dLossless(nn.Module):
                 coords = self.init_coords.clone()
                 occupancys = self.batch_eval(coords, **kwargs).view(self.batchsize, self.channels, D, H, W)
                 with torch.no_grad():
-                    coords_accum = coords // stride
+                    done = torch.ones((D, H, W), dtype=torch.bool, device=occupancys.device)   # every level-0 voxel
                     calculated[coords[0, :, 2], coords[0, :, 1], coords[0, :, 0]] = True
                 continue
 
-            coords_accum = coords_accum * 2
+            with torch.no_grad():
+                done_prev = done
+                done = torch.zeros((D, H, W), dtype=torch.bool, device=occupancys.device)
+                done[::2, ::2, ::2] = done_prev                                        # coords_accum * 2 (:271)
             occupancys, is_boundary = self._upsample(occupancys, D, H, W)
             with torch.no_grad():
                 # 3^3 box filter > 0  ==  3^3 max-pool of the 0/1 mask (seg3d_lossless.py:296)
                 is_boundary = (F.max_pool3d(is_boundary.float(), 3, 1, 1) > 0)[0, 0]
-                is_boundary[coords_accum[0, :, 2], coords_accum[0, :, 1], coords_accum[0, :, 0]] = False
+                is_boundary &= ~done                                                    # minus already computed (:299-301)
                 point_coords = is_boundary.permute(2, 1, 0).nonzero(as_tuple=False).unsqueeze(0)
                 point_indices = (point_coords[:, :, 2] * H * W + point_coords[:, :, 1] * W + point_coords[:, :, 0])
                 R, C, D, H, W = occupancys.shape
@@ -133,8 +140,7 @@ class Seg3dLossless(nn.Module):
                           .view(R, C, D, H, W))
             with torch.no_grad():
                 conflicts = ((occupancys_interp - self.balance_value) * (occupancys_topk - self.balance_value) < 0)[0, 0]
-                voxels = coords // stride
-                coords_accum = torch.cat([voxels, coords_accum], dim=1).unique(dim=1)
+                done.view(-1)[point_indices[0]] = True                                  # union with the new voxels
                 calculated[coords[0, :, 2], coords[0, :, 1], coords[0, :, 0]] = True
 
             while conflicts.sum() > 0:
@@ -164,7 +170,6 @@ class Seg3dLossless(nn.Module):
                               .scatter_(2, point_indices.unsqueeze(1).expand(-1, C, -1), occupancys_topk)
                               .view(R, C, D, H, W))
                 with torch.no_grad():
-                    voxels = coords // stride
-                    coords_accum = torch.cat([voxels, coords_accum], dim=1).unique(dim=1)
+                    done.view(-1)[point_indices[0]] = True
                     calculated[coords[0, :, 2], coords[0, :, 1], coords[0, :, 0]] = True
         return occupancys

@@ -28,7 +28,11 @@ def init_distributed(backend: str | None = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # RECMV_DIST_BACKEND=gloo lets several ranks share one GPU (functional tests of the N>1 path on a 1-GPU box;
+            # RCCL refuses two ranks on the same device)
+            backend = os.environ.get("RECMV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if os.environ.get("RECMV_SHARE_GPU0") == "1":
+            local_rank = 0
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

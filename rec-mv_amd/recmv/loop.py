@@ -379,7 +379,7 @@ class HotLoop:
         self.garment_optimizer.step()
         pc_sdf_loss = 0.
         for g_i, name in enumerate(self.garment_names):                                   # :966-970
-            mnfld_pred = self.garment_nets[g_i](self.garment_vs[g_i], ratio).view(-1)
+            mnfld_pred = self.garment_nets[g_i](self.garment_vs[g_i], ratio, features=False).view(-1)
             sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
             self.info['pc_{}_loss_sdf'.format(name)] = sdf_loss.detach()
             pc_sdf_loss = pc_sdf_loss + sdf_loss * conf.get_float('pc_weight.weight')
@@ -438,7 +438,7 @@ class HotLoop:
             sel = torch.rand(V, device=dev) < float(surface_sample_points) / float(V)
             nonmnfld = utils.sample_points(torch.cat([init_ps, TmpVs[sel].detach()], dim=0), 1.8, 0.01)
             nonmnfld.requires_grad_()
-            pred = net(nonmnfld, ratio, jet=True)
+            pred = net(nonmnfld, ratio, jet=True, features=False)
             grad = net.gradient(nonmnfld, pred)
             grad_loss = ((grad.norm(2, dim=-1) - 1) ** 2).mean()                           # eikonal :1118
             self.info['{}_grad_loss'.format(name)] = grad_loss.detach()

@@ -92,10 +92,13 @@ class ImplicitNetwork(nn.Module):
         return annealing_weights(self.multires, ratio)
 
     # -- forward ---------------------------------------------------------------------------------
-    def forward(self, input, ratio=None, jet=False):
-        """`jet=True` (extension over the reference's signature): also carry d f / d x forward through the layers
-        (csrc/mlp_jet.hip); a following `gradient(input, output)` then returns it without autograd's double
-        backward, and the whole term is differentiable to first order in the parameters and the input."""
+    def forward(self, input, ratio=None, jet=False, features=True):
+        """Extensions over the reference's signature (both optional):
+        `jet=True`: also carry d f / d x forward through the layers (csrc/mlp_jet.hip); a following
+        `gradient(input, output)` then returns it without autograd's double backward, and the whole term is
+        differentiable to first order in the parameters and the input.
+        `features=False`: evaluate only the first `d_out` rows of the last layer (the SDF value) — for the terms that
+        never read `rendcond` (eikonal, |SDF(vertices)|); the unused rows get a zero gradient either way."""
         ws = self._pe_weights(ratio) if self.embed_fn is not None else None
         needs_grad = torch.is_grad_enabled() and (input.requires_grad or
                                                   any(p.requires_grad for p in self.parameters()))
@@ -105,9 +108,9 @@ class ImplicitNetwork(nn.Module):
         if not needs_grad and fast:
             x = self._forward_inference(input, ws)
         elif jet and fast and len(self.skip_in) <= 1:
-            x, J = self._forward_jet(input, ws)
+            x, J = self._forward_jet(input, ws, None if features else self.d_out)
         else:
-            x = self._forward_autograd(input, ws)
+            x = self._forward_autograd(input, ws, None if features else self.d_out)
         if x.shape[-1] > self.d_out:
             self.rendcond = x[:, self.d_out:]
             x = x[:, 0:self.d_out]
@@ -117,18 +120,23 @@ class ImplicitNetwork(nn.Module):
             self.__dict__['_jet'] = (input, x, J)
         return x
 
-    def _forward_jet(self, input, ws):
+    def _forward_jet(self, input, ws, n_last=None):
         from ..chains import mlp_jet
         nl = self.num_layers - 1
         Ws, bs = [], []
         for l in range(nl):
             W, b = self._weight(l)
+            if n_last is not None and l == nl - 1:
+                W, b = W[:n_last].contiguous(), b[:n_last]
             Ws.append(W)
             bs.append(b)
-        return mlp_jet(input, None, None, Ws, bs, self.dims, self.multires, ws, 0,
+        dims = list(self.dims)
+        if n_last is not None:
+            dims[-1] = n_last
+        return mlp_jet(input, None, None, Ws, bs, dims, self.multires, ws, 0,
                        self.skip_in[0] if len(self.skip_in) else -1, ops.ACT_SOFTPLUS, 100.0, False, self.d_out)
 
-    def _forward_autograd(self, input, ws):
+    def _forward_autograd(self, input, ws, n_last=None):
         if self.embed_fn is not None:
             input = self.embed_fn(input, ws)
         x = input
@@ -137,6 +145,8 @@ class ImplicitNetwork(nn.Module):
                 x = torch.cat([x, input], 1) / np.sqrt(2)                           # network.py:105-106
             W, b = self._weight(l)
             last = l == self.num_layers - 2
+            if last and n_last is not None:
+                W, b = W[:n_last], b[:n_last]
             pad = (-x.shape[1]) % 4
             if pad and x.is_cuda:
                 # K = 39 -> 40 with a zero column on both operands: 16-byte aligned rows for the MFMA kernel's

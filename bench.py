@@ -194,6 +194,11 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--stage", default="coarse")
+    ap.add_argument("--settle-iters", type=int, default=240,
+                    help="untimed iterations run once after building the loop, before the warm-up: state "
+                         "preparation that takes the synthetic optimisation out of Adam's start-up transient, in "
+                         "which the SDF moves away from the explicit mesh faster than the 20-step root finder can "
+                         "follow and almost no ray reaches the render phases (DESIGN.md §7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--gemm-mode", choices=["f32", "bf16x6"], default="f32",
@@ -231,6 +236,12 @@ def main():
     mode_id = {"f32": 0, "bf16x6": 1}
     L.lib().recmv_set_gemm_mode(mode_id[args.gemm_mode])
     it = 0
+    for _ in range(args.settle_iters):
+        loop.step(it, allreduce)
+        it += 1
+        if it % 60 == 0:
+            torch.cuda.synchronize()
+            log("settling: iteration %d, rays converged %s" % (it, loop.info.get('rays_converged')))
     for _ in range(args.warmup):
         loop.step(it, allreduce)
         it += 1
@@ -242,12 +253,14 @@ def main():
     if getattr(loop, "phase_ms", None):
         loop.phase_ms = {}          # RECMV_TIMING=1: report the timed steps only
     rays = 0
+    converged = 0
     rdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         _, r = loop.step(it, allreduce)
         rays += int(r)
+        converged += sum(loop.info.get('rays_converged', []))     # host ints the loop's own gate read back
         it += 1
         if it % 5 == 0:
             log("step %d" % it)
@@ -311,13 +324,17 @@ def main():
             "config": {
                 "workload": "configs[1]: PeopleSnapshot female-3-casual-like, 512x512, frames_per_step=%d per GPU, "
                             "2 garments, sample_pix_num=%d, stage=%s pyramid %s, remesh every %d iters (inside the "
-                            "timed region when steps>=%d); pytorch3d rasterisers replaced by projections "
-                            "(recmv/loop.py docstring)" % (loop.batch_size, loop.sample_pix, args.stage,
+                            "timed region when steps>=%d); surface points from the HIP first-hit mesh rasteriser + "
+                            "FindSurfacePs, the point-splat silhouette term replaced by a projection (recmv/loop.py "
+                            "docstring)" % (loop.batch_size, loop.sample_pix, args.stage,
                                                           tuple(int(v) for v in loop.engine.resolutions[-1]),
                                                           loop.remesh_intersect, loop.remesh_intersect),
                 "parallelism": "frame-sharded dp%d, 1 RCCL all-reduce of shared grads / step" % world,
                 "mc_vertices": [int(v.shape[0]) for v in loop.garment_vs],
                 "rays_per_iter": int(loop.info.get('rays_total', 0)),
+                "rays_converged_per_iter": round(converged / max(args.steps, 1), 1),
+                "settle_iters": args.settle_iters,
+                "surface_pixels_last_iter": loop.info.get('surface_pixels'),
             },
         }
         if gs:

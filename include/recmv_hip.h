@@ -255,6 +255,27 @@ int recmv_add_scaled_2d(const float* a, int64_t lda, const float* b, int64_t ldb
                         int64_t rows, int64_t cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * First-hit mesh rasteriser (csrc/rasterize_meshes.hip).
+ *   replaces `self.maskRender(def_garment_mesh)` -> Fragments in find_surface_ps
+ *   (engineer/networks/OptimGarmentNetwork.py:742-767; settings :2336-2347) = pytorch3d 0.4.0
+ *   `rasterize_meshes(faces_per_pixel=1, perspective_correct, clip_barycentric_coords=False)`, whose outputs feed
+ *   utils/FindSurfacePs.py:7-37.
+ * face_verts [total_faces,3,3] f32: NDC x, y (+x left, +y up; pixel column c is centred at x = 1-(2c+1)/W, row r at
+ * y = 1-(2r+1)/H — model/CameraMine.py:132-142) and view-space depth z of the three corners of every face, meshes
+ * packed one after another; mesh n owns faces [mesh_first_face[n], +mesh_num_faces[n]) (device int64 [N]);
+ * max_faces_per_mesh >= max(mesh_num_faces) (host value, sizes the launch).  blur_radius is pytorch3d's (squared NDC
+ * distance; 0 = hard coverage).  Outputs per pixel [N,H,W]: pix_to_face (packed face index, -1 = none), zbuf,
+ * bary_coords [N,H,W,3], dists (signed squared distance to the nearest edge, negative inside); -1 where empty.
+ * Ties in depth go to the lowest face index; the result does not depend on scheduling.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t recmv_rasterize_meshes_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t total_faces);
+int recmv_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces,
+                           int64_t N, int64_t total_faces, int64_t max_faces_per_mesh, int64_t H, int64_t W,
+                           float blur_radius, int perspective_correct, int cull_backfaces, int64_t* pix_to_face,
+                           float* zbuf, float* bary_coords, float* dists, void* workspace, int64_t workspace_bytes,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused linear-blend skinning on ray points and the root finder's per-ray step (csrc/lbs_fused.hip).
  *   replaces LBSkinner.forward with batch_inds (model/Deformer.py:405-445) and its input gradient, and the
  *   energy / update arithmetic of OptimizeGarmentSurfacePs (utils/FindSurfacePs.py:316-351), no autograd.

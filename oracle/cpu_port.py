@@ -56,6 +56,15 @@ class _MatmulTN:
         return A.t() @ B
 
 
+def _rasterize_meshes(face_verts, mesh_first_face, mesh_num_faces, image_size, blur_radius=0.0, faces_per_pixel=1,
+                      perspective_correct=True, clip_barycentric_coords=False, cull_backfaces=False,
+                      max_faces_per_mesh=None):
+    from recmv.raster import Fragments
+    assert faces_per_pixel == 1 and not clip_barycentric_coords
+    return Fragments(*orc.rasterize_meshes(face_verts, mesh_first_face, mesh_num_faces, image_size, blur_radius,
+                                           perspective_correct, cull_backfaces, scan=True))
+
+
 def install():
     import recmv.FastMinv as FM
     import recmv.GridSamplerMine as GS
@@ -63,13 +72,14 @@ def install():
     import recmv.interp2x_boundary3d as IP
     import recmv.loop as LP
     import recmv.ops as ops
+    import recmv.raster as RS
     import recmv.utils.utils as UU
     if _saved:
         return
     _saved.update(dict(la=ops.linear_act, nt=ops.MatmulNT, tn=ops.MatmulTN, gnt=ops.gemm_nt,
                        gf=GS.forward, gb=GS.backward, gd=GS.dbackward, fm=FM.Fast3x3Minv, fmb=FM.Fast3x3Minv_backward,
                        uu=UU.Fast3x3Minv, uub=UU.Fast3x3Minv_backward, lp=LP.Fast3x3Minv, ipf=IP.forward,
-                       ipb=IP.backward, mc=MC.mc_gpu))
+                       ipb=IP.backward, mc=MC.mc_gpu, rs=RS.rasterize_meshes))
     ops.linear_act, ops.MatmulNT, ops.MatmulTN, ops.gemm_nt = _linear_act, _MatmulNT, _MatmulTN, _gemm_nt
     GS.forward = lambda i, g, a, b: orc.gs3d_forward(i, g)
     GS.backward = lambda i, g, go, a, b, need_grad_input=True: orc.gs3d_backward(i, g, go, need_grad_input)
@@ -79,6 +89,7 @@ def install():
     FM.Fast3x3Minv_backward = UU.Fast3x3Minv_backward = orc.inv3x3_backward
     IP.forward, IP.backward = orc.interp2x_forward, orc.interp2x_backward
     MC.mc_gpu = orc.mc
+    RS.rasterize_meshes = _rasterize_meshes
 
 
 def uninstall():
@@ -88,6 +99,7 @@ def uninstall():
     import recmv.interp2x_boundary3d as IP
     import recmv.loop as LP
     import recmv.ops as ops
+    import recmv.raster as RS
     import recmv.utils.utils as UU
     if not _saved:
         return
@@ -98,4 +110,5 @@ def uninstall():
     LP.Fast3x3Minv = _saved['lp']
     IP.forward, IP.backward = _saved['ipf'], _saved['ipb']
     MC.mc_gpu = _saved['mc']
+    RS.rasterize_meshes = _saved['rs']
     _saved.clear()

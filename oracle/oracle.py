@@ -183,3 +183,26 @@ def mc(sdfs: torch.Tensor, xstep=1.0, ystep=1.0, zstep=1.0, xmin=0.0, ymin=0.0, 
     rc = f(*args, _p(verts), _p(faces), counts)
     assert rc == 0
     return [verts, faces]
+
+
+# ------------------------------------------------------------------------------------ mesh rasteriser
+def rasterize_meshes(face_verts, mesh_first_face, mesh_num_faces, image_size, blur_radius=0.0,
+                     perspective_correct=True, cull_backfaces=False, scan=False):
+    """pytorch3d `rasterize_meshes(..., faces_per_pixel=1)` contract on packed NDC face vertices [F,3,3]:
+    returns (pix_to_face [N,H,W,1] int64, zbuf [N,H,W,1], bary_coords [N,H,W,1,3], dists [N,H,W,1]); -1 = empty.
+    scan=True runs the face-ordered CPU port (same answer; the variant bench.py's cpu_baseline times)."""
+    fv = _cpu(face_verts).contiguous().float()
+    first = _cpu(mesh_first_face).contiguous().long()
+    num = _cpu(mesh_num_faces).contiguous().long()
+    H, W = image_size
+    N = first.numel()
+    p2f = torch.empty(N, H, W, 1, dtype=torch.int64)
+    zbuf = torch.empty(N, H, W, 1, dtype=torch.float32)
+    bary = torch.empty(N, H, W, 1, 3, dtype=torch.float32)
+    dists = torch.empty(N, H, W, 1, dtype=torch.float32)
+    fn = lib().oracle_rasterize_meshes_scan if scan else lib().oracle_rasterize_meshes
+    rc = fn(_p(fv), _p(first), _p(num), C.c_int64(N), C.c_int64(H), C.c_int64(W),
+                                       C.c_float(blur_radius), C.c_int(int(perspective_correct)),
+                                       C.c_int(int(cull_backfaces)), _p(p2f), _p(zbuf), _p(bary), _p(dists))
+    assert rc == 0
+    return p2f, zbuf, bary, dists

@@ -168,3 +168,160 @@ int oracle_mc(const float* sdf, int64_t NX, int64_t NY, int64_t NZ, float iso, f
   counts[1] = nf;
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Mesh rasteriser, one face per pixel — the fragments `maskRender` gives `utils.FindSurfacePs`
+ * (engineer/networks/OptimGarmentNetwork.py:742-767, utils/FindSurfacePs.py:7-37).
+ *
+ * PARITY UNPINNED against the real thing: the reference calls pytorch3d 0.4.0
+ * (`rasterize_meshes`, settings at OptimGarmentNetwork.py:2336-2347: faces_per_pixel=1, blur_radius=0,
+ * perspective_correct=True, clip_barycentric_coords=False), which is not vendored in /root/reference and not
+ * installed here.  This restates its published per-pixel algorithm (RasterizeMeshesNaive: every pixel loops over
+ * the faces of its mesh in order and keeps the nearest; geometry helpers of csrc/utils/geometry_utils.h) with the
+ * reference's pixel convention (model/CameraMine.py:132-142: pixel i is centred at NDC 1-(2i+1)/S).
+ * One deliberate deviation: a candidate whose interpolated depth is NaN is dropped (upstream keeps it).
+ * ------------------------------------------------------------------------------------------- */
+#define RAST_EPS 1e-8f
+
+static float rast_edge(float px, float py, float ax, float ay, float bx, float by) {
+  return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
+static float rast_point_line(float px, float py, float ax, float ay, float bx, float by) {
+  float bax = bx - ax, bay = by - ay;
+  float l2 = bax * bax + bay * bay;
+  if (l2 <= RAST_EPS) return (px - bx) * (px - bx) + (py - by) * (py - by);
+  float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+  float tt = fminf(fmaxf(t, 0.f), 1.f);
+  float qx = ax + tt * bax, qy = ay + tt * bay;
+  return (px - qx) * (px - qx) + (py - qy) * (py - qy);
+}
+
+static float rast_min3(float a, float b, float c) { return fminf(fminf(a, b), c); }
+static float rast_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+/* One (pixel centre, face) test of CheckPixelInsideFace; returns 0 when the face does not cover the pixel. */
+static int rast_pair(const float* v, float px, float py, float blur_radius, int perspective_correct,
+                     int cull_backfaces, float* out /* z, dist, b0, b1, b2 */) {
+  const float br = sqrtf(blur_radius);
+  const float x0 = v[0], y0 = v[1], z0 = v[2], x1 = v[3], y1 = v[4], z1 = v[5], x2 = v[6], y2 = v[7], z2 = v[8];
+  const float xmin = rast_min3(x0, x1, x2) - br, xmax = rast_max3(x0, x1, x2) + br;
+  const float ymin = rast_min3(y0, y1, y2) - br, ymax = rast_max3(y0, y1, y2) + br;
+  const float zmax = rast_max3(z0, z1, z2);
+  const int outside = (px < xmin || px > xmax || py < ymin || py > ymax);
+  const float face_area = rast_edge(x0, y0, x1, y1, x2, y2);
+  const int back_face = face_area < 0.f;
+  const int zero_area = (face_area <= RAST_EPS && face_area >= -RAST_EPS);
+  if (zmax < 0.f || (cull_backfaces && back_face) || outside || zero_area || face_area != face_area) return 0;
+  const float area = rast_edge(x2, y2, x0, y0, x1, y1) + RAST_EPS;
+  const float w0 = rast_edge(px, py, x1, y1, x2, y2) / area;
+  const float w1 = rast_edge(px, py, x2, y2, x0, y0) / area;
+  const float w2 = rast_edge(px, py, x0, y0, x1, y1) / area;
+  float b0 = w0, b1 = w1, b2 = w2;
+  if (perspective_correct) {
+    const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+    const float denom = fmaxf(t0 + t1 + t2, RAST_EPS);
+    b0 = t0 / denom;
+    b1 = t1 / denom;
+    b2 = t2 / denom;
+  }
+  const float pz = b0 * z0 + b1 * z1 + b2 * z2;
+  if (pz < 0.f || pz != pz) return 0;
+  const float e01 = rast_point_line(px, py, x0, y0, x1, y1);
+  const float e02 = rast_point_line(px, py, x0, y0, x2, y2);
+  const float e12 = rast_point_line(px, py, x1, y1, x2, y2);
+  const float dist = fminf(fminf(e01, e02), e12);
+  const int inside = w0 > 0.f && w1 > 0.f && w2 > 0.f;
+  if (!inside && dist >= blur_radius) return 0;
+  out[0] = pz + 0.f;
+  out[1] = inside ? -dist : dist;
+  out[2] = b0;
+  out[3] = b1;
+  out[4] = b2;
+  return 1;
+}
+
+/* The checker: every pixel loops over every face of its mesh, in order (RasterizeMeshesNaive). */
+int oracle_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_face, const int64_t* mesh_num_faces,
+                            int64_t N, int64_t H, int64_t W, float blur_radius, int perspective_correct,
+                            int cull_backfaces, int64_t* pix_to_face, float* zbuf, float* bary, float* dists) {
+  if (N < 0 || H <= 0 || W <= 0) return -1;
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t i = 0; i < N * H * W; ++i) {
+    const int64_t n = i / (H * W), pix = i % (H * W);
+    /* upstream flips both axes: output pixel (r, c) looks through NDC (1-(2c+1)/W, 1-(2r+1)/H) */
+    const int64_t r = pix / W, c = pix % W;
+    const float px = 1.f - (2.f * (float)c + 1.f) / (float)W;
+    const float py = 1.f - (2.f * (float)r + 1.f) / (float)H;
+    int64_t best = -1;
+    float q[5] = {-1.f, -1.f, -1.f, -1.f, -1.f}, cand[5];
+    for (int64_t f = mesh_first_face[n]; f < mesh_first_face[n] + mesh_num_faces[n]; ++f) {
+      if (!rast_pair(face_verts + 9 * f, px, py, blur_radius, perspective_correct, cull_backfaces, cand)) continue;
+      /* K = 1 queue: the first candidate enters, a later one replaces it only when strictly nearer */
+      if (best < 0 || cand[0] < q[0]) {
+        best = f;
+        memcpy(q, cand, sizeof(q));
+      }
+    }
+    pix_to_face[i] = best;
+    zbuf[i] = q[0];
+    dists[i] = q[1];
+    bary[3 * i] = q[2];
+    bary[3 * i + 1] = q[3];
+    bary[3 * i + 2] = q[4];
+  }
+  return 0;
+}
+
+/* The CPU port timed as `cpu_baseline` (bench.py): same pair test, but organised the way a CPU scan converter is —
+ * every face visits only the pixel centres of its bounding box; threads own bands of rows, so no locking and the same
+ * answer as the per-pixel loop (faces are visited in index order inside a band). */
+int oracle_rasterize_meshes_scan(const float* face_verts, const int64_t* mesh_first_face,
+                                 const int64_t* mesh_num_faces, int64_t N, int64_t H, int64_t W, float blur_radius,
+                                 int perspective_correct, int cull_backfaces, int64_t* pix_to_face, float* zbuf,
+                                 float* bary, float* dists) {
+  if (N < 0 || H <= 0 || W <= 0) return -1;
+  const float br = sqrtf(blur_radius);
+  const int64_t band = 8, nbands = (H + band - 1) / band;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+  for (int64_t n = 0; n < N; ++n) {
+    for (int64_t bi = 0; bi < nbands; ++bi) {
+      const int64_t rlo = bi * band, rhi = (rlo + band < H ? rlo + band : H) - 1;
+      for (int64_t i = (n * H + rlo) * W; i < (n * H + rhi + 1) * W; ++i) {
+        pix_to_face[i] = -1;
+        zbuf[i] = dists[i] = -1.f;
+        bary[3 * i] = bary[3 * i + 1] = bary[3 * i + 2] = -1.f;
+      }
+      for (int64_t f = mesh_first_face[n]; f < mesh_first_face[n] + mesh_num_faces[n]; ++f) {
+        const float* v = face_verts + 9 * f;
+        const float ylo = rast_min3(v[1], v[4], v[7]) - br, yhi = rast_max3(v[1], v[4], v[7]) + br;
+        const float xlo = rast_min3(v[0], v[3], v[6]) - br, xhi = rast_max3(v[0], v[3], v[6]) + br;
+        if (!(ylo == ylo && yhi == yhi && xlo == xlo && xhi == xhi)) continue;
+        /* centre(i) = 1 - (2i+1)/S in [lo, hi]; widened by one pixel, the pair test decides */
+        double r0d = floor(((double)H * (1.0 - yhi) - 1.0) * 0.5) - 1.0, r1d = ceil(((double)H * (1.0 - ylo) - 1.0) * 0.5) + 1.0;
+        double c0d = floor(((double)W * (1.0 - xhi) - 1.0) * 0.5) - 1.0, c1d = ceil(((double)W * (1.0 - xlo) - 1.0) * 0.5) + 1.0;
+        int64_t r0 = r0d < (double)rlo ? rlo : (r0d > (double)H ? H : (int64_t)r0d);
+        int64_t r1 = r1d > (double)rhi ? rhi : (r1d < -1.0 ? -1 : (int64_t)r1d);
+        int64_t c0 = c0d < 0.0 ? 0 : (c0d > (double)W ? W : (int64_t)c0d);
+        int64_t c1 = c1d > (double)(W - 1) ? W - 1 : (c1d < -1.0 ? -1 : (int64_t)c1d);
+        for (int64_t r = r0; r <= r1; ++r)
+          for (int64_t c = c0; c <= c1; ++c) {
+            const float px = 1.f - (2.f * (float)c + 1.f) / (float)W;
+            const float py = 1.f - (2.f * (float)r + 1.f) / (float)H;
+            float cand[5];
+            if (!rast_pair(v, px, py, blur_radius, perspective_correct, cull_backfaces, cand)) continue;
+            const int64_t i = (n * H + r) * W + c;
+            if (pix_to_face[i] < 0 || cand[0] < zbuf[i]) {
+              pix_to_face[i] = f;
+              zbuf[i] = cand[0];
+              dists[i] = cand[1];
+              bary[3 * i] = cand[2];
+              bary[3 * i + 1] = cand[3];
+              bary[3 * i + 2] = cand[4];
+            }
+          }
+      }
+    }
+  }
+  return 0;
+}

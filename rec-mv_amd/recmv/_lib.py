@@ -16,7 +16,7 @@ _PKG = Path(__file__).resolve().parent.parent          # rec-mv_amd/
 LIB_PATH = _PKG / "lib" / "librecmv_hip.so"
 
 RECMV_OK = 0
-ABI_VERSION = 2          # include/recmv_hip.h; bumped when a signature changes (v2: recmv_mc_count / recmv_mc_emit)
+ABI_VERSION = 3          # include/recmv_hip.h; bumped when a signature changes (v2: recmv_mc_count / recmv_mc_emit)
 F32, F64 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = 0, 1, 2, 3
 
@@ -110,6 +110,9 @@ def _declare(lib):
         "recmv_lbs_vjp_input": (C.c_int, [vp, vp, i64, vp, i64, C.POINTER(LbsGrid), vp, vp, vp]),
         "recmv_lbs_vjp_params_stage": (C.c_int, [vp, vp, i64, i64, C.POINTER(LbsGrid), vp, vp, vp, vp, vp]),
         "recmv_rootfind_update": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
+        "recmv_rasterize_meshes_workspace_bytes": (i64, [i64, i64, i64, i64]),
+        "recmv_rasterize_meshes": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, f32, i32, i32, vp, vp, vp, vp, vp,
+                                             i64, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)       # AttributeError if the symbol is missing: fail loudly

@@ -14,14 +14,15 @@ OptimGarmentNetwork.py:1885-1969) -> `loss.backward()` -> `propagateTmpPsGrad` (
   dct_poses_loss        :1221-1250 (pose smoothness on 30-frame windows)
   propagateTmpPsGrad    :2159-2313 implicit differentiation of the surface point
 
-What is NOT here, and why: the pytorch3d mesh/point rasterisers and alpha
-compositor are third-party code outside /root/reference and outside this tier's scope.  Their two uses are
-replaced by projections that keep every hot-path call and every gradient path in place:
+What is NOT here, and why: pytorch3d's POINT rasteriser + alpha compositor (the splatted
+silhouette of `compute_garment_pc_loss`) is third-party code outside /root/reference and outside this tier's scope;
+it is replaced by a projection that keeps every hot-path call and every gradient path in place:
   * silhouette IoU of the splatted point cloud -> a differentiable distance-to-mask term sampled at the
     projected deformed vertices (same inputs: deformed vertices; same gradient sinks: explicit vertices,
-    deformer parameters, per-frame codes, poses);
-  * first-hit surface points of the rasterised mesh -> MC vertices projected to their nearest pixel centre
-    (so the root finder starts within half a pixel of the surface, like a barycentric hit).
+    deformer parameters, per-frame codes, poses).
+The MESH rasteriser of `find_surface_ps` is here (recmv/raster.py on csrc/rasterize_meshes.hip): the visible canonical
+surface points come from first-hit fragments + `utils.FindSurfacePs`, and `sample_train_ray` draws its Bernoulli
+subset of them with the host RNG exactly like the reference (:1020).
 The feature-curve branch (`project_2d_loss`, "next" row 3) is likewise outside this tier.
 The CPU SVD of the deformer Jacobians (:1148, a host round trip per garment per iteration) is replaced by
 closed-form singular values on the device (`singular_values_3x3`).
@@ -38,6 +39,7 @@ import torch
 import torch.nn.functional as F
 
 from . import MCGpu
+from . import raster
 from . import utils
 from .FastMinv import Fast3x3Minv
 from .MCAcc import Seg3dLossless
@@ -158,6 +160,14 @@ class SyntheticFrames:
         sl = frame_ids % self.n_img
         return self.img[sl], self.normal[sl]
 
+    def garment_masks(self, g_i, frame_ids):
+        """Ground-truth garment segmentation of the batch's frames [N,H,W] (datas['upper'] / ['bottom'],
+        OptimGarmentNetwork.py:1896-1902).  Synthetic frames: everything is garment, so every rasterised surface pixel
+        passes the `gt > 0` selection of sample_train_ray (:1013) — the gather itself still runs."""
+        if getattr(self, '_mask', None) is None:
+            self._mask = torch.ones(self.n_img, self.H, self.W, device=self.device)
+        return self._mask[frame_ids % self.n_img]
+
 
 class _CondPair:
     """dataset.conds[0] / [1] = the per-frame deformer / colour codes, assignable (utils/utils.py:386-387)."""
@@ -196,11 +206,20 @@ class HotLoop:
             r = max(_zero_level_radius(n, device) for n in self.garment_nets)
             h = 1.45 * r
             bbox = ((-h, -1.44 * h, -h), (h, 1.44 * h, h))
-        g = torch.Generator().manual_seed(seed + 1)
         D, Hh, Ww = skin_grid
-        ws = torch.softmax(2.0 * torch.randn(1, 24, D, Hh, Ww, generator=g), dim=1)
-        Js = 0.25 * torch.randn(24, 3, generator=g)
         bmin, bmax = bbox
+        # Synthetic rig: a 24-joint skeleton that fits the canonical box and SMOOTH blend weights (softmax of the
+        # squared distance to the joints), like the diffused SMPL weights the reference bakes into its volume
+        # (model/Deformer.py:289-330).  Smoothness matters for the workload: neighbouring surface points must stay
+        # neighbours after skinning, or the rasterised first hits are no starting points for the root finder.
+        Js = _skeleton(0.5 * (bmax[1] - bmin[1]) / 1.44 / 1.45)
+        axes = [torch.linspace(bmin[i], bmax[i], n + 1)[:-1] + 0.5 * (bmax[i] - bmin[i]) / n
+                for i, n in ((2, D), (1, Hh), (0, Ww))]                       # voxel centres, align_corners=False
+        zz, yy, xx = torch.meshgrid(*axes, indexing='ij')
+        vox = torch.stack([xx, yy, zz], dim=-1)                                # [D,H,W,3] (x,y,z)
+        d2 = (torch.cdist(vox.view(-1, 3), Js) ** 2).view(D, Hh, Ww, 24)
+        sigma = 0.12 * (bmax[1] - bmin[1]) / 1.44 / 1.45
+        ws = torch.softmax(-d2 / (2.0 * sigma * sigma), dim=-1).permute(3, 0, 1, 2).unsqueeze(0).contiguous()
         skinner = LBSkinner(ws, list(bmin), list(bmax), Js, SMPL_PARENTS, init_pose=_apose(), align_corners=False,
                             bbox_extend=torch.tensor([bmax[i] - bmin[i] for i in range(3)]),
                             bbox_center=torch.tensor([(bmax[i] + bmin[i]) / 2 for i in range(3)]))
@@ -372,6 +391,12 @@ class HotLoop:
                 closs = utils.GMRobustError(offset2, cc, True).mean() if cc > 0. else torch.sqrt(offset2).mean()
                 loss = loss + closs * cw
             garment_loss = garment_loss + loss
+        # find_surface_ps reads the deformed meshes and the PRE-step vertices (:918 runs before the SGD step): take
+        # the snapshot here, rasterise later on a side stream while the backward below keeps the device busy
+        self._surface_inputs = ([d.detach() for d in def_vs], [v.detach().clone() for v in self.garment_vs])
+        self._surface_ready = torch.cuda.Event() if torch.device(self.device).type == 'cuda' else None
+        if self._surface_ready is not None:
+            self._surface_ready.record()
         self.garment_optimizer.zero_grad()
         garment_loss.backward()                    # grads also reach deformer / codes / poses and stay for Adam (:959)
         if getattr(self, '_allreduce', None) is not None:
@@ -386,23 +411,55 @@ class HotLoop:
         return [d.detach() for d in def_vs], pc_sdf_loss
 
     # ------------------------------------------------------------------------------------------ rays
-    def sample_train_ray(self, N, def_vs, cameras):
-        """Stand-in for find_surface_ps + sample_train_ray (:742-767, :983-1055): per garment, ~sample_pix/garments
-        rays per frame through MC vertices snapped to their nearest pixel centre."""
+    def find_surface_ps(self, def_vs, tmp_vs, cameras):
+        """OptimGarmentNetwork.py:742-767: per garment, rasterise the N deformed meshes and turn the first-hit
+        fragments into (batch, row, col, canonical point, face) of every covered pixel."""
+        rast = raster.MeshRasterizer(cameras, (self.dataset.H, self.dataset.W), blur_radius=0.,
+                                     perspective_correct=True, cull_backfaces=False)             # :2336-2347
+        out = []
+        with torch.no_grad():
+            for def_v, gv, gf in zip(def_vs, tmp_vs, self.garment_fs):
+                out.append(utils.FindSurfacePs(gv, gf, rast(def_v, gf)))
+        return out
+
+    def sample_train_ray(self, N, frame_ids, cameras):
+        """find_surface_ps + sample_train_ray (:742-767, :983-1055).  Runs on a side stream: `nonzero` inside
+        FindSurfacePs waits for the rasteriser only, not for the mask-loss backward queued on the main stream."""
         sample_pix = self.conf.get_int('sample_pix_num') if 'sample_pix_num' in self.conf else self.sample_pix
         sample_pix = sample_pix // self.garment_size
-        H, W = self.dataset.H, self.dataset.W
+        def_vs, tmp_vs = self._surface_inputs
+        cuda = torch.device(self.device).type == 'cuda'
+        if cuda:
+            main = torch.cuda.current_stream(self.device)
+            if getattr(self, '_surface_stream', None) is None:
+                self._surface_stream = torch.cuda.Stream(device=self.device)
+            side = self._surface_stream
+            side.wait_event(self._surface_ready)
+        ctx = torch.cuda.stream(side) if cuda else contextlib.nullcontext()
         out = []
-        for g_i in range(self.garment_size):
-            V = self.garment_vs[g_i].shape[0]
-            R = min(sample_pix, V)
-            vid = torch.stack([torch.randperm(V, device=self.device)[:R] for _ in range(N)]).view(-1)
-            batch_inds = torch.arange(N, device=self.device).repeat_interleave(R)
-            pix = cameras.project(def_vs[g_i][batch_inds, vid])
-            col = pix[:, 0].round().clamp(0, W - 1)
-            row = pix[:, 1].round().clamp(0, H - 1)
-            rays = cameras.view_rays(torch.stack([col, row, torch.ones_like(col)], dim=-1).float())
-            out.append((batch_inds, row.long(), col.long(), self.garment_vs[g_i].detach()[vid].clone(), rays))
+        with ctx, torch.no_grad():
+            found = self.find_surface_ps(def_vs, tmp_vs, cameras)
+            for g_i, (batch_inds, row_inds, col_inds, init_pts, _faces) in enumerate(found):
+                gt = self.dataset.garment_masks(g_i, frame_ids)                         # :1013-1018
+                keep = (gt[batch_inds, row_inds, col_inds] > 0.).nonzero(as_tuple=True)[0]
+                batch_inds, row_inds, col_inds, init_pts = (t[keep] for t in (batch_inds, row_inds, col_inds,
+                                                                              init_pts))
+                pnum = batch_inds.shape[0]
+                if pnum > sample_pix * N:                                               # :1019-1027, host RNG
+                    sel = torch.rand(pnum) < float(sample_pix * N) / float(pnum)
+                    idx = sel.nonzero(as_tuple=True)[0].to(batch_inds.device, non_blocking=False)
+                    batch_inds, row_inds, col_inds, init_pts = (t[idx] for t in (batch_inds, row_inds, col_inds,
+                                                                                 init_pts))
+                rays = cameras.view_rays(torch.cat([col_inds.view(-1, 1), row_inds.view(-1, 1),
+                                                    torch.ones_like(col_inds.view(-1, 1))], dim=-1).float())
+                out.append((batch_inds, row_inds, col_inds, init_pts.contiguous(), rays))
+        if cuda:
+            main.wait_stream(side)
+            for sample in out:
+                for t in sample:
+                    t.record_stream(main)
+        self._surface_inputs = None
+        self.info['surface_pixels'] = [int(f[0].shape[0]) for f in found]
         return out
 
     def opt_garment_surface_ps(self, frame_ids, cameras, ratio, samples):
@@ -457,7 +514,9 @@ class HotLoop:
                 total_loss = total_loss + def_loss * conf.get_float('def_regu.weight')
             check = checks[g_i]
             # the reference gates on rayInfo[1] > 0 via .item(); the gate is kept but read once per garment
-            if int(self._ray_valid[g_i]) > 0:
+            n_valid = int(self._ray_valid[g_i])
+            self.info.setdefault('rays_converged', []).append(n_valid)
+            if n_valid > 0:
                 self.TmpPs[g_i] = init_ps[check]
                 self.TmpPs[g_i].requires_grad = True
                 self.rays[g_i] = rays[check]
@@ -534,7 +593,7 @@ class HotLoop:
         d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
         cameras = self._cameras()                                                          # rebuilt graph (:1036)
         with self._phase('sample_rays'):
-            samples = self.sample_train_ray(N, def_vs, cameras)
+            samples = self.sample_train_ray(N, frame_ids, cameras)
         with self._phase('root_find'):
             init_ps_list, checks = self.opt_garment_surface_ps(frame_ids, cameras, ratio, samples)
         with self._phase('render_loss_fwd'):
@@ -692,6 +751,20 @@ def _zero_level_radius(net, device, ndir=64, iters=24):
         lo = torch.where(inside, mid, lo)
         hi = torch.where(inside, hi, mid)
     return float((0.5 * (lo + hi)).mean())
+
+
+def _skeleton(radius):
+    """24 joints in the SMPL order (pelvis, hips, spine, knees, ... hands), a generic standing figure scaled so that
+    it fits inside the initial SDF sphere of the given radius."""
+    j = torch.tensor([
+        [0.00, 0.00, 0.00], [0.07, -0.09, 0.00], [-0.07, -0.09, 0.00], [0.00, 0.11, -0.02],
+        [0.10, -0.47, 0.00], [-0.10, -0.47, 0.00], [0.00, 0.25, 0.00], [0.09, -0.87, -0.03],
+        [-0.09, -0.87, -0.03], [0.00, 0.30, 0.02], [0.11, -0.93, 0.09], [-0.11, -0.93, 0.09],
+        [0.00, 0.51, -0.01], [0.08, 0.42, 0.00], [-0.08, 0.42, 0.00], [0.00, 0.60, 0.03],
+        [0.19, 0.44, -0.01], [-0.19, 0.44, -0.01], [0.45, 0.43, -0.03], [-0.45, 0.43, -0.03],
+        [0.70, 0.43, -0.03], [-0.70, 0.43, -0.03], [0.79, 0.42, -0.04], [-0.79, 0.42, -0.04]])
+    j = j - torch.tensor([0.0, -0.16, 0.0])                 # centre the figure (feet -0.93 .. head 0.60)
+    return j * (radius / 0.80)
 
 
 def _apose():

@@ -43,6 +43,20 @@ class RectifiedPerspectiveCameras:
         y = self.principal_point[cam_id, 1] - ps[:, 1] * self.focal_length[cam_id, 1] / ps[:, 2]
         return torch.cat([x.view(-1, 1), y.view(-1, 1)], dim=1)
 
+    def transform_points_ndc(self, ps, cam_id=0):
+        """World points [P,3] -> (x_ndc, y_ndc, z_view): the full projection of the reference camera with its own
+        calibration matrix (model/CameraMine.py:62-88, 281-300: fx' = fx/(W/2), px' = 1 - 1/W - px/(W/2), rows
+        [fx',0,px',0],[0,fy',py',0]), so that pixel column c is hit by the ray of `view_rays((c, r, 1))`."""
+        v = (ps.unsqueeze(-1) * self.R[cam_id].unsqueeze(0)).sum(-2) + self.T[cam_id].view(1, 3)
+        W = float(self.image_size[cam_id, 0])          # host tensor: no device round trip
+        H = float(self.image_size[cam_id, 1])
+        fx = self.focal_length[cam_id, 0] / (W / 2.0)
+        fy = self.focal_length[cam_id, 1] / (H / 2.0)
+        px = 1. - 1. / W - self.principal_point[cam_id, 0] / (W / 2.0)
+        py = 1. - 1. / H - self.principal_point[cam_id, 1] / (H / 2.0)
+        z = v[:, 2]
+        return torch.stack([(fx * v[:, 0] + px * z) / z, (fy * v[:, 1] + py * z) / z, z], dim=1)
+
     def angThreshold(self, pixoffset=0.4, cam_id=0):
         """Smallest angle (degrees) subtended by `pixoffset` pixels at the image border
         (CameraMine.py:176-205)."""

@@ -30,7 +30,10 @@ def test_loop_two_steps_on_cpu_port():
         loop = _tiny_loop()
         before = [p.detach().clone() for p in loop.shared_parameters()]
         l0, rays = loop.step(0)
-        assert torch.isfinite(l0) and rays == 2 * 3 * 16
+        # rays: a Bernoulli(sample_pix * N / pixels) subset of the rasterised surface pixels of each garment
+        # (OptimGarmentNetwork.py:1019-1027): expectation 2 garments x 3 frames x 16, binomial spread
+        assert torch.isfinite(l0) and 40 <= rays <= 160
+        assert all(n > 3 * 16 for n in loop.info['surface_pixels']), "each garment covers more pixels than it samples"
         assert loop.body_vs.shape[0] > 0 and all(v.shape[0] > 0 for v in loop.garment_vs)
         for name in loop.garment_names:
             assert f'{name}_grad_loss' in loop.info and f'pc_{name}_loss_sdf' in loop.info

@@ -135,6 +135,37 @@ def bench_mc(quick):
         report(f"mc_emit {n}^3", t, b, nbytes=12 * V + 24 * Fc)
 
 
+def bench_raster(quick):
+    """First-hit rasteriser on an MC mesh, 3 frames of 512x512 (the loop's find_surface_ps shape)."""
+    from recmv import MCGpu, raster
+    from recmv.model import RectifiedPerspectiveCameras
+    for n in ([193] if quick else [129, 193, 257]):
+        vol = body_like_volume(n)
+        step = 2.0 / (n - 1)
+        v, f = MCGpu.mc_gpu(vol, step, step, step, -1.0, -1.0, -1.0, 0.0)
+        H = W = 512
+        cam = RectifiedPerspectiveCameras(torch.tensor([[1000., 1000.]], device=DEV),
+                                          torch.tensor([[256., 256.]], device=DEV),
+                                          torch.diag(torch.tensor([-1., -1., 1.])).view(1, 3, 3).to(DEV),
+                                          torch.tensor([[0., 0., 3.]], device=DEV), image_size=[(W, H)])
+        N = 3
+        def_vs = (0.55 * v)[None].repeat(N, 1, 1) + 0.02 * torch.arange(N, device=DEV).view(N, 1, 1)
+        rast = raster.MeshRasterizer(cam, (H, W))
+        frags = rast(def_vs, f)
+        covered = int((frags.pix_to_face >= 0).sum())
+        ndc = cam.transform_points_ndc(def_vs.reshape(-1, 3)).view(N, -1, 3)
+        fv = ndc[:, f.reshape(-1)].reshape(-1, 3, 3).contiguous()
+        F = f.shape[0]
+        first = torch.arange(N, device=DEV) * F
+        num = torch.full((N,), F, device=DEV, dtype=torch.int64)
+        t, b = timeit(lambda: raster.rasterize_meshes(fv, first, num, (H, W), max_faces_per_mesh=F))
+        # algorithmic bytes: 36 B per face + per pixel 8 B key write/read + 32 B of outputs
+        report(f"rasterize_meshes {N}x{H}x{W}, {F} faces/mesh", t, b, nbytes=36 * N * F + N * H * W * (16 + 32),
+               faces=N * F, covered_pixels=covered)
+        t, b = timeit(lambda: rast(def_vs, f))
+        report(f"MeshRasterizer (project + gather + rasterise) {N}x{H}x{W}", t, b, faces=N * F)
+
+
 def bench_gemm(quick):
     from recmv import ops
     shapes = [(460800, 512, 512), (153600, 512, 512), (6144, 512, 512), (3072, 512, 512), (153600, 512, 39), (153600, 257, 512),
@@ -182,7 +213,7 @@ def bench_sdf(quick):
     report(f"sdf_mlp fwd+bwd(theta,x) autograd path P={P}", t, b, flops=3 * flop_pt * P)
 
 
-ALL = {"inv": bench_inv, "sampler": bench_sampler, "interp": bench_interp, "mc": bench_mc, "gemm": bench_gemm,
+ALL = {"inv": bench_inv, "sampler": bench_sampler, "interp": bench_interp, "mc": bench_mc, "raster": bench_raster, "gemm": bench_gemm,
        "sdf": bench_sdf}
 
 if __name__ == "__main__":

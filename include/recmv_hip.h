@@ -276,6 +276,39 @@ int recmv_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_fa
                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Point-cloud rasteriser + alpha compositor, forward and backward (csrc/rasterize_points.hip).
+ *   replaces `self.pcRender(Pointclouds(...))` of the mask loss (engineer/networks/OptimGarmentNetwork.py:937;
+ *   PointsRendererWithFrags(_Split) model/CameraMine.py:306-415; settings engineer/networks/OptimNetwork.py:87-100:
+ *   points_per_pixel = 50, radius 0.006 / 0.00465 / 0.0041) = pytorch3d 0.4.0 `rasterize_points` +
+ *   `alpha_composite` and their backward passes.
+ * points [total_points,3] f32: NDC x, y (same pixel convention as recmv_rasterize_meshes) and view depth z, clouds
+ * packed one after another; cloud n owns points [cloud_first_point[n], +cloud_num_points[n]) (device int64 [N]).
+ * Fragments, all [N,H,W,K] with K = points_per_pixel, K fastest: idx (packed point index, int32, -1 = none), zbuf,
+ * dists (squared NDC distance of the point to the pixel centre; a point is listed when it is < radius^2 and z >= 0),
+ * the K nearest in depth, sorted by (depth, index), packed to the front.
+ *   recmv_rasterize_points_backward : grad_points [total_points,3] = d/dpoints of (grad_dists . dists + grad_zbuf . zbuf)
+ *                                     (grad_zbuf may be NULL); accumulates with float atomics.
+ *   recmv_alpha_composite_forward   : images [N,C,H,W]; images[n,c,y,x] = sum_k a_k prod_{l<k}(1 - a_l) features[c,idx_k]
+ *                                     with alphas [N,H,W,K] (the caller's 1 - dists/radius^2) and features [C,total_points].
+ *   recmv_alpha_composite_backward  : grad_alphas [N,H,W,K] (no atomics); grad_features [C,total_points] or NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t recmv_rasterize_points_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t total_points, float radius);
+int recmv_rasterize_points(const float* points, const int64_t* cloud_first_point, const int64_t* cloud_num_points,
+                           int64_t N, int64_t total_points, int64_t max_points_per_cloud, int64_t H, int64_t W,
+                           float radius, int points_per_pixel, int32_t* idx, float* zbuf, float* dists,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+int recmv_rasterize_points_backward(const float* points, const int32_t* idx, const float* grad_dists,
+                                    const float* grad_zbuf, int64_t N, int64_t total_points, int64_t H, int64_t W,
+                                    int points_per_pixel, float* grad_points, void* stream);
+int recmv_alpha_composite_forward(const int32_t* idx, const float* alphas, const float* features, int64_t N,
+                                  int64_t H, int64_t W, int points_per_pixel, int64_t C, int64_t total_points,
+                                  float* images, void* stream);
+int recmv_alpha_composite_backward(const int32_t* idx, const float* alphas, const float* features,
+                                   const float* grad_images, int64_t N, int64_t H, int64_t W, int points_per_pixel,
+                                   int64_t C, int64_t total_points, float* grad_alphas, float* grad_features,
+                                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused linear-blend skinning on ray points and the root finder's per-ray step (csrc/lbs_fused.hip).
  *   replaces LBSkinner.forward with batch_inds (model/Deformer.py:405-445) and its input gradient, and the
  *   energy / update arithmetic of OptimizeGarmentSurfacePs (utils/FindSurfacePs.py:316-351), no autograd.

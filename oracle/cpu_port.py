@@ -65,6 +65,40 @@ def _rasterize_meshes(face_verts, mesh_first_face, mesh_num_faces, image_size, b
                                            perspective_correct, cull_backfaces, scan=True))
 
 
+class _RasterizePointsCPU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, first, num, H, W, radius, K):
+        idx, zbuf, dists = orc.rasterize_points(points.detach(), first, num, (H, W), radius, K, scan=True)
+        ctx.save_for_backward(points.detach(), idx)
+        ctx.mark_non_differentiable(idx)
+        return idx, zbuf, dists
+
+    @staticmethod
+    def backward(ctx, _gi, g_zbuf, g_dists):
+        points, idx = ctx.saved_tensors
+        return orc.rasterize_points_backward(points, idx, g_dists, g_zbuf), None, None, None, None, None, None
+
+
+def _rasterize_points(points, cloud_first_point, cloud_num_points, image_size, radius, points_per_pixel=8,
+                      max_points_per_cloud=None):
+    from recmv.raster import PointFragments
+    return PointFragments(*_RasterizePointsCPU.apply(points, cloud_first_point, cloud_num_points, int(image_size[0]),
+                                                     int(image_size[1]), float(radius), int(points_per_pixel)))
+
+
+class _AlphaCompositeCPU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, alphas, features):
+        ctx.save_for_backward(idx, alphas.detach(), features.detach())
+        return orc.alpha_composite_forward(idx, alphas.detach(), features.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, alphas, features = ctx.saved_tensors
+        ga, gf = orc.alpha_composite_backward(idx, alphas, features, g, ctx.needs_input_grad[2])
+        return None, ga, gf
+
+
 def install():
     import recmv.FastMinv as FM
     import recmv.GridSamplerMine as GS
@@ -79,7 +113,8 @@ def install():
     _saved.update(dict(la=ops.linear_act, nt=ops.MatmulNT, tn=ops.MatmulTN, gnt=ops.gemm_nt,
                        gf=GS.forward, gb=GS.backward, gd=GS.dbackward, fm=FM.Fast3x3Minv, fmb=FM.Fast3x3Minv_backward,
                        uu=UU.Fast3x3Minv, uub=UU.Fast3x3Minv_backward, lp=LP.Fast3x3Minv, ipf=IP.forward,
-                       ipb=IP.backward, mc=MC.mc_gpu, rs=RS.rasterize_meshes))
+                       ipb=IP.backward, mc=MC.mc_gpu, rs=RS.rasterize_meshes, rp=RS.rasterize_points,
+                       ac=RS.alpha_composite))
     ops.linear_act, ops.MatmulNT, ops.MatmulTN, ops.gemm_nt = _linear_act, _MatmulNT, _MatmulTN, _gemm_nt
     GS.forward = lambda i, g, a, b: orc.gs3d_forward(i, g)
     GS.backward = lambda i, g, go, a, b, need_grad_input=True: orc.gs3d_backward(i, g, go, need_grad_input)
@@ -90,6 +125,8 @@ def install():
     IP.forward, IP.backward = orc.interp2x_forward, orc.interp2x_backward
     MC.mc_gpu = orc.mc
     RS.rasterize_meshes = _rasterize_meshes
+    RS.rasterize_points = _rasterize_points
+    RS.alpha_composite = _AlphaCompositeCPU.apply
 
 
 def uninstall():
@@ -111,4 +148,5 @@ def uninstall():
     IP.forward, IP.backward = _saved['ipf'], _saved['ipb']
     MC.mc_gpu = _saved['mc']
     RS.rasterize_meshes = _saved['rs']
+    RS.rasterize_points, RS.alpha_composite = _saved['rp'], _saved['ac']
     _saved.clear()

@@ -206,3 +206,58 @@ def rasterize_meshes(face_verts, mesh_first_face, mesh_num_faces, image_size, bl
                                        C.c_int(int(cull_backfaces)), _p(p2f), _p(zbuf), _p(bary), _p(dists))
     assert rc == 0
     return p2f, zbuf, bary, dists
+
+
+# ------------------------------------------------------------------------------------ point rasteriser
+def rasterize_points(points, cloud_first, cloud_num, image_size, radius, points_per_pixel, scan=False):
+    """pytorch3d `rasterize_points` contract on packed NDC points [P,3]: (idx [N,H,W,K] int32, zbuf, dists)."""
+    pts = _cpu(points).contiguous().float()
+    first, num = _cpu(cloud_first).contiguous().long(), _cpu(cloud_num).contiguous().long()
+    H, W = image_size
+    N, K = first.numel(), int(points_per_pixel)
+    idx = torch.empty(N, H, W, K, dtype=torch.int32)
+    zbuf = torch.empty(N, H, W, K, dtype=torch.float32)
+    dists = torch.empty(N, H, W, K, dtype=torch.float32)
+    fn = lib().oracle_rasterize_points_scan if scan else lib().oracle_rasterize_points
+    rc = fn(_p(pts), _p(first), _p(num), C.c_int64(N), C.c_int64(H), C.c_int64(W), C.c_float(radius), C.c_int(K),
+            _p(idx), _p(zbuf), _p(dists))
+    assert rc == 0
+    return idx, zbuf, dists
+
+
+def rasterize_points_backward(points, idx, grad_dists, grad_zbuf=None):
+    pts = _cpu(points).contiguous().float()
+    N, H, W, K = idx.shape
+    out = torch.empty_like(pts)
+    gd = grad_dists.contiguous() if grad_dists is not None else None
+    gz = grad_zbuf.contiguous() if grad_zbuf is not None else None
+    rc = lib().oracle_rasterize_points_backward(_p(pts), _p(idx.contiguous()), _p(gd), _p(gz), C.c_int64(N),
+                                                C.c_int64(pts.shape[0]), C.c_int64(H), C.c_int64(W), C.c_int(K),
+                                                _p(out))
+    assert rc == 0
+    return out
+
+
+def alpha_composite_forward(idx, alphas, features):
+    """idx / alphas [N,H,W,K], features [C,P] -> images [N,C,H,W]."""
+    N, H, W, K = idx.shape
+    Cc, P = features.shape
+    images = torch.empty(N, Cc, H, W, dtype=torch.float32)
+    rc = lib().oracle_alpha_composite_forward(_p(idx.contiguous()), _p(alphas.contiguous()), _p(features.contiguous()),
+                                              C.c_int64(N), C.c_int64(H), C.c_int64(W), C.c_int(K), C.c_int64(Cc),
+                                              C.c_int64(P), _p(images))
+    assert rc == 0
+    return images
+
+
+def alpha_composite_backward(idx, alphas, features, grad_images, need_grad_features=True):
+    N, H, W, K = idx.shape
+    Cc, P = features.shape
+    ga = torch.empty(N, H, W, K, dtype=torch.float32)
+    gf = torch.empty(Cc, P, dtype=torch.float32) if need_grad_features else None
+    rc = lib().oracle_alpha_composite_backward(_p(idx.contiguous()), _p(alphas.contiguous()),
+                                               _p(features.contiguous()), _p(grad_images.contiguous()), C.c_int64(N),
+                                               C.c_int64(H), C.c_int64(W), C.c_int(K), C.c_int64(Cc), C.c_int64(P),
+                                               _p(ga), _p(gf))
+    assert rc == 0
+    return ga, gf

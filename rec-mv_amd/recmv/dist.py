@@ -82,8 +82,14 @@ class GradAllReduce:
 def broadcast_state(tensors, src=0):
     """Make every rank start from rank `src`'s values (initial state)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        for t in tensors:
-            dist.broadcast(t.data, src=src)
+        with torch.no_grad():
+            for t in tensors:
+                # receive into a buffer and copy_ in: the collective itself does not bump the parameter's version
+                # counter, and every cache keyed on `_version` (normalised weights, transposes, chain descriptors)
+                # must see the new values
+                buf = t.detach().clone()
+                dist.broadcast(buf, src=src)
+                t.copy_(buf)
 
 
 def barrier():

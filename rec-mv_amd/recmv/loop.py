@@ -14,15 +14,14 @@ OptimGarmentNetwork.py:1885-1969) -> `loss.backward()` -> `propagateTmpPsGrad` (
   dct_poses_loss        :1221-1250 (pose smoothness on 30-frame windows)
   propagateTmpPsGrad    :2159-2313 implicit differentiation of the surface point
 
-What is NOT here, and why: pytorch3d's POINT rasteriser + alpha compositor (the splatted
-silhouette of `compute_garment_pc_loss`) is third-party code outside /root/reference and outside this tier's scope;
-it is replaced by a projection that keeps every hot-path call and every gradient path in place:
-  * silhouette IoU of the splatted point cloud -> a differentiable distance-to-mask term sampled at the
-    projected deformed vertices (same inputs: deformed vertices; same gradient sinks: explicit vertices,
-    deformer parameters, per-frame codes, poses).
-The MESH rasteriser of `find_surface_ps` is here (recmv/raster.py on csrc/rasterize_meshes.hip): the visible canonical
-surface points come from first-hit fragments + `utils.FindSurfacePs`, and `sample_train_ray` draws its Bernoulli
-subset of them with the host RNG exactly like the reference (:1020).
+What is NOT here, and why: nothing of `OptimGarmentNetwork.forward` except the
+feature-curve branch below.  The two pytorch3d renderers on the path are restated on HIP kernels (recmv/raster.py):
+  * `pcRender` (point splat, 50 points per pixel, alpha compositor, :937) -> csrc/rasterize_points.hip, forward and
+    backward; the IoU mask loss of compute_garment_pc_loss (:621-667) runs on its silhouettes;
+  * `maskRender` (first-hit mesh rasteriser, :767) -> csrc/rasterize_meshes.hip; the visible canonical surface points
+    come from its fragments + `utils.FindSurfacePs`, and `sample_train_ray` draws its Bernoulli subset of them with the
+    host RNG exactly like the reference (:1020).
+Frames are synthetic (SyntheticFrames): images, normals and garment segmentations are generated, not loaded.
 The feature-curve branch (`project_2d_loss`, "next" row 3) is likewise outside this tier.
 The CPU SVD of the deformer Jacobians (:1148, a host round trip per garment per iteration) is replaced by
 closed-form singular values on the device (`singular_values_3x3`).
@@ -160,13 +159,27 @@ class SyntheticFrames:
         sl = frame_ids % self.n_img
         return self.img[sl], self.normal[sl]
 
+    def set_garment_silhouettes(self, radii, seed=0):
+        """Synthetic ground-truth segmentation: garment g of image slot k is a slightly elliptical disc — the outline
+        of a sphere of radius radii[g] seen by this camera, jittered by a few pixels per slot — so that the IoU term of
+        the mask loss starts near, but not at, its optimum."""
+        g = torch.Generator().manual_seed(seed)
+        fx, fy = float(self.focal.detach()[0, 0]), float(self.focal.detach()[0, 1])
+        cx, cy, Z = float(self.pp.detach()[0, 0]), float(self.pp.detach()[0, 1]), float(self.T.detach()[0, 2])
+        ys, xs = torch.meshgrid(torch.arange(self.H, dtype=torch.float32), torch.arange(self.W, dtype=torch.float32),
+                                indexing='ij')
+        self._masks = []
+        for r in radii:
+            rx, ry = fx * r / math.sqrt(Z * Z - r * r), 1.06 * fy * r / math.sqrt(Z * Z - r * r)
+            jit = 3.0 * torch.randn(self.n_img, 2, generator=g)
+            m = (((xs[None] - cx - jit[:, 0, None, None]) / rx) ** 2
+                 + ((ys[None] - cy - jit[:, 1, None, None]) / ry) ** 2 <= 1.0).float()
+            self._masks.append(m.to(self.device))
+
     def garment_masks(self, g_i, frame_ids):
         """Ground-truth garment segmentation of the batch's frames [N,H,W] (datas['upper'] / ['bottom'],
-        OptimGarmentNetwork.py:1896-1902).  Synthetic frames: everything is garment, so every rasterised surface pixel
-        passes the `gt > 0` selection of sample_train_ray (:1013) — the gather itself still runs."""
-        if getattr(self, '_mask', None) is None:
-            self._mask = torch.ones(self.n_img, self.H, self.W, device=self.device)
-        return self._mask[frame_ids % self.n_img]
+        OptimGarmentNetwork.py:1896-1902)."""
+        return self._masks[g_i][frame_ids % self.n_img]
 
 
 class _CondPair:
@@ -229,10 +242,12 @@ class HotLoop:
         self.dataset = SyntheticFrames(n_frames, self.garment_size, H, W, device, seed=seed + 2,
                                        condlen=conf.get_int('mlp_deformer.condlen'),
                                        rendlen=conf.get_int('render_net.condlen'))
+        self.dataset.set_garment_silhouettes([_zero_level_radius(n, device) for n in self.garment_nets], seed=seed + 3)
         res = resolutions if resolutions is not None else RESOLUTIONS[stage]
         self.engine = Seg3dLossless(query_func=None, b_min=list(bmin), b_max=list(bmax), resolutions=res,
                                     align_corners=False, balance_value=0.0, use_cuda_impl=True, faster=False).to(device)
         self.remesh_intersect = conf.get_int(f'train.{stage}.point_render.remesh_intersect')
+        self.pc_radius = conf.get_float(f'train.{stage}.point_render.radius')        # OptimNetwork.py:87-93
         self.batch_size = conf.get_int(f'train.{stage}.point_render.batch_size')
         self.sample_pix = conf.get_int('train.sample_pix_num')
         self.sdfShrinkRadius = 0.0
@@ -258,6 +273,7 @@ class HotLoop:
         self.stage = stage
         self.conf = conf.get_config('loss_' + stage)
         self.remesh_intersect = conf.get_int(f'train.{stage}.point_render.remesh_intersect')
+        self.pc_radius = conf.get_float(f'train.{stage}.point_render.radius')
         self.batch_size = conf.get_int(f'train.{stage}.point_render.batch_size')
         old = self.engine
         self.engine = Seg3dLossless(query_func=None, b_min=old.b_min.view(-1).tolist(), b_max=old.b_max.view(-1).tolist(),
@@ -368,23 +384,32 @@ class HotLoop:
 
     # ------------------------------------------------------------------------------------------ mask loss
     def mask_loss(self, N, frame_ids, ratio, cameras):
+        """OptimGarmentNetwork.py:841-981: deform the explicit garment meshes, splat the merged point cloud into one
+        alpha-composited silhouette per garment (pcRender, :937), IoU loss against the dilated ground-truth masks +
+        LBS-consistency term (compute_garment_pc_loss, :621-667), SGD step on the explicit vertices, |SDF| loss."""
         d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
         conf = self.conf
+        H, W = self.dataset.H, self.dataset.W
+        def_vs = [self.deformer(gv[None, :, :].expand(N, -1, 3), [d_cond_list[g_i + 1], [poses, trans]], ratio=ratio,
+                                offset_type=name)                                          # :910
+                  for g_i, (gv, name) in enumerate(zip(self.garment_vs, self.garment_names))]
+        whole = torch.cat(def_vs, dim=1) if len(def_vs) > 1 else def_vs[0]                 # :925-935
+        pc_render = raster.PointsRendererWithFrags_Split(cameras, (H, W), radius=self.pc_radius, points_per_pixel=50)
+        garment_masks_list, _frags = pc_render(whole, split_size=self.garment_vs[0].shape[0])   # :937
+        rpx = int(np.round(self.pc_radius / 2. * float(min(H, W)) / 1.2))                  # :940-941
         garment_loss = 0.
-        def_vs = []
         for g_i, name in enumerate(self.garment_names):
-            gv = self.garment_vs[g_i]
-            defv = self.deformer(gv[None, :, :].expand(N, -1, 3), [d_cond_list[g_i + 1], [poses, trans]], ratio=ratio,
-                                 offset_type=name)                                         # :910
-            def_vs.append(defv)
-            # silhouette surrogate (see module docstring): projected vertices should fall inside the image disc
-            pix = cameras.project(defv.reshape(-1, 3))
-            c = torch.stack([self.dataset.pp[0, 0], self.dataset.pp[0, 1]]).view(1, 2)
-            rad = ((pix - c) / (0.45 * min(self.dataset.H, self.dataset.W))).norm(dim=1)
-            mask_loss = torch.relu(rad - 1.0).mean() + 1e-3 * rad.mean()
-            loss = mask_loss
+            gt = self.dataset.garment_masks(g_i, frame_ids)
+            if rpx > 0:                                                                   # :947
+                gt = F.max_pool2d(gt, kernel_size=2 * rpx + 1, stride=1, padding=rpx)
+            masks = garment_masks_list[g_i][..., -1]                                      # :624-629
+            mask_loss = (1. - (masks * gt).view(N, -1).sum(1)
+                         / (masks + gt - masks * gt).abs().view(N, -1).sum(1)).mean()
+            self.info['pc_{}_mask_loss'.format(name)] = mask_loss.detach()
+            loss = mask_loss * (conf.get_float('pc_weight.mask_weight') if 'pc_weight.mask_weight' in conf else 1.)
+            gv, defv = self.garment_vs[g_i], def_vs[g_i]
             cw = conf.get_float('pc_weight.def_consistent.weight')
-            if cw > 0.:                                                                   # :655-663
+            if cw > 0.:                                                                   # :651-662
                 offset2 = defv - self.deformer.defs[1](gv.view(1, -1, 3).expand(N, -1, 3), [poses, trans])
                 offset2 = (offset2 * offset2).sum(-1)
                 cc = conf.get_float('pc_weight.def_consistent.c')

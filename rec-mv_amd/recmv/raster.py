@@ -81,3 +81,133 @@ class MeshRasterizer:
         num = torch.full((N,), F, device=verts.device, dtype=torch.int64)
         return rasterize_meshes(face_verts, first, num, self.image_size, self.blur_radius, 1,
                                 self.perspective_correct, False, self.cull_backfaces, max_faces_per_mesh=F)
+
+
+# ------------------------------------------------------------------------------------------- points
+PointFragments = namedtuple("PointFragments", ["idx", "zbuf", "dists"])
+
+
+class _RasterizePoints(torch.autograd.Function):
+    """pytorch3d `_RasterizePoints` (renderer/points/rasterize_points.py): idx is not differentiable, dists and zbuf
+    are, w.r.t. the packed NDC points."""
+
+    @staticmethod
+    def forward(ctx, points, cloud_first, cloud_num, H, W, radius, K, max_points):
+        L.require_cuda(points, "points")
+        L.require_contiguous(points, "points")
+        if points.dtype != torch.float32 or points.dim() != 2 or points.shape[1] != 3:
+            raise ValueError("points must be float32 of shape [P,3]")
+        for t, name in ((cloud_first, "cloud_first_point"), (cloud_num, "cloud_num_points")):
+            L.require_cuda(t, name)
+            L.require_contiguous(t, name)
+            if t.dtype != torch.int64:
+                raise ValueError(name + " must be int64")
+        N, P = cloud_first.numel(), points.shape[0]
+        dev = points.device
+        idx = torch.empty((N, H, W, K), dtype=torch.int32, device=dev)
+        zbuf = torch.empty((N, H, W, K), dtype=torch.float32, device=dev)
+        dists = torch.empty((N, H, W, K), dtype=torch.float32, device=dev)
+        lib = L.lib()
+        with torch.cuda.device(dev):
+            nbytes = int(lib.recmv_rasterize_points_workspace_bytes(N, H, W, P, float(radius)))
+            if nbytes < 0:
+                raise ValueError("rasterize_points: bad sizes / radius")
+            ws = torch.empty(max(nbytes, 64), dtype=torch.uint8, device=dev)
+            L.check(lib.recmv_rasterize_points(L.ptr(points), L.ptr(cloud_first), L.ptr(cloud_num), N, P,
+                                               P if max_points is None else int(max_points), H, W, float(radius),
+                                               int(K), L.ptr(idx), L.ptr(zbuf), L.ptr(dists), L.ptr(ws), ws.numel(),
+                                               L.stream_ptr(dev)), "rasterize_points")
+        ctx.save_for_backward(points, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx, zbuf, dists
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, _g_idx, g_zbuf, g_dists):
+        points, idx = ctx.saved_tensors
+        N, H, W, K = idx.shape
+        g_points = torch.empty_like(points)
+        with torch.cuda.device(points.device):
+            L.check(L.lib().recmv_rasterize_points_backward(
+                L.ptr(points), L.ptr(idx), L.ptr(g_dists.contiguous()) if g_dists is not None else None,
+                L.ptr(g_zbuf.contiguous()) if g_zbuf is not None else None, N, points.shape[0], H, W, K,
+                L.ptr(g_points), L.stream_ptr(points.device)), "rasterize_points_backward")
+        return g_points, None, None, None, None, None, None, None
+
+
+def rasterize_points(points, cloud_first_point, cloud_num_points, image_size, radius, points_per_pixel=8,
+                     max_points_per_cloud=None):
+    """points [P,3] f32 CUDA (x_ndc, y_ndc, z_view), clouds packed back to back.  Returns `PointFragments`
+    (idx int32 [N,H,W,K], zbuf, dists), differentiable w.r.t. `points` through dists / zbuf."""
+    H, W = int(image_size[0]), int(image_size[1])
+    return PointFragments(*_RasterizePoints.apply(points, cloud_first_point, cloud_num_points, H, W, float(radius),
+                                                  int(points_per_pixel), max_points_per_cloud))
+
+
+class _AlphaComposite(torch.autograd.Function):
+    """pytorch3d `alpha_composite` on fragment-major tensors: idx / alphas [N,H,W,K], features [C,P] -> [N,C,H,W]."""
+
+    @staticmethod
+    def forward(ctx, idx, alphas, features):
+        for t, name in ((idx, "idx"), (alphas, "alphas"), (features, "features")):
+            L.require_cuda(t, name)
+            L.require_contiguous(t, name)
+        if idx.dtype != torch.int32 or alphas.dtype != torch.float32 or features.dtype != torch.float32:
+            raise ValueError("alpha_composite: idx int32, alphas / features float32")
+        if idx.shape != alphas.shape or idx.dim() != 4 or features.dim() != 2:
+            raise ValueError("alpha_composite: idx / alphas [N,H,W,K], features [C,P]")
+        N, H, W, K = idx.shape
+        C, P = features.shape
+        images = torch.empty((N, C, H, W), dtype=torch.float32, device=idx.device)
+        with torch.cuda.device(idx.device):
+            L.check(L.lib().recmv_alpha_composite_forward(L.ptr(idx), L.ptr(alphas), L.ptr(features), N, H, W, K, C, P,
+                                                          L.ptr(images), L.stream_ptr(idx.device)),
+                    "alpha_composite_forward")
+        ctx.save_for_backward(idx, alphas, features)
+        return images
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_images):
+        idx, alphas, features = ctx.saved_tensors
+        N, H, W, K = idx.shape
+        C, P = features.shape
+        g_alphas = torch.empty_like(alphas)
+        g_features = torch.empty_like(features) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(idx.device):
+            L.check(L.lib().recmv_alpha_composite_backward(
+                L.ptr(idx), L.ptr(alphas), L.ptr(features), L.ptr(g_images.contiguous()), N, H, W, K, C, P,
+                L.ptr(g_alphas), L.ptr(g_features) if g_features is not None else None, L.stream_ptr(idx.device)),
+                "alpha_composite_backward")
+        return None, g_alphas, g_features
+
+
+def alpha_composite(idx, alphas, features):
+    return _AlphaComposite.apply(idx, alphas, features)
+
+
+class PointsRendererWithFrags_Split:
+    """`PointsRendererWithFrags_Split(PointsRasterizer, AlphaCompositor)` of the reference (model/CameraMine.py:347-415)
+    for N clouds with the same number of points: every frame's cloud is [upper garment vertices ; bottom garment
+    vertices]; returns one alpha-composited silhouette per garment — the other garment's points take part in the
+    compositing with feature 0, so they occlude — and the fragments."""
+
+    def __init__(self, cameras, image_size, radius, points_per_pixel=50):
+        self.cameras = cameras
+        self.image_size = (int(image_size[0]), int(image_size[1]))
+        self.radius = float(radius)
+        self.points_per_pixel = int(points_per_pixel)
+
+    def __call__(self, points, split_size):
+        N, V = points.shape[0], points.shape[1]
+        H, W = self.image_size
+        dev = points.device
+        ndc = self.cameras.transform_points_ndc(points.reshape(-1, 3)).contiguous()
+        first = torch.arange(N, device=dev, dtype=torch.int64) * V
+        num = torch.full((N,), V, device=dev, dtype=torch.int64)
+        frags = rasterize_points(ndc, first, num, (H, W), self.radius, self.points_per_pixel, max_points_per_cloud=V)
+        weights = 1 - frags.dists / (self.radius * self.radius)                    # CameraMine.py:361-362
+        upper = (torch.arange(N * V, device=dev) % V) < int(split_size)            # :367-372
+        features = torch.stack([upper, ~upper]).to(torch.float32).contiguous()
+        images = alpha_composite(frags.idx, weights, features)                     # [N,2,H,W]
+        return [images[:, 0, :, :, None], images[:, 1, :, :, None]], frags

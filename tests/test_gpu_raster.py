@@ -145,3 +145,103 @@ def test_surface_points_project_to_their_pixel_centres_full_size():
     # determinism: the scatter formulation gives the same image every time
     again = raster.MeshRasterizer(cam, (H, W))(def_vs, faces)
     assert torch.equal(again.pix_to_face, frags.pix_to_face) and torch.equal(again.zbuf, frags.zbuf)
+
+
+# ------------------------------------------------------------------------------------------- points
+def _cloud(seed, n, zlo=0.5, zhi=3.0):
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(-1.05, 1.05, size=(n, 2))
+    z = rng.uniform(zlo, zhi, size=(n, 1))
+    return torch.from_numpy(np.concatenate([xy, z], 1).astype(np.float32))
+
+
+def _bits(a, b, name):
+    a = a.cpu()
+    assert a.shape == b.shape and a.dtype == b.dtype, name
+    if a.dtype.is_floating_point:
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), name + " must be bit-identical"
+    else:
+        assert torch.equal(a, b), name + " must be identical"
+
+
+@pytest.mark.parametrize("case", [
+    dict(seed=0, clouds=[4000], hw=(48, 48), K=8, r=0.05),
+    dict(seed=1, clouds=[1500, 0, 2500], hw=(40, 72), K=50, r=0.11),          # ragged + empty cloud, H != W, K = 50
+    dict(seed=2, clouds=[6000], hw=(24, 24), K=3, r=0.3, zlo=-0.3),           # saturated lists, points behind the camera
+    dict(seed=3, clouds=[3000, 3000], hw=(64, 64), K=50, r=0.006 * 8),        # the loop's splat size, scaled to 64 px
+])
+def test_rasterize_points_and_composite_vs_oracle(oracle, case):
+    from recmv import raster
+    n = case["clouds"]
+    pts = _cloud(case["seed"], sum(n), zlo=case.get("zlo", 0.5))
+    if sum(n) > 100:
+        pts[11] = pts[10]                                                     # equal depth and position: index decides
+        H, W = case["hw"]
+        pts[12, 0], pts[12, 1] = 1 - (2 * 5 + 1) / W, 1 - (2 * 4 + 1) / H     # exactly on a pixel centre (alpha = 1)
+    first = torch.tensor([0] + list(np.cumsum(n)[:-1]), dtype=torch.int64)
+    num = torch.tensor(n, dtype=torch.int64)
+    K, r = case["K"], case["r"]
+    ref = oracle.rasterize_points(pts, first, num, case["hw"], r, K)
+    p_gpu = pts.to(DEV).requires_grad_(True)
+    frags = raster.rasterize_points(p_gpu, first.to(DEV), num.to(DEV), case["hw"], r, K, max_points_per_cloud=max(n))
+    for name, a, b in zip(("idx", "zbuf", "dists"), frags, ref):
+        _bits(a.detach(), b, name)
+    assert (ref[0] >= 0).sum() > 100
+    # compositor: forward and grad_alphas are fixed-order sums -> bit-exact; grad_features / grad_points use atomics
+    rng = np.random.default_rng(case["seed"] + 100)
+    feats = torch.from_numpy(rng.uniform(0, 1, size=(2, sum(n))).astype(np.float32))
+    valid = ref[0] >= 0
+    alphas_ref = (1 - ref[2] / (r * r)) * valid
+    # keep alpha < 1 so that the published backward (division by 1 - alpha) stays finite on both sides
+    alphas_ref = alphas_ref.clamp(max=0.999)
+    img_ref = oracle.alpha_composite_forward(ref[0], alphas_ref, feats)
+    f_gpu = feats.to(DEV).requires_grad_(True)
+    a_gpu = alphas_ref.to(DEV).requires_grad_(True)
+    img = raster.alpha_composite(frags.idx, a_gpu, f_gpu)
+    _bits(img.detach(), img_ref, "images")
+    g = torch.from_numpy(rng.normal(size=tuple(img_ref.shape)).astype(np.float32))
+    img.backward(g.to(DEV))
+    ga_ref, gf_ref = oracle.alpha_composite_backward(ref[0], alphas_ref, feats, g)
+    _bits(a_gpu.grad, ga_ref, "grad_alphas")
+    assert torch.allclose(f_gpu.grad.cpu(), gf_ref, rtol=1e-4, atol=1e-5)
+    gd = torch.from_numpy(rng.normal(size=tuple(ref[2].shape)).astype(np.float32)) * valid
+    gz = torch.from_numpy(rng.normal(size=tuple(ref[2].shape)).astype(np.float32)) * valid
+    (frags.dists * gd.to(DEV) + frags.zbuf * gz.to(DEV)).sum().backward()
+    gp_ref = oracle.rasterize_points_backward(pts, ref[0], gd, gz)
+    assert torch.allclose(p_gpu.grad.cpu(), gp_ref, rtol=1e-4, atol=1e-5)
+
+
+def test_points_renderer_split_full_size_properties():
+    """3 x 512 x 512, two garments of ~75k vertices, K = 50, radius 0.006 (the coarse stage's splat): silhouettes in
+    [0,1], the two garments' images never add up to more than 1, gradients reach the points and are finite, and the
+    forward is reproducible bit for bit."""
+    from recmv import raster
+    upper, _ = _sphere_mesh(129, radius=0.45)
+    lower, _ = _sphere_mesh(129, radius=0.40)
+    lower = lower + torch.tensor([0.0, -0.25, 0.0], device=DEV)
+    H = W = 512
+    cam = _camera(H, W)
+    offs = torch.tensor([[0., 0., 0.], [0.07, -0.03, 0.2], [-0.1, 0.05, -0.1]], device=DEV)
+    cloud = (torch.cat([upper, lower])[None] + offs[:, None]).requires_grad_(True)
+    rend = raster.PointsRendererWithFrags_Split(cam, (H, W), radius=0.006, points_per_pixel=50)
+    imgs, frags = rend(cloud, split_size=upper.shape[0])
+    assert imgs[0].shape == (3, H, W, 1) and frags.idx.shape == (3, H, W, 50)
+    for im in imgs:
+        assert im.min() >= 0 and im.max() <= 1 + 1e-5
+    assert (imgs[0] + imgs[1]).max() <= 1 + 1e-5
+    cover = ((imgs[0] + imgs[1])[..., 0] > 0.5).float().mean()
+    assert 0.1 < cover < 0.6
+    # lists are packed, sorted by depth, and every listed point is within the radius
+    valid = frags.idx >= 0
+    assert (valid[..., 1:] <= valid[..., :-1]).all()
+    z = torch.where(valid, frags.zbuf, torch.full_like(frags.zbuf, float("inf")))
+    assert (z[..., 1:] >= z[..., :-1]).all()
+    assert (frags.dists[valid] < 0.006 ** 2).all() and (frags.dists[valid] >= 0).all()
+    gt = torch.zeros(3, H, W, device=DEV)
+    gt[:, 100:400, 150:380] = 1
+    m = imgs[0][..., -1]
+    loss = (1. - (m * gt).view(3, -1).sum(1) / (m + gt - m * gt).abs().view(3, -1).sum(1)).mean()   # :626
+    loss.backward()
+    assert torch.isfinite(cloud.grad).all() and cloud.grad.abs().sum() > 0
+    again, frags2 = rend(cloud.detach(), split_size=upper.shape[0])
+    assert torch.equal(frags2.idx, frags.idx) and torch.equal(again[0], imgs[0].detach())

@@ -509,7 +509,7 @@ int oracle_alpha_composite_backward(const int32_t* idx, const float* alphas, con
         for (int t = 0; t < k; ++t) {
           if (idx[i * K + t] < 0) continue;
           const float alpha_t = alphas[i * K + t];
-          grad_alphas[i * K + t] += -g * f * cum_alpha * alpha / (1.f - alpha_t);
+          grad_alphas[i * K + t] += -g * f * cum_alpha * alpha / (1.f - alpha_t + 1e-9f); /* upstream kEpsilon */
         }
         cum_alpha = cum_alpha * (1.f - alpha);
       }

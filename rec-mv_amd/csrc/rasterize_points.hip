@@ -25,6 +25,9 @@ namespace {
 
 #pragma clang fp contract(off)
 
+// upstream's guard in the compositor backward: a point exactly on a pixel centre has alpha = 1 and would divide by 0
+constexpr float kAlphaEps = 1e-9f;
+
 __device__ __forceinline__ float pix_to_ndc(int i, int S) { return 1.f - (2.f * (float)i + 1.f) / (float)S; }
 
 // Conservative index range of the pixel centres within [c - r, c + r] (NDC decreases with the index).
@@ -196,7 +199,7 @@ alpha_backward_kernel(const int* __restrict__ idx, const float* __restrict__ alp
       for (int t = 0; t < k; ++t) {
         if (idx[i * K + t] < 0) continue;
         const float at = alphas[i * K + t];
-        g_alphas[i * K + t] += -g * f * cum * a / (1.f - at);
+        g_alphas[i * K + t] += -g * f * cum * a / (1.f - at + kAlphaEps);
       }
       cum = cum * (1.f - a);
     }

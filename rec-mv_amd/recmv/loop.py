@@ -378,6 +378,8 @@ class HotLoop:
         self.garment_vs, self.garment_fs = vs_list[1:], fs_list[1:]
         if self.body_vs.shape[0] == 0:
             raise AssertionError('tmp sdf vanished...')
+        if any(v.shape[0] == 0 for v in self.garment_vs):
+            raise AssertionError('a garment sdf has no zero level inside the box (diverged optimisation?)')
         for v in self.garment_vs:
             v.requires_grad = True
         self.garment_optimizer = torch.optim.SGD(self.garment_vs, lr=0.05, momentum=0.9)

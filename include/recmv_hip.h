@@ -289,8 +289,12 @@ int recmv_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_fa
  *   recmv_rasterize_points_backward : grad_points [total_points,3] = d/dpoints of (grad_dists . dists + grad_zbuf . zbuf)
  *                                     (grad_zbuf may be NULL); accumulates with float atomics.
  *   recmv_alpha_composite_forward   : images [N,C,H,W]; images[n,c,y,x] = sum_k a_k prod_{l<k}(1 - a_l) features[c,idx_k]
- *                                     with alphas [N,H,W,K] (the caller's 1 - dists/radius^2) and features [C,total_points].
- *   recmv_alpha_composite_backward  : grad_alphas [N,H,W,K] (no atomics); grad_features [C,total_points] or NULL.
+ *                                     with alphas [N,H,W,K] and features [C,total_points].  radius2 == 0: `alphas`
+ *                                     are the opacities.  radius2 != 0: `alphas` holds the rasteriser's dists and
+ *                                     a = 1 - dists / radius2 (PointsRendererWithFrags' 1 - d2/radius^2,
+ *                                     model/CameraMine.py:361-362, fused).  idx lists must be packed to the front.
+ *   recmv_alpha_composite_backward  : grad_alphas [N,H,W,K] = gradient w.r.t. the `alphas` INPUT (opacities or
+ *                                     dists), no atomics; grad_features [C,total_points] or NULL.
  * ---------------------------------------------------------------------------------------------- */
 int64_t recmv_rasterize_points_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t total_points, float radius);
 int recmv_rasterize_points(const float* points, const int64_t* cloud_first_point, const int64_t* cloud_num_points,
@@ -302,11 +306,11 @@ int recmv_rasterize_points_backward(const float* points, const int32_t* idx, con
                                     int points_per_pixel, float* grad_points, void* stream);
 int recmv_alpha_composite_forward(const int32_t* idx, const float* alphas, const float* features, int64_t N,
                                   int64_t H, int64_t W, int points_per_pixel, int64_t C, int64_t total_points,
-                                  float* images, void* stream);
+                                  float radius2, float* images, void* stream);
 int recmv_alpha_composite_backward(const int32_t* idx, const float* alphas, const float* features,
                                    const float* grad_images, int64_t N, int64_t H, int64_t W, int points_per_pixel,
-                                   int64_t C, int64_t total_points, float* grad_alphas, float* grad_features,
-                                   void* stream);
+                                   int64_t C, int64_t total_points, float radius2, float* grad_alphas,
+                                   float* grad_features, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused linear-blend skinning on ray points and the root finder's per-ray step (csrc/lbs_fused.hip).

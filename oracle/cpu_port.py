@@ -114,7 +114,7 @@ def install():
                        gf=GS.forward, gb=GS.backward, gd=GS.dbackward, fm=FM.Fast3x3Minv, fmb=FM.Fast3x3Minv_backward,
                        uu=UU.Fast3x3Minv, uub=UU.Fast3x3Minv_backward, lp=LP.Fast3x3Minv, ipf=IP.forward,
                        ipb=IP.backward, mc=MC.mc_gpu, rs=RS.rasterize_meshes, rp=RS.rasterize_points,
-                       ac=RS.alpha_composite))
+                       ac=RS.alpha_composite, acd=RS.alpha_composite_dists))
     ops.linear_act, ops.MatmulNT, ops.MatmulTN, ops.gemm_nt = _linear_act, _MatmulNT, _MatmulTN, _gemm_nt
     GS.forward = lambda i, g, a, b: orc.gs3d_forward(i, g)
     GS.backward = lambda i, g, go, a, b, need_grad_input=True: orc.gs3d_backward(i, g, go, need_grad_input)
@@ -127,6 +127,8 @@ def install():
     RS.rasterize_meshes = _rasterize_meshes
     RS.rasterize_points = _rasterize_points
     RS.alpha_composite = _AlphaCompositeCPU.apply
+    RS.alpha_composite_dists = lambda idx, dists, radius, features: _AlphaCompositeCPU.apply(
+        idx, 1 - dists / (radius * radius), features)
 
 
 def uninstall():
@@ -148,5 +150,5 @@ def uninstall():
     IP.forward, IP.backward = _saved['ipf'], _saved['ipb']
     MC.mc_gpu = _saved['mc']
     RS.rasterize_meshes = _saved['rs']
-    RS.rasterize_points, RS.alpha_composite = _saved['rp'], _saved['ac']
+    RS.rasterize_points, RS.alpha_composite, RS.alpha_composite_dists = _saved['rp'], _saved['ac'], _saved['acd']
     _saved.clear()

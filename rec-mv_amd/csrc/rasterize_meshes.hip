@@ -15,7 +15,7 @@
 // garment has ~2 faces per covered pixel, so the work here is organised by FACE:
 //   pass 1  one thread per face walks the pixel centres inside the face's bounding box (usually 0-2 of them) and
 //           does a 64-bit atomicMin of (depth bits << 32 | face index) on the pixel's key.  Faces whose box holds
-//           more than kInlinePixels centres are queued and walked by a whole wavefront each (pass 1b).
+//           more than kInlinePixels (48) centres are queued and walked by a whole wavefront each (pass 1b).
 //           The minimum is order independent: ties in depth go to the lowest face index, which is what the
 //           first-come `pz < q_max_z` test of the per-pixel loop keeps.
 //   pass 2  one thread per pixel decodes the winner and recomputes its outputs with the same arithmetic.
@@ -28,7 +28,7 @@ namespace {
 #pragma clang fp contract(off)
 
 constexpr float kEps = 1e-8f;
-constexpr int kInlinePixels = 16;
+constexpr int kInlinePixels = 48;
 constexpr unsigned long long kEmptyKey = ~0ull;
 
 struct Tri {
@@ -108,12 +108,18 @@ __device__ __forceinline__ Tri load_tri(const float* __restrict__ fv, int64_t f)
   return t;
 }
 
-// Conservative range of pixel indices whose centres can lie in [lo, hi] (NDC, decreasing in the index).
+// Range of pixel indices whose centres can lie in [lo, hi] (NDC, decreasing in the index).  centre(i) = 1 - (2i+1)/S
+// in [lo, hi]  <=>  (S(1-hi)-1)/2 <= i <= (S(1-lo)-1)/2; the bounds are relaxed by 1e-3 of a pixel (orders of
+// magnitude above the rounding of the expression, so no covered centre is lost) — the exact test is pixel_face's.
 __device__ __forceinline__ void pixel_range(float lo, float hi, int S, int& i0, int& i1) {
-  // centre(i) = 1 - (2i+1)/S  in [lo, hi]  <=>  (S(1-hi)-1)/2 <= i <= (S(1-lo)-1)/2 ; widen by one for rounding
   const float a = ((float)S * (1.f - hi) - 1.f) * 0.5f;
   const float b = ((float)S * (1.f - lo) - 1.f) * 0.5f;
-  const float fa = floorf(a) - 1.f, fb = ceilf(b) + 1.f;
+  const float fa = ceilf(a - 1e-3f - 1e-6f * fabsf(a)), fb = floorf(b + 1e-3f + 1e-6f * fabsf(b));
+  if (!(fa == fa) || !(fb == fb)) {
+    i0 = 0;
+    i1 = -1;
+    return;
+  }
   i0 = fa < 0.f ? 0 : (fa > (float)S ? S : (int)fa);
   i1 = fb > (float)(S - 1) ? S - 1 : (fb < -1.f ? -1 : (int)fb);
 }

@@ -98,6 +98,7 @@ points_place_kernel(const int* __restrict__ pix_count, int64_t npix, int64_t* __
   if (i < npix) pix_offset[i] = (int64_t)base + (incl - c);
 }
 
+// idx / zbuf / dists arrive pre-filled with -1: only the listed points are written (4 of 5 pixels are empty).
 __global__ void __launch_bounds__(256)
 points_resolve_kernel(const float* __restrict__ pts, const int* __restrict__ pix_count,
                       const int64_t* __restrict__ pix_offset, const unsigned long long* __restrict__ entries,
@@ -106,31 +107,24 @@ points_resolve_kernel(const float* __restrict__ pts, const int* __restrict__ pix
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
   const int cnt = pix_count[i];
+  if (cnt == 0) return;
   const unsigned long long* e = entries + pix_offset[i];
   const int64_t pix = i % ((int64_t)H * W);
   const float xf = pix_to_ndc((int)(pix % W), W), yf = pix_to_ndc((int)(pix / W), H);
   unsigned long long last = 0;
-  bool have_last = false;
-  int k = 0;
   const int take = cnt < K ? cnt : K;
-  for (; k < take; ++k) {
+  for (int k = 0; k < take; ++k) {
     unsigned long long best = ~0ull;
     for (int j = 0; j < cnt; ++j) {
       const unsigned long long v = e[j];
-      if ((!have_last || v > last) && v < best) best = v;
+      if ((k == 0 || v > last) && v < best) best = v;
     }
     last = best;
-    have_last = true;
     const int64_t p = (int64_t)(uint32_t)(best & 0xffffffffull);
     const float dx = xf - pts[3 * p], dy = yf - pts[3 * p + 1];
     idx[i * K + k] = (int)p;
     zbuf[i * K + k] = __uint_as_float((uint32_t)(best >> 32));
     dists[i * K + k] = dx * dx + dy * dy;
-  }
-  for (; k < K; ++k) {
-    idx[i * K + k] = -1;
-    zbuf[i * K + k] = -1.f;
-    dists[i * K + k] = -1.f;
   }
 }
 
@@ -157,11 +151,17 @@ points_backward_kernel(const float* __restrict__ pts, const int* __restrict__ id
   }
 }
 
-// images[n,c,y,x] = sum_k w_k prod_{l<k} (1 - w_l) features[c, idx_k]
+// images[n,c,y,x] = sum_k a_k prod_{l<k} (1 - a_l) features[c, idx_k];  a = alphas, or 1 - alphas / radius2 when
+// radius2 != 0 (then `alphas` holds the rasteriser's squared distances: PointsRendererWithFrags' 1 - d2 / r^2).
+// Lists are packed to the front (rasteriser contract), so the first -1 ends a pixel.
+__device__ __forceinline__ float alpha_of(float v, float radius2) {
+  return radius2 != 0.f ? 1.f - v / radius2 : v;
+}
+
 __global__ void __launch_bounds__(256)
 alpha_forward_kernel(const int* __restrict__ idx, const float* __restrict__ alphas,
                      const float* __restrict__ features, int64_t P, int64_t npix, int64_t HW, int K, int C,
-                     float* __restrict__ images) {
+                     float radius2, float* __restrict__ images) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
   const int64_t n = i / HW, pix = i % HW;
@@ -169,8 +169,8 @@ alpha_forward_kernel(const int* __restrict__ idx, const float* __restrict__ alph
     float cum = 1.f, res = 0.f;
     for (int k = 0; k < K; ++k) {
       const int p = idx[i * K + k];
-      if (p < 0) continue;
-      const float a = alphas[i * K + k];
+      if (p < 0) break;
+      const float a = alpha_of(alphas[i * K + k], radius2);
       res += cum * a * features[(int64_t)c * P + p];
       cum = cum * (1.f - a);
     }
@@ -178,32 +178,35 @@ alpha_forward_kernel(const int* __restrict__ idx, const float* __restrict__ alph
   }
 }
 
+// g_alphas arrives zero-filled; only listed entries are touched.
 __global__ void __launch_bounds__(256)
 alpha_backward_kernel(const int* __restrict__ idx, const float* __restrict__ alphas,
                       const float* __restrict__ features, const float* __restrict__ g_images, int64_t P, int64_t npix,
-                      int64_t HW, int K, int C, float* __restrict__ g_alphas, float* __restrict__ g_features) {
+                      int64_t HW, int K, int C, float radius2, float* __restrict__ g_alphas,
+                      float* __restrict__ g_features) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
+  if (idx[i * K] < 0) return;
   const int64_t n = i / HW, pix = i % HW;
-  for (int k = 0; k < K; ++k) g_alphas[i * K + k] = 0.f;
   for (int c = 0; c < C; ++c) {
     const float g = g_images[(n * C + c) * HW + pix];
     float cum = 1.f;
     for (int k = 0; k < K; ++k) {
       const int p = idx[i * K + k];
-      if (p < 0) continue;
-      const float a = alphas[i * K + k];
+      if (p < 0) break;
+      const float a = alpha_of(alphas[i * K + k], radius2);
       const float f = features[(int64_t)c * P + p];
       if (g_features) atomicAdd(g_features + (int64_t)c * P + p, cum * a * g);
       g_alphas[i * K + k] += cum * f * g;
       for (int t = 0; t < k; ++t) {
-        if (idx[i * K + t] < 0) continue;
-        const float at = alphas[i * K + t];
+        const float at = alpha_of(alphas[i * K + t], radius2);
         g_alphas[i * K + t] += -g * f * cum * a / (1.f - at + kAlphaEps);
       }
       cum = cum * (1.f - a);
     }
   }
+  if (radius2 != 0.f)   // chain rule of a = 1 - d / radius2
+    for (int k = 0; k < K && idx[i * K + k] >= 0; ++k) g_alphas[i * K + k] = -g_alphas[i * K + k] / radius2;
 }
 
 }  // namespace
@@ -253,6 +256,9 @@ extern "C" int recmv_rasterize_points(const float* points, const int64_t* cloud_
   } else {
     points_place_kernel<<<pgrid, 256, 0, s>>>(pix_count, npix, pix_offset, total);
   }
+  RECMV_HIP_TRY(hipMemsetAsync(idx, 0xFF, (size_t)(npix * points_per_pixel * 4), s));                  // -1
+  RECMV_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)zbuf, 0xBF800000, (size_t)(npix * points_per_pixel), s));   // -1.f
+  RECMV_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)dists, 0xBF800000, (size_t)(npix * points_per_pixel), s));
   points_resolve_kernel<<<pgrid, 256, 0, s>>>(points, pix_count, pix_offset, entries, npix, (int)H, (int)W,
                                               points_per_pixel, idx, zbuf, dists);
   return check_launch("rasterize_points");
@@ -275,28 +281,30 @@ extern "C" int recmv_rasterize_points_backward(const float* points, const int32_
 
 extern "C" int recmv_alpha_composite_forward(const int32_t* idx, const float* alphas, const float* features,
                                              int64_t N, int64_t H, int64_t W, int points_per_pixel, int64_t C,
-                                             int64_t total_points, float* images, void* stream) {
+                                             int64_t total_points, float radius2, float* images, void* stream) {
   RECMV_REQUIRE(N >= 0 && H > 0 && W > 0 && points_per_pixel > 0 && C > 0 && total_points >= 0,
                 "alpha_composite_forward: bad sizes");
   const int64_t npix = N * H * W;
   if (npix == 0) return RECMV_OK;
   alpha_forward_kernel<<<(unsigned)ceil_div(npix, 256), 256, 0, (hipStream_t)stream>>>(
-      idx, alphas, features, total_points, npix, H * W, points_per_pixel, (int)C, images);
+      idx, alphas, features, total_points, npix, H * W, points_per_pixel, (int)C, radius2, images);
   return check_launch("alpha_composite_forward");
 }
 
 extern "C" int recmv_alpha_composite_backward(const int32_t* idx, const float* alphas, const float* features,
                                               const float* grad_images, int64_t N, int64_t H, int64_t W,
                                               int points_per_pixel, int64_t C, int64_t total_points,
-                                              float* grad_alphas, float* grad_features, void* stream) {
+                                              float radius2, float* grad_alphas, float* grad_features,
+                                              void* stream) {
   RECMV_REQUIRE(N >= 0 && H > 0 && W > 0 && points_per_pixel > 0 && C > 0 && total_points >= 0,
                 "alpha_composite_backward: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   if (grad_features) RECMV_HIP_TRY(hipMemsetAsync(grad_features, 0, (size_t)(C * total_points * sizeof(float)), s));
   const int64_t npix = N * H * W;
   if (npix == 0) return RECMV_OK;
+  RECMV_HIP_TRY(hipMemsetAsync(grad_alphas, 0, (size_t)(npix * points_per_pixel * sizeof(float)), s));
   alpha_backward_kernel<<<(unsigned)ceil_div(npix, 256), 256, 0, s>>>(idx, alphas, features, grad_images, total_points,
                                                                        npix, H * W, points_per_pixel, (int)C,
-                                                                       grad_alphas, grad_features);
+                                                                       radius2, grad_alphas, grad_features);
   return check_launch("alpha_composite_backward");
 }

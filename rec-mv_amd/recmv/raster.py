@@ -148,7 +148,7 @@ class _AlphaComposite(torch.autograd.Function):
     """pytorch3d `alpha_composite` on fragment-major tensors: idx / alphas [N,H,W,K], features [C,P] -> [N,C,H,W]."""
 
     @staticmethod
-    def forward(ctx, idx, alphas, features):
+    def forward(ctx, idx, alphas, features, radius2=0.0):
         for t, name in ((idx, "idx"), (alphas, "alphas"), (features, "features")):
             L.require_cuda(t, name)
             L.require_contiguous(t, name)
@@ -161,9 +161,10 @@ class _AlphaComposite(torch.autograd.Function):
         images = torch.empty((N, C, H, W), dtype=torch.float32, device=idx.device)
         with torch.cuda.device(idx.device):
             L.check(L.lib().recmv_alpha_composite_forward(L.ptr(idx), L.ptr(alphas), L.ptr(features), N, H, W, K, C, P,
-                                                          L.ptr(images), L.stream_ptr(idx.device)),
+                                                          float(radius2), L.ptr(images), L.stream_ptr(idx.device)),
                     "alpha_composite_forward")
         ctx.save_for_backward(idx, alphas, features)
+        ctx.radius2 = float(radius2)
         return images
 
     @staticmethod
@@ -177,13 +178,20 @@ class _AlphaComposite(torch.autograd.Function):
         with torch.cuda.device(idx.device):
             L.check(L.lib().recmv_alpha_composite_backward(
                 L.ptr(idx), L.ptr(alphas), L.ptr(features), L.ptr(g_images.contiguous()), N, H, W, K, C, P,
-                L.ptr(g_alphas), L.ptr(g_features) if g_features is not None else None, L.stream_ptr(idx.device)),
-                "alpha_composite_backward")
-        return None, g_alphas, g_features
+                ctx.radius2, L.ptr(g_alphas), L.ptr(g_features) if g_features is not None else None,
+                L.stream_ptr(idx.device)), "alpha_composite_backward")
+        return None, g_alphas, g_features, None
 
 
 def alpha_composite(idx, alphas, features):
-    return _AlphaComposite.apply(idx, alphas, features)
+    """pytorch3d `alpha_composite` on fragment-major tensors (idx / alphas [N,H,W,K], packed lists)."""
+    return _AlphaComposite.apply(idx, alphas, features, 0.0)
+
+
+def alpha_composite_dists(idx, dists, radius, features):
+    """The compositor on the rasteriser's squared distances: opacities 1 - dists / radius^2 are formed inside the
+    kernels (and their chain rule in the backward) instead of by four full-size element-wise passes."""
+    return _AlphaComposite.apply(idx, dists, features, float(radius) * float(radius))
 
 
 class PointsRendererWithFrags_Split:
@@ -206,8 +214,8 @@ class PointsRendererWithFrags_Split:
         first = torch.arange(N, device=dev, dtype=torch.int64) * V
         num = torch.full((N,), V, device=dev, dtype=torch.int64)
         frags = rasterize_points(ndc, first, num, (H, W), self.radius, self.points_per_pixel, max_points_per_cloud=V)
-        weights = 1 - frags.dists / (self.radius * self.radius)                    # CameraMine.py:361-362
         upper = (torch.arange(N * V, device=dev) % V) < int(split_size)            # :367-372
         features = torch.stack([upper, ~upper]).to(torch.float32).contiguous()
-        images = alpha_composite(frags.idx, weights, features)                     # [N,2,H,W]
+        # weights = 1 - dists / r^2 (CameraMine.py:361-362) fused into the compositor
+        images = alpha_composite_dists(frags.idx, frags.dists, self.radius, features)          # [N,2,H,W]
         return [images[:, 0, :, :, None], images[:, 1, :, :, None]], frags

@@ -206,6 +206,17 @@ def test_rasterize_points_and_composite_vs_oracle(oracle, case):
     _bits(a_gpu.grad, ga_ref, "grad_alphas")
     assert torch.isfinite(ga_ref).all()
     assert torch.allclose(f_gpu.grad.cpu(), gf_ref, rtol=1e-4, atol=1e-5)
+    # fused opacities (1 - dists / r^2 inside the kernels) == the composition of torch ops, values and gradients
+    d1 = frags.dists.detach().clone().requires_grad_(True)
+    d2 = frags.dists.detach().clone().requires_grad_(True)
+    im1 = raster.alpha_composite(frags.idx, 1 - d1 / (r * r), f_gpu.detach())
+    im2 = raster.alpha_composite_dists(frags.idx, d2, r, f_gpu.detach())
+    assert torch.allclose(im1, im2, rtol=1e-5, atol=1e-6)     # torch divides by a scalar as x * (1/s): 1 ulp apart
+    im1.backward(g.to(DEV))
+    im2.backward(g.to(DEV))
+    vg = valid.to(DEV)
+    assert torch.allclose(d1.grad[vg], d2.grad[vg], rtol=1e-4, atol=1e-6 * float(d1.grad[vg].abs().max()))
+    assert (d2.grad[~vg] == 0).all()
     gd = torch.from_numpy(rng.normal(size=tuple(ref[2].shape)).astype(np.float32)) * valid
     gz = torch.from_numpy(rng.normal(size=tuple(ref[2].shape)).astype(np.float32)) * valid
     (frags.dists * gd.to(DEV) + frags.zbuf * gz.to(DEV)).sum().backward()

@@ -473,8 +473,10 @@ class HotLoop:
                                                                               init_pts))
                 pnum = batch_inds.shape[0]
                 if pnum > sample_pix * N:                                               # :1019-1027, host RNG
-                    sel = torch.rand(pnum) < float(sample_pix * N) / float(pnum)
-                    idx = sel.nonzero(as_tuple=True)[0].to(batch_inds.device, non_blocking=False)
+                    # same draw as the reference (torch's host generator); the compare + nonzero run in numpy: torch
+                    # would fork its whole intra-op thread pool for ~1e5 elements (tens of ms on a 256-core host)
+                    sel = torch.rand(pnum).numpy() < float(sample_pix * N) / float(pnum)
+                    idx = torch.from_numpy(np.flatnonzero(sel)).to(batch_inds.device, non_blocking=False)
                     batch_inds, row_inds, col_inds, init_pts = (t[idx] for t in (batch_inds, row_inds, col_inds,
                                                                                  init_pts))
                 rays = cameras.view_rays(torch.cat([col_inds.view(-1, 1), row_inds.view(-1, 1),

@@ -66,3 +66,45 @@ def srays():
 
 
 timed("sample_train_ray (2 rasterisations + FindSurfacePs + sampling)", srays)
+
+# ---- sample_train_ray, section by section (synchronised timers)
+import contextlib  # noqa: E402
+
+
+class T:
+    def __init__(self):
+        self.acc = {}
+
+    @contextlib.contextmanager
+    def __call__(self, name):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        yield
+        torch.cuda.synchronize()
+        self.acc[name] = self.acc.get(name, 0.0) + time.perf_counter() - t0
+
+
+tm = T()
+REP = 5
+for _ in range(REP):
+    tmp_vs = [v.detach().clone() for v in loop.garment_vs]
+    with tm("find_surface_ps"):
+        found = loop.find_surface_ps(def_vs, tmp_vs, cams)
+    for g_i, (b, r, c, p0, _f) in enumerate(found):
+        with tm("gt mask gather + nonzero + 4 index"):
+            gt = loop.dataset.garment_masks(g_i, frame_ids)
+            keep = (gt[b, r, c] > 0.).nonzero(as_tuple=True)[0]
+            b, r, c, p0 = (t[keep] for t in (b, r, c, p0))
+        pnum = b.shape[0]
+        with tm("host rand + nonzero"):
+            import numpy as np
+            sel = torch.rand(pnum).numpy() < float(1024 * N) / float(pnum)
+            idx = torch.from_numpy(np.flatnonzero(sel))
+        with tm("H2D of the index"):
+            idx = idx.to(b.device)
+        with tm("4 index + rays"):
+            b, r, c, p0 = (t[idx] for t in (b, r, c, p0))
+            rays = cams.view_rays(torch.cat([c.view(-1, 1), r.view(-1, 1), torch.ones_like(c.view(-1, 1))], -1).float())
+for k, v in tm.acc.items():
+    print("  %-44s %8.3f ms / call" % (k, v / REP * 1e3))
+print("  pnum", pnum, "threads", torch.get_num_threads())

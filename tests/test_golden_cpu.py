@@ -102,3 +102,46 @@ def test_golden_seg3d_mesh_is_closed_sphere_like():
     g = load("seg3d")
     from test_mc_oracle import mesh_invariants
     assert mesh_invariants(g["verts"], g["faces"]) == 2
+
+
+class _Frags:
+    def __init__(self, p2f, bary):
+        self.pix_to_face, self.bary_coords = p2f, bary
+
+
+def test_find_surface_ps_matches_the_reference_function():
+    """utils/FindSurfacePs.py:7-37 run for real (tests/golden/make_golden_raster.py): same pixels, same faces (bit-exact
+    indices — the "surface-point indices" of the north star), same canonical points; K = 1 shortcut and K = 3 path."""
+    from recmv.utils import FindSurfacePs
+    g = load("findsurface")
+    for suf, p2f, bary in (("", g["pix_to_face"], g["bary"]), ("3", g["pix_to_face3"], g["bary3"])):
+        b, r, c, p0, f = FindSurfacePs(g["verts"], g["faces"], _Frags(p2f, bary))
+        for got, key in ((b, "batch"), (r, "row"), (c, "col"), (f, "finds")):
+            assert torch.equal(got, g[key + suf]), key + suf
+        torch.testing.assert_close(p0, g["init" + suf], rtol=0, atol=1e-7)
+    assert g["batch"].numel() > 1000 and g["batch3"].numel() > 100
+
+
+def test_oracle_rasteriser_reproduces_the_fixture_fragments(oracle):
+    g = load("findsurface")
+    F = g["faces"].shape[0]
+    p2f, zbuf, bary, dists = oracle.rasterize_meshes(g["fv"], torch.tensor([0, F]), torch.tensor([F, F]),
+                                                     (int(g["H"]), int(g["W"])))
+    assert torch.equal(p2f, g["pix_to_face"])
+    assert torch.equal(bary.view(torch.int32), g["bary"].view(torch.int32))
+
+
+def test_camera_ndc_matches_the_reference_calibration_matrix():
+    """transform_points_ndc vs the projection through the reference's own `_get_sfm_calibration_matrix`
+    (model/CameraMine.py:210-300) and MeshRasterizer.transform's view-space depth."""
+    from recmv.model import RectifiedPerspectiveCameras
+    g = load("camera_ndc")
+    cam = RectifiedPerspectiveCameras(g["focal"], g["pp"], g["R"], g["T"], image_size=[(int(g["W"]), int(g["H"]))])
+    out = cam.transform_points_ndc(g["pts"])
+    torch.testing.assert_close(out[:, :2], g["ndc_xy"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out[:, 2], g["view_z"], rtol=0, atol=1e-6)
+    # and the pixel convention that ties it to the rays: NDC x of pixel column c is 1 - (2c+1)/W
+    W, H = int(g["W"]), int(g["H"])
+    pix = cam.project(g["pts"])
+    torch.testing.assert_close(1 - (2 * pix[:, 0] + 1) / W, out[:, 0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(1 - (2 * pix[:, 1] + 1) / H, out[:, 1], rtol=1e-4, atol=1e-5)

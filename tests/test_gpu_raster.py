@@ -258,3 +258,25 @@ def test_points_renderer_split_full_size_properties():
     assert torch.isfinite(cloud.grad).all() and cloud.grad.abs().sum() > 0
     again, frags2 = rend(cloud.detach(), split_size=upper.shape[0])
     assert torch.equal(frags2.idx, frags.idx) and torch.equal(again[0], imgs[0].detach())
+
+
+def test_fixture_fragments_and_reference_surface_points_on_device():
+    """Golden path (tests/golden/findsurface.npz, made with the reference's own FindSurfacePs): the HIP rasteriser gives
+    the fixture's fragments bit for bit, and FindSurfacePs on the device gives the reference's indices."""
+    from pathlib import Path
+    from recmv import raster, utils
+    g = {k: torch.from_numpy(v) for k, v in np.load(Path(__file__).parent / "golden" / "findsurface.npz").items()}
+    F = g["faces"].shape[0]
+    H, W = int(g["H"]), int(g["W"])
+    frags = raster.rasterize_meshes(g["fv"].to(DEV), torch.tensor([0, F], device=DEV), torch.tensor([F, F], device=DEV),
+                                    (H, W), max_faces_per_mesh=F)
+    assert torch.equal(frags.pix_to_face.cpu(), g["pix_to_face"])
+    assert torch.equal(frags.bary_coords.cpu().view(torch.int32), g["bary"].view(torch.int32))
+    b, r, c, p0, f = utils.FindSurfacePs(g["verts"].to(DEV), g["faces"].to(DEV), frags)
+    for got, key in ((b, "batch"), (r, "row"), (c, "col"), (f, "finds")):
+        assert torch.equal(got.cpu(), g[key]), key
+    assert torch.allclose(p0.cpu(), g["init"], rtol=0, atol=1e-6)
+    fr3 = raster.Fragments(g["pix_to_face3"].to(DEV), None, g["bary3"].to(DEV), None)
+    b, r, c, p0, f = utils.FindSurfacePs(g["verts"].to(DEV), g["faces"].to(DEV), fr3)
+    for got, key in ((b, "batch3"), (r, "row3"), (c, "col3"), (f, "finds3")):
+        assert torch.equal(got.cpu(), g[key]), key

@@ -99,32 +99,74 @@ points_place_kernel(const int* __restrict__ pix_count, int64_t npix, int64_t* __
 }
 
 // idx / zbuf / dists arrive pre-filled with -1: only the listed points are written (4 of 5 pixels are empty).
+// A pixel's list is ordered by RANK: the position of an entry is the number of entries with a smaller key (keys are
+// unique: they carry the point index).  Pixels with up to kLightPixel candidates are ranked by their own thread;
+// longer lists (silhouette limbs, folds) are queued and ranked by a whole wavefront each, so that one crowded pixel
+// does not stall the 63 others of its wave for O(n^2) loads.
+constexpr int kLightPixel = 12;
+
+__device__ __forceinline__ void write_fragment(const float* __restrict__ pts, unsigned long long key, int64_t out,
+                                               float xf, float yf, int* __restrict__ idx, float* __restrict__ zbuf,
+                                               float* __restrict__ dists) {
+  const int64_t p = (int64_t)(uint32_t)(key & 0xffffffffull);
+  const float dx = xf - pts[3 * p], dy = yf - pts[3 * p + 1];
+  idx[out] = (int)p;
+  zbuf[out] = __uint_as_float((uint32_t)(key >> 32));
+  dists[out] = dx * dx + dy * dy;
+}
+
 __global__ void __launch_bounds__(256)
 points_resolve_kernel(const float* __restrict__ pts, const int* __restrict__ pix_count,
                       const int64_t* __restrict__ pix_offset, const unsigned long long* __restrict__ entries,
                       int64_t npix, int H, int W, int K, int* __restrict__ idx, float* __restrict__ zbuf,
-                      float* __restrict__ dists) {
+                      float* __restrict__ dists, int* __restrict__ heavy_list, unsigned long long* __restrict__ heavy_n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
   const int cnt = pix_count[i];
   if (cnt == 0) return;
+  if (cnt > kLightPixel) {
+    heavy_list[atomicAdd(heavy_n, 1ull)] = (int)i;   // order of the queue is irrelevant
+    return;
+  }
   const unsigned long long* e = entries + pix_offset[i];
+  unsigned long long v[kLightPixel];
+#pragma unroll
+  for (int j = 0; j < kLightPixel; ++j) v[j] = j < cnt ? e[j] : ~0ull;
   const int64_t pix = i % ((int64_t)H * W);
   const float xf = pix_to_ndc((int)(pix % W), W), yf = pix_to_ndc((int)(pix / W), H);
-  unsigned long long last = 0;
-  const int take = cnt < K ? cnt : K;
-  for (int k = 0; k < take; ++k) {
-    unsigned long long best = ~0ull;
-    for (int j = 0; j < cnt; ++j) {
-      const unsigned long long v = e[j];
-      if ((k == 0 || v > last) && v < best) best = v;
+#pragma unroll
+  for (int j = 0; j < kLightPixel; ++j) {
+    if (j < cnt) {
+      int rank = 0;
+#pragma unroll
+      for (int t = 0; t < kLightPixel; ++t) rank += (v[t] < v[j]) ? 1 : 0;
+      if (rank < K) write_fragment(pts, v[j], i * K + rank, xf, yf, idx, zbuf, dists);
     }
-    last = best;
-    const int64_t p = (int64_t)(uint32_t)(best & 0xffffffffull);
-    const float dx = xf - pts[3 * p], dy = yf - pts[3 * p + 1];
-    idx[i * K + k] = (int)p;
-    zbuf[i * K + k] = __uint_as_float((uint32_t)(best >> 32));
-    dists[i * K + k] = dx * dx + dy * dy;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+points_resolve_heavy_kernel(const float* __restrict__ pts, const int* __restrict__ pix_count,
+                            const int64_t* __restrict__ pix_offset, const unsigned long long* __restrict__ entries,
+                            int H, int W, int K, int* __restrict__ idx, float* __restrict__ zbuf,
+                            float* __restrict__ dists, const int* __restrict__ heavy_list,
+                            const unsigned long long* __restrict__ heavy_n) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) / kWave;
+  const int64_t total = (int64_t)*heavy_n;
+  for (int64_t q = wave; q < total; q += nwaves) {
+    const int64_t i = heavy_list[q];
+    const int cnt = pix_count[i];
+    const unsigned long long* e = entries + pix_offset[i];
+    const int64_t pix = i % ((int64_t)H * W);
+    const float xf = pix_to_ndc((int)(pix % W), W), yf = pix_to_ndc((int)(pix / W), H);
+    for (int j = lane; j < cnt; j += kWave) {
+      const unsigned long long mine = e[j];
+      int rank = 0;
+      for (int t = 0; t < cnt; ++t) rank += (e[t] < mine) ? 1 : 0;   // uniform address: one broadcast load per t
+      if (rank < K) write_fragment(pts, mine, i * K + rank, xf, yf, idx, zbuf, dists);
+    }
   }
 }
 
@@ -178,7 +220,12 @@ alpha_forward_kernel(const int* __restrict__ idx, const float* __restrict__ alph
   }
 }
 
-// g_alphas arrives zero-filled; only listed entries are touched.
+// g_alphas arrives zero-filled; only listed entries are touched.  The published double loop
+//     g_a[t] = sum_c g_c ( cum_t f_tc - sum_{k>t} f_kc cum_k a_k / (1 - a_t + eps) )
+// is linear in g, so with F_k = sum_c g_c f_kc and the "composite seen from behind t"
+//     R_t = sum_{k>t} F_k a_k prod_{t<l<k} (1 - a_l)        (R_{t-1} = F_t a_t + (1 - a_t) R_t, R_last = 0)
+// it becomes  g_a[t] = cum_t ( F_t - R_t (1 - a_t) / (1 - a_t + eps) ):  O(K) per pixel instead of O(K^2), no
+// cancellation and no amplification by 1 / (1 - a_t).  R_t is parked in g_alphas between the two sweeps.
 __global__ void __launch_bounds__(256)
 alpha_backward_kernel(const int* __restrict__ idx, const float* __restrict__ alphas,
                       const float* __restrict__ features, const float* __restrict__ g_images, int64_t P, int64_t npix,
@@ -188,25 +235,41 @@ alpha_backward_kernel(const int* __restrict__ idx, const float* __restrict__ alp
   if (i >= npix) return;
   if (idx[i * K] < 0) return;
   const int64_t n = i / HW, pix = i % HW;
-  for (int c = 0; c < C; ++c) {
-    const float g = g_images[(n * C + c) * HW + pix];
+  int len = 0;
+  if (g_features) {
     float cum = 1.f;
-    for (int k = 0; k < K; ++k) {
-      const int p = idx[i * K + k];
+    for (; len < K; ++len) {
+      const int p = idx[i * K + len];
       if (p < 0) break;
-      const float a = alpha_of(alphas[i * K + k], radius2);
-      const float f = features[(int64_t)c * P + p];
-      if (g_features) atomicAdd(g_features + (int64_t)c * P + p, cum * a * g);
-      g_alphas[i * K + k] += cum * f * g;
-      for (int t = 0; t < k; ++t) {
-        const float at = alpha_of(alphas[i * K + t], radius2);
-        g_alphas[i * K + t] += -g * f * cum * a / (1.f - at + kAlphaEps);
-      }
+      const float a = alpha_of(alphas[i * K + len], radius2);
+      for (int c = 0; c < C; ++c)
+        atomicAdd(g_features + (int64_t)c * P + p, cum * a * g_images[(n * C + c) * HW + pix]);
       cum = cum * (1.f - a);
     }
+  } else {
+    while (len < K && idx[i * K + len] >= 0) ++len;
   }
-  if (radius2 != 0.f)   // chain rule of a = 1 - d / radius2
-    for (int k = 0; k < K && idx[i * K + k] >= 0; ++k) g_alphas[i * K + k] = -g_alphas[i * K + k] / radius2;
+  float R = 0.f;
+  for (int t = len - 1; t >= 0; --t) {
+    const int p = idx[i * K + t];
+    const float a = alpha_of(alphas[i * K + t], radius2);
+    float F = 0.f;
+    for (int c = 0; c < C; ++c) F += g_images[(n * C + c) * HW + pix] * features[(int64_t)c * P + p];
+    g_alphas[i * K + t] = R;
+    R = F * a + (1.f - a) * R;
+  }
+  float cum = 1.f;
+  for (int t = 0; t < len; ++t) {
+    const int p = idx[i * K + t];
+    const float a = alpha_of(alphas[i * K + t], radius2);
+    float F = 0.f;
+    for (int c = 0; c < C; ++c) F += g_images[(n * C + c) * HW + pix] * features[(int64_t)c * P + p];
+    const float one_m = 1.f - a;
+    float ga = cum * (F - g_alphas[i * K + t] * (one_m / (one_m + kAlphaEps)));
+    if (radius2 != 0.f) ga = -ga / radius2;   // chain rule of a = 1 - d / radius2
+    g_alphas[i * K + t] = ga;
+    cum = cum * one_m;
+  }
 }
 
 }  // namespace
@@ -259,8 +322,12 @@ extern "C" int recmv_rasterize_points(const float* points, const int64_t* cloud_
   RECMV_HIP_TRY(hipMemsetAsync(idx, 0xFF, (size_t)(npix * points_per_pixel * 4), s));                  // -1
   RECMV_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)zbuf, 0xBF800000, (size_t)(npix * points_per_pixel), s));   // -1.f
   RECMV_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)dists, 0xBF800000, (size_t)(npix * points_per_pixel), s));
+  // the fill cursors are dead after the fill pass: their storage becomes the queue of crowded pixels
+  unsigned long long* heavy_n = total + 1;
   points_resolve_kernel<<<pgrid, 256, 0, s>>>(points, pix_count, pix_offset, entries, npix, (int)H, (int)W,
-                                              points_per_pixel, idx, zbuf, dists);
+                                              points_per_pixel, idx, zbuf, dists, pix_cursor, heavy_n);
+  points_resolve_heavy_kernel<<<kNumCU * 4, 256, 0, s>>>(points, pix_count, pix_offset, entries, (int)H, (int)W,
+                                                         points_per_pixel, idx, zbuf, dists, pix_cursor, heavy_n);
   return check_launch("rasterize_points");
 }
 

@@ -187,7 +187,7 @@ def test_rasterize_points_and_composite_vs_oracle(oracle, case):
     for name, a, b in zip(("idx", "zbuf", "dists"), frags, ref):
         _bits(a.detach(), b, name)
     assert (ref[0] >= 0).sum() > 100
-    # compositor: forward and grad_alphas are fixed-order sums -> bit-exact; grad_features / grad_points use atomics
+    # compositor: the forward is a fixed-order sum -> bit-exact; grad_features / grad_points use atomics
     rng = np.random.default_rng(case["seed"] + 100)
     feats = torch.from_numpy(rng.uniform(0, 1, size=(2, sum(n))).astype(np.float32))
     valid = ref[0] >= 0
@@ -203,8 +203,10 @@ def test_rasterize_points_and_composite_vs_oracle(oracle, case):
     g = torch.from_numpy(rng.normal(size=tuple(img_ref.shape)).astype(np.float32))
     img.backward(g.to(DEV))
     ga_ref, gf_ref = oracle.alpha_composite_backward(ref[0], alphas_ref, feats, g)
-    _bits(a_gpu.grad, ga_ref, "grad_alphas")
-    assert torch.isfinite(ga_ref).all()
+    # grad_alphas: the kernel evaluates the published O(K^2) double loop through an O(K) suffix recursion
+    # (different summation order) -> tolerance, not bits
+    assert torch.isfinite(ga_ref).all() and torch.isfinite(a_gpu.grad).all()
+    assert torch.allclose(a_gpu.grad.cpu(), ga_ref, rtol=1e-4, atol=2e-6 * float(ga_ref.abs().max()))
     assert torch.allclose(f_gpu.grad.cpu(), gf_ref, rtol=1e-4, atol=1e-5)
     # fused opacities (1 - dists / r^2 inside the kernels) == the composition of torch ops, values and gradients
     d1 = frags.dists.detach().clone().requires_grad_(True)

@@ -220,6 +220,9 @@ def main():
     from recmv.loop import HotLoop
     import torch.distributed as tdist
 
+    # the loop's host side only launches kernels; torch's intra-op pool (one thread per core: 256 here) makes every
+    # small CPU op (index bookkeeping, the ray sampler's host RNG) pay a fork/join of the whole pool
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
     rank, local_rank, world = rdist.init_distributed()
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
     if world != args.gpus and world > 1:

@@ -74,6 +74,7 @@ def main(argv=None):
     from recmv.hocon import ConfigFactory
     from recmv.loop import HotLoop
 
+    torch.set_num_threads(min(8, os.cpu_count() or 1))     # host side only launches kernels (see bench.py)
     config = ConfigFactory.parse_file(args.conf)
     rank, local_rank, world = rdist.init_distributed()
     assert torch.cuda.is_available(), "train.py needs a GPU (librecmv_hip.so has no CPU fallback)"

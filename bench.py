@@ -92,7 +92,7 @@ def mc_extract_timing(device):
 
     def query(points):
         with torch.no_grad():
-            return sdf.forward(points.reshape(-1, 3), 1.0).reshape(1, 1, -1)
+            return sdf.forward(points.reshape(-1, 3), 1.0, features=False).reshape(1, 1, -1)   # as the loop's query
 
     eng = Seg3dLossless(query_func=query, b_min=[-1, -1, -1], b_max=[1, 1, 1],
                         resolutions=[(33, 33, 33), (65, 65, 65), (129, 129, 129), (257, 257, 257)],

@@ -357,7 +357,8 @@ class HotLoop:
         def run(net):
             def query(points):
                 with torch.no_grad():
-                    return net.forward(points.reshape(-1, 3), ratio).reshape(1, 1, -1)
+                    # only the SDF value is read here: skip the 256 render-feature rows of the last layer
+                    return net.forward(points.reshape(-1, 3), ratio, features=False).reshape(1, 1, -1)
             engine.balance_value = balance_value
             engine.query_func = query
             sdfs = engine.forward()

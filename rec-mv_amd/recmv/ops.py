@@ -20,8 +20,12 @@ from . import _lib as L
 
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = L.ACT_NONE, L.ACT_RELU, L.ACT_SOFTPLUS, L.ACT_TANH
 
-_tn_ws = {}
+_tn_ws = {}      # scratch per (device, stream): kernels of concurrent streams must not share a workspace
 _lb_ws = {}
+
+
+def _ws_key(dev):
+    return (dev.index, torch.cuda.current_stream(dev).cuda_stream)
 
 
 def transposed(W):
@@ -46,10 +50,10 @@ def linear_backward(gy, y, x, W, act, act_param, need_gx=True, need_gW=True, nee
     dev = gy.device
     lib = L.lib()
     need = int(lib.recmv_linear_backward_workspace_bytes(M, N, K))
-    ws = _lb_ws.get(dev.index)
+    ws = _lb_ws.get(_ws_key(dev))
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        _lb_ws[dev.index] = ws
+        _lb_ws[_ws_key(dev)] = ws
     gx = torch.empty((M, K), dtype=torch.float32, device=dev) if need_gx else None
     gW = torch.empty((N, K), dtype=torch.float32, device=dev) if need_gW else None
     gb = torch.empty((N,), dtype=torch.float32, device=dev) if need_gb else None
@@ -110,7 +114,7 @@ def gemm_tn(A, B):
     lib = L.lib()
     with torch.cuda.device(A.device):
         need = int(lib.recmv_gemm_tn_workspace_bytes(M, N, K))
-        key = A.device.index
+        key = _ws_key(A.device)
         ws = _tn_ws.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.empty(max(need, 256), dtype=torch.uint8, device=A.device)

@@ -1,0 +1,143 @@
+"""Kernel-only durations of the HBM-bound kernels at named shapes, from a rocprofv3 kernel trace.
+
+The event-based micro-benchmark (tools/microbench.py) cannot see below ~20 us: the GPU waits for the python wrapper
+between the two events.  Here every case is a run of identical launches bracketed by a separator kernel, the trace is
+read back from the rocpd database in start order, and each segment is reported per kernel name.
+
+    # on the GPU box
+    cd /tmp && rocprofv3 --kernel-trace -d /tmp/ko -o run -- python $REPO/tools/kernel_only.py run /tmp/ko_cases.json
+    python tools/kernel_only.py report /tmp/ko /tmp/ko_cases.json > profiles/<name>.txt
+"""
+import glob
+import json
+import sqlite3
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(REPO / "rec-mv_amd"), str(REPO), str(REPO / "tools")]
+REPS = 10
+HBM_PEAK = 8.0e12
+
+
+def run(out_json):
+    import torch
+    from recmv import FastMinv, GridSamplerMine, MCGpu, interp2x_boundary3d, raster
+    dev = "cuda:0"
+    cases = []
+    sep = torch.zeros(257, device=dev)
+
+    def case(name, nbytes, fn):
+        torch.sort(sep)                          # (the warm-up call gets a segment of its own, skipped by the report)
+        fn()
+        torch.cuda.synchronize()
+        torch.sort(sep)                          # separator launch: a (rocprim) sort kernel nothing else here uses
+        for _ in range(REPS):
+            fn()
+        torch.cuda.synchronize()
+        cases.append({"name": name, "alg_bytes": int(nbytes)})
+
+    # ---- sampler on the skinning grid (channels-last), random and surface-coherent points
+    C, D, H, W = 24, 65, 225, 129
+    vol = torch.softmax(2 * torch.randn(1, C, D, H, W, device=dev), dim=1).contiguous(memory_format=torch.channels_last_3d)
+    for P in (153600, 460800, 1 << 20, 1 << 22):
+        n = int(round(P ** 0.5))
+        u, v = torch.meshgrid(torch.linspace(-0.9, 0.9, n, device=dev), torch.linspace(-0.9, 0.9, n, device=dev),
+                              indexing="ij")
+        surf = torch.stack([u, v, 0.3 * torch.sin(3 * u) * torch.cos(2 * v)], -1).view(1, 1, 1, -1, 3).contiguous()
+        Pc = surf.shape[3]
+        go = torch.randn(1, C, 1, 1, Pc, device=dev)
+        gg = torch.randn(1, 1, 1, Pc, 3, device=dev)
+        case(f"sampler fwd, surface-coherent P={Pc} (coords + output bytes)", Pc * (12 + 4 * C),
+             lambda: GridSamplerMine.forward(vol, surf, 0, 1))
+        case(f"sampler bwd (grid only), surface-coherent P={Pc}", Pc * (12 + 4 * C + 12),
+             lambda: GridSamplerMine.backward(vol, surf, go, 0, 1, need_grad_input=False))
+        case(f"sampler dbwd, surface-coherent P={Pc}", Pc * (12 + 12 + 4 * C + 12 + 4 * C),
+             lambda: GridSamplerMine.dbackward(None, gg, vol, surf, go, 0, 1, need_grad_input=False))
+        if P <= (1 << 20):
+            grid = (torch.rand(1, 1, 1, P, 3, device=dev) - 0.5) * 2.2
+            case(f"sampler fwd, uniformly random P={P} (+ touched records)", P * (12 + 4 * C) + min(4 * C * D * H * W, 32 * C * P),
+                 lambda: GridSamplerMine.forward(vol, grid, 0, 1))
+    # ---- 3x3 inverse
+    for n in (1 << 20, 1 << 24):
+        ms = torch.randn(n, 3, 3, device=dev)
+        case(f"inv3x3 fwd n={n}", 73 * n, lambda: FastMinv.Fast3x3Minv(ms))
+    # ---- 2x boundary upsampler
+    for n in (65, 129):
+        x = torch.randn(1, 1, n, n, n, device=dev)
+        case(f"interp2x fwd {n}^3 -> {2 * n - 1}^3", 4 * n ** 3 + 5 * (2 * n - 1) ** 3,
+             lambda: interp2x_boundary3d.forward(x, 0.0))
+    # ---- marching cubes (count + emit: classify / scan / emit kernels reported separately)
+    from microbench import body_like_volume
+    for n in (257, 385):
+        vol3 = body_like_volume(n)
+        step = 2.0 / (n - 1)
+        v, f = MCGpu.mc_gpu(vol3, step, step, step, -1.0, -1.0, -1.0, 0.0)
+        case(f"mc_gpu {n}^3 (V={v.shape[0]}, F={f.shape[0]}): volume + vertices + faces", 4 * n ** 3 + 12 * v.shape[0] + 24 * f.shape[0],
+             lambda: MCGpu.mc_gpu(vol3, step, step, step, -1.0, -1.0, -1.0, 0.0))
+    # ---- first-hit mesh rasteriser
+    vol3 = body_like_volume(193)
+    step = 2.0 / 192
+    v, f = MCGpu.mc_gpu(vol3, step, step, step, -1.0, -1.0, -1.0, 0.0)
+    from recmv.model import RectifiedPerspectiveCameras
+    cam = RectifiedPerspectiveCameras(torch.tensor([[1000., 1000.]], device=dev), torch.tensor([[256., 256.]], device=dev),
+                                      torch.diag(torch.tensor([-1., -1., 1.])).view(1, 3, 3).to(dev),
+                                      torch.tensor([[0., 0., 3.]], device=dev), image_size=[(512, 512)])
+    N = 3
+    dv = (0.55 * v)[None].repeat(N, 1, 1) + 0.02 * torch.arange(N, device=dev).view(N, 1, 1)
+    ndc = cam.transform_points_ndc(dv.reshape(-1, 3)).view(N, -1, 3)
+    fv = ndc[:, f.reshape(-1)].reshape(-1, 3, 3).contiguous()
+    F = f.shape[0]
+    first = torch.arange(N, device=dev) * F
+    num = torch.full((N,), F, device=dev, dtype=torch.int64)
+    case(f"rasterize_meshes 3x512x512, {F} faces/mesh", 36 * N * F + N * 512 * 512 * 48,
+         lambda: raster.rasterize_meshes(fv, first, num, (512, 512), max_faces_per_mesh=F))
+    pts = ndc.reshape(-1, 3).contiguous()
+    V = v.shape[0]
+    pfirst = torch.arange(N, device=dev) * V
+    pnum = torch.full((N,), V, device=dev, dtype=torch.int64)
+    case(f"rasterize_points 3x512x512, {V} points/cloud, K=50, r=0.006", 12 * N * V + N * 512 * 512 * 50 * 12,
+         lambda: raster.rasterize_points(pts, pfirst, pnum, (512, 512), 0.006, 50, max_points_per_cloud=V))
+    json.dump(cases, open(out_json, "w"))
+
+
+def report(prof_dir, cases_json):
+    cases = json.load(open(cases_json))
+    db = glob.glob(prof_dir + "/**/*.db", recursive=True)[0]
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+
+    def is_sep(name):
+        return "recmv::" not in name and "sort" in name.lower()
+
+    # a case = the recmv launches between one separator (sort) and the next; cases without REPS launches of some
+    # kernel are the single warm-up calls and are skipped
+    out, body, ci = [], None, 0
+    for name, s, e in rows + [("sort (sentinel)", 0, 0)]:
+        if is_sep(name):
+            if body and max(len(v) for v in body.values()) >= REPS and ci < len(cases):
+                out.append((cases[ci], body))
+                ci += 1
+            body = {}
+        elif body is not None and "recmv::" in name:
+            body.setdefault(name, []).append(e - s)
+    print("# kernel-only durations (rocprofv3 --kernel-trace), %d launches per case; GB/s = algorithmic bytes / sum of the"
+          " case's kernels" % REPS)
+    for c, body in out:
+        tot, parts = 0.0, []
+        for k, d in body.items():
+            tot += sum(d) / REPS
+            short = k.split("recmv::(anonymous namespace)::")[-1].split("(")[0]
+            parts.append("%s %.1f us x%d" % (short, (sum(d) / len(d)) / 1e3, max(len(d) // REPS, 1)))
+        gbs = c["alg_bytes"] / (tot * 1e-9) / 1e9
+        print("%-78s %9.1f us  %8.1f GB/s  %.3f of 8 TB/s   [%s]" % (c["name"], tot / 1e3, gbs, gbs * 1e9 / HBM_PEAK,
+                                                                    "; ".join(parts)))
+    if ci != len(cases):
+        print("# WARNING: matched %d of %d cases" % (ci, len(cases)))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(sys.argv[2])
+    else:
+        report(sys.argv[2], sys.argv[3])

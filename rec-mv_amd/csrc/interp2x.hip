@@ -6,9 +6,9 @@
 // (v > balance).  Equivalent to F.interpolate(trilinear, align_corners=True) + (0 < valid < 1)
 // (MCAcc/seg3d_lossless.py:273-282).
 //
-// Design: one lane per output voxel, x fastest, so a wave reads <= 2 source rows (L1/L2 resident) and
-// writes 256 contiguous bytes of f32 plus 64 contiguous mask bytes; grid-stride over a capped grid on
-// the caller's stream (the reference launches 1024-thread blocks on the default stream).  The sources
+// Design: forward = one lane per source cell, lanes along x (8 coalesced row loads -> up to 8 outputs, see the
+// kernel); backward = one lane per input voxel gathering its 27 output neighbours; both on the caller's stream
+// (the reference launches 1024-thread blocks of single voxels on the default stream).  The sources
 // are summed in the reference's order (v1..v8) so results match its CUDA build bit for bit.
 //
 // Algorithmic bytes: 4 n^3 in + 5 (2n-1)^3 out (forward); 4 (2n-1)^3 in + 4 n^3 out (backward).
@@ -20,63 +20,66 @@ namespace {
 constexpr int kBlk = 256;
 #pragma clang fp contract(off)
 
+// One lane per SOURCE CELL (t, u, v): its 8 corner values c[z][y][x] are loaded once (coalesced along x) and produce
+// the up to 8 outputs (2t+a, 2u+b, 2v+c), a, b, c in {0,1}, that lie inside the cell: no per-output index
+// arithmetic, no parity divergence, every source value is fetched once per neighbouring cell instead of once per
+// output, and the two x-parities of a lane are adjacent in memory.  The sums keep the reference's source order (x
+// fastest, then y, then z; the skip_x / skip_y 4-point cases z fastest) and the mean is a multiplication by the
+// exact power of two 1/2, 1/4, 1/8 — bit-identical to `(sum)/2.`, `/4.0`, `/8.0` in double + store rounding.
 template <typename T>
-__global__ __launch_bounds__(kBlk) void interp2x_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
-                                                            uint8_t* __restrict__ bnd, int64_t bc,
+__device__ __forceinline__ void put(T* __restrict__ out, uint8_t* __restrict__ bnd, int64_t o, T s, T scale,
+                                    bool differ) {
+  out[o] = s * scale;
+  bnd[o] = differ ? 1 : 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void interp2x_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                            uint8_t* __restrict__ bnd, int64_t rows,
                                                             int d, int h, int w, float balance) {
   const int D = 2 * d - 1, H = 2 * h - 1, W = 2 * w - 1;
-  const int64_t total = bc * D * H * W;
-  for (int64_t i = (int64_t)blockIdx.x * kBlk + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlk) {
-    const int x = (int)(i % W);
-    const int y = (int)((i / W) % H);
-    const int z = (int)((i / ((int64_t)H * W)) % D);
-    const int64_t b = i / ((int64_t)D * H * W);
+  const T bal = (T)balance;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int u = (int)(row % h);
+    const int t = (int)((row / h) % d);
+    const int64_t b = row / ((int64_t)h * d);
+    const bool hy = u < h - 1, hz = t < d - 1;          // odd y / odd z outputs exist for this cell row
+    const int u1 = hy ? u + 1 : u, t1 = hz ? t + 1 : t;
     const T* src = in + b * (int64_t)d * h * w;
-    const int x0 = (x - (x & 1)) >> 1, x1 = (x + (x & 1)) >> 1;  // (x-1)/2,(x+1)/2 for odd; x/2 for even
-    const int y0 = (y - (y & 1)) >> 1, y1 = (y + (y & 1)) >> 1;
-    const int z0 = (z - (z & 1)) >> 1, z1 = (z + (z & 1)) >> 1;
-    const int ox = x & 1, oy = y & 1, oz = z & 1;
-    // Source order of the reference: x fastest, then y, then z for the 2-D/3-D stencils that include x;
-    // the (skip_x) 4-point case iterates z fastest then y, the (skip_y) case z fastest then x.
-    T v[8];
-    int cnt = 0;
-    auto at = [&](int zz, int yy, int xx) { return src[((int64_t)zz * h + yy) * w + xx]; };
-    if (!ox && !oy && !oz) {
-      out[i] = at(z0, y0, x0);
-      bnd[i] = 0;
-      continue;
-    } else if (ox && oy && oz) {
-      v[0] = at(z0, y0, x0); v[1] = at(z0, y0, x1); v[2] = at(z0, y1, x0); v[3] = at(z0, y1, x1);
-      v[4] = at(z1, y0, x0); v[5] = at(z1, y0, x1); v[6] = at(z1, y1, x0); v[7] = at(z1, y1, x1);
-      cnt = 8;
-    } else if (ox && oy) {  // skip_z
-      v[0] = at(z0, y0, x0); v[1] = at(z0, y0, x1); v[2] = at(z0, y1, x0); v[3] = at(z0, y1, x1);
-      cnt = 4;
-    } else if (oy && oz) {  // skip_x: v1=(z-,y-) v2=(z+,y-) v3=(z-,y+) v4=(z+,y+)
-      v[0] = at(z0, y0, x0); v[1] = at(z1, y0, x0); v[2] = at(z0, y1, x0); v[3] = at(z1, y1, x0);
-      cnt = 4;
-    } else if (ox && oz) {  // skip_y: v1=(z-,x-) v2=(z+,x-) v3=(z-,x+) v4=(z+,x+)
-      v[0] = at(z0, y0, x0); v[1] = at(z1, y0, x0); v[2] = at(z0, y0, x1); v[3] = at(z1, y0, x1);
-      cnt = 4;
-    } else if (oy) {
-      v[0] = at(z0, y0, x0); v[1] = at(z0, y1, x0);
-      cnt = 2;
-    } else if (ox) {
-      v[0] = at(z0, y0, x0); v[1] = at(z0, y0, x1);
-      cnt = 2;
-    } else {  // oz
-      v[0] = at(z0, y0, x0); v[1] = at(z1, y0, x0);
-      cnt = 2;
+    const T* r00 = src + ((int64_t)t * h + u) * w;       // (z-, y-)
+    const T* r01 = src + ((int64_t)t * h + u1) * w;      // (z-, y+)
+    const T* r10 = src + ((int64_t)t1 * h + u) * w;      // (z+, y-)
+    const T* r11 = src + ((int64_t)t1 * h + u1) * w;     // (z+, y+)
+    const int64_t o00 = ((b * D + 2 * t) * H + 2 * u) * (int64_t)W;     // output rows (z, y) of this cell row
+    const int64_t o01 = o00 + W, o10 = o00 + (int64_t)H * W, o11 = o10 + W;
+    for (int v = threadIdx.x; v < w; v += blockDim.x) {
+      const bool hx = v < w - 1;
+      const int v1 = hx ? v + 1 : v;
+      const T c000 = r00[v], c001 = r00[v1], c010 = r01[v], c011 = r01[v1];
+      const T c100 = r10[v], c101 = r10[v1], c110 = r11[v], c111 = r11[v1];
+      const bool f = c000 > bal;
+      const bool g001 = (c001 > bal) != f, g010 = (c010 > bal) != f, g011 = (c011 > bal) != f;
+      const bool g100 = (c100 > bal) != f, g101 = (c101 > bal) != f, g110 = (c110 > bal) != f;
+      const bool g111 = (c111 > bal) != f;
+      const int x = 2 * v;
+      out[o00 + x] = c000;
+      bnd[o00 + x] = 0;
+      if (hx) put(out, bnd, o00 + x + 1, c000 + c001, (T)0.5, g001);
+      if (hy) {
+        put(out, bnd, o01 + x, c000 + c010, (T)0.5, g010);
+        if (hx) put(out, bnd, o01 + x + 1, ((c000 + c001) + c010) + c011, (T)0.25, g001 || g010 || g011);
+      }
+      if (hz) {
+        put(out, bnd, o10 + x, c000 + c100, (T)0.5, g100);
+        if (hx) put(out, bnd, o10 + x + 1, ((c000 + c100) + c001) + c101, (T)0.25, g100 || g001 || g101);   // skip_y
+        if (hy) {
+          put(out, bnd, o11 + x, ((c000 + c100) + c010) + c110, (T)0.25, g100 || g010 || g110);           // skip_x
+          if (hx)
+            put(out, bnd, o11 + x + 1, ((((((c000 + c001) + c010) + c011) + c100) + c101) + c110) + c111, (T)0.125,
+                g001 || g010 || g011 || g100 || g101 || g110 || g111);
+        }
+      }
     }
-    T s = v[0];
-    bool f0 = v[0] > (T)balance, differ = false;
-    for (int k = 1; k < cnt; ++k) {
-      s = s + v[k];
-      differ |= ((v[k] > (T)balance) != f0);
-    }
-    // (sum)/2., /4.0, /8.0 in the reference: exact scaling by a power of two in either precision
-    out[i] = (T)((double)s / (double)cnt);
-    bnd[i] = differ ? 1 : 0;
   }
 }
 
@@ -96,34 +99,34 @@ __global__ __launch_bounds__(kBlk) void interp2x_bwd_kernel(const T* __restrict_
     const int X = 2 * x, Y = 2 * y, Z = 2 * z;
     T grad = at(Z, Y, X);
     // 6 edge neighbours (weight 1/2), order of interp2x_boundary3d_kernel.cu:180-191
-    if (xm) grad = (T)((double)grad + (double)at(Z, Y, X - 1) / 2.0);
-    if (xp) grad = (T)((double)grad + (double)at(Z, Y, X + 1) / 2.0);
-    if (ym) grad = (T)((double)grad + (double)at(Z, Y - 1, X) / 2.0);
-    if (yp) grad = (T)((double)grad + (double)at(Z, Y + 1, X) / 2.0);
-    if (zm) grad = (T)((double)grad + (double)at(Z - 1, Y, X) / 2.0);
-    if (zp) grad = (T)((double)grad + (double)at(Z + 1, Y, X) / 2.0);
+    if (xm) grad = (T)((double)grad + (double)at(Z, Y, X - 1) * 0.5);
+    if (xp) grad = (T)((double)grad + (double)at(Z, Y, X + 1) * 0.5);
+    if (ym) grad = (T)((double)grad + (double)at(Z, Y - 1, X) * 0.5);
+    if (yp) grad = (T)((double)grad + (double)at(Z, Y + 1, X) * 0.5);
+    if (zm) grad = (T)((double)grad + (double)at(Z - 1, Y, X) * 0.5);
+    if (zp) grad = (T)((double)grad + (double)at(Z + 1, Y, X) * 0.5);
     // 12 face neighbours (weight 1/4): xy, xz, yz  (:194-219)
-    if (xm && ym) grad = (T)((double)grad + (double)at(Z, Y - 1, X - 1) / 4.0);
-    if (xp && ym) grad = (T)((double)grad + (double)at(Z, Y - 1, X + 1) / 4.0);
-    if (xm && yp) grad = (T)((double)grad + (double)at(Z, Y + 1, X - 1) / 4.0);
-    if (xp && yp) grad = (T)((double)grad + (double)at(Z, Y + 1, X + 1) / 4.0);
-    if (xm && zm) grad = (T)((double)grad + (double)at(Z - 1, Y, X - 1) / 4.0);
-    if (xp && zm) grad = (T)((double)grad + (double)at(Z - 1, Y, X + 1) / 4.0);
-    if (xm && zp) grad = (T)((double)grad + (double)at(Z + 1, Y, X - 1) / 4.0);
-    if (xp && zp) grad = (T)((double)grad + (double)at(Z + 1, Y, X + 1) / 4.0);
-    if (ym && zm) grad = (T)((double)grad + (double)at(Z - 1, Y - 1, X) / 4.0);
-    if (yp && zm) grad = (T)((double)grad + (double)at(Z - 1, Y + 1, X) / 4.0);
-    if (ym && zp) grad = (T)((double)grad + (double)at(Z + 1, Y - 1, X) / 4.0);
-    if (yp && zp) grad = (T)((double)grad + (double)at(Z + 1, Y + 1, X) / 4.0);
+    if (xm && ym) grad = (T)((double)grad + (double)at(Z, Y - 1, X - 1) * 0.25);
+    if (xp && ym) grad = (T)((double)grad + (double)at(Z, Y - 1, X + 1) * 0.25);
+    if (xm && yp) grad = (T)((double)grad + (double)at(Z, Y + 1, X - 1) * 0.25);
+    if (xp && yp) grad = (T)((double)grad + (double)at(Z, Y + 1, X + 1) * 0.25);
+    if (xm && zm) grad = (T)((double)grad + (double)at(Z - 1, Y, X - 1) * 0.25);
+    if (xp && zm) grad = (T)((double)grad + (double)at(Z - 1, Y, X + 1) * 0.25);
+    if (xm && zp) grad = (T)((double)grad + (double)at(Z + 1, Y, X - 1) * 0.25);
+    if (xp && zp) grad = (T)((double)grad + (double)at(Z + 1, Y, X + 1) * 0.25);
+    if (ym && zm) grad = (T)((double)grad + (double)at(Z - 1, Y - 1, X) * 0.25);
+    if (yp && zm) grad = (T)((double)grad + (double)at(Z - 1, Y + 1, X) * 0.25);
+    if (ym && zp) grad = (T)((double)grad + (double)at(Z + 1, Y - 1, X) * 0.25);
+    if (yp && zp) grad = (T)((double)grad + (double)at(Z + 1, Y + 1, X) * 0.25);
     // 8 corner neighbours (weight 1/8)  (:222-237)
-    if (xm && ym && zm) grad = (T)((double)grad + (double)at(Z - 1, Y - 1, X - 1) / 8.0);
-    if (xp && ym && zm) grad = (T)((double)grad + (double)at(Z - 1, Y - 1, X + 1) / 8.0);
-    if (xm && yp && zm) grad = (T)((double)grad + (double)at(Z - 1, Y + 1, X - 1) / 8.0);
-    if (xp && yp && zm) grad = (T)((double)grad + (double)at(Z - 1, Y + 1, X + 1) / 8.0);
-    if (xm && ym && zp) grad = (T)((double)grad + (double)at(Z + 1, Y - 1, X - 1) / 8.0);
-    if (xp && ym && zp) grad = (T)((double)grad + (double)at(Z + 1, Y - 1, X + 1) / 8.0);
-    if (xm && yp && zp) grad = (T)((double)grad + (double)at(Z + 1, Y + 1, X - 1) / 8.0);
-    if (xp && yp && zp) grad = (T)((double)grad + (double)at(Z + 1, Y + 1, X + 1) / 8.0);
+    if (xm && ym && zm) grad = (T)((double)grad + (double)at(Z - 1, Y - 1, X - 1) * 0.125);
+    if (xp && ym && zm) grad = (T)((double)grad + (double)at(Z - 1, Y - 1, X + 1) * 0.125);
+    if (xm && yp && zm) grad = (T)((double)grad + (double)at(Z - 1, Y + 1, X - 1) * 0.125);
+    if (xp && yp && zm) grad = (T)((double)grad + (double)at(Z - 1, Y + 1, X + 1) * 0.125);
+    if (xm && ym && zp) grad = (T)((double)grad + (double)at(Z + 1, Y - 1, X - 1) * 0.125);
+    if (xp && ym && zp) grad = (T)((double)grad + (double)at(Z + 1, Y - 1, X + 1) * 0.125);
+    if (xm && yp && zp) grad = (T)((double)grad + (double)at(Z + 1, Y + 1, X - 1) * 0.125);
+    if (xp && yp && zp) grad = (T)((double)grad + (double)at(Z + 1, Y + 1, X + 1) * 0.125);
     gi[i] = grad;
   }
 }
@@ -140,15 +143,16 @@ extern "C" int recmv_interp2x_boundary3d_forward(const void* input, void* output
   if (bc == 0 || d == 0 || h == 0 || w == 0) return RECMV_OK;
   RECMV_REQUIRE(input && output && is_boundary, "interp2x_forward: NULL pointer");
   RECMV_REQUIRE(d < (1 << 30) && h < (1 << 30) && w < (1 << 30), "interp2x_forward: size too large");
-  const int64_t total = bc * (2 * d - 1) * (2 * h - 1) * (2 * w - 1);
+  const int64_t rows = bc * d * h;                       // rows of source cells
   hipStream_t s = (hipStream_t)stream;
-  const int g = stream_grid(total, kBlk);
+  const int blk = (int)(w >= 256 ? 256 : ceil_div(w, kWave) * kWave);
+  const unsigned g = (unsigned)(rows < (1ll << 30) ? rows : (1ll << 30));
   if (dtype == RECMV_F32)
-    hipLaunchKernelGGL(interp2x_fwd_kernel<float>, dim3(g), dim3(kBlk), 0, s, (const float*)input,
-                       (float*)output, is_boundary, bc, (int)d, (int)h, (int)w, balance_value);
+    hipLaunchKernelGGL(interp2x_fwd_kernel<float>, dim3(g), dim3(blk), 0, s, (const float*)input,
+                       (float*)output, is_boundary, rows, (int)d, (int)h, (int)w, balance_value);
   else if (dtype == RECMV_F64)
-    hipLaunchKernelGGL(interp2x_fwd_kernel<double>, dim3(g), dim3(kBlk), 0, s, (const double*)input,
-                       (double*)output, is_boundary, bc, (int)d, (int)h, (int)w, balance_value);
+    hipLaunchKernelGGL(interp2x_fwd_kernel<double>, dim3(g), dim3(blk), 0, s, (const double*)input,
+                       (double*)output, is_boundary, rows, (int)d, (int)h, (int)w, balance_value);
   else {
     set_error("interp2x_forward: dtype %d unsupported", dtype);
     return RECMV_ERR_UNSUPPORTED;

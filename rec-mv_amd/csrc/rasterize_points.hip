@@ -11,7 +11,7 @@
 // How: pytorch3d walks every pixel over every point (naive) or over per-bin point lists (coarse-to-fine).  A splat of
 // radius 1.5 pixels covers ~7 pixel centres, so the work here is organised by POINT:
 //   count    one thread per point: +1 on every pixel centre inside its disc
-//   place    one thread per pixel: wave prefix sum of the counts + ONE atomicAdd per wave reserves list storage
+//   place    one thread per pixel: prefix sum of the counts + ONE atomicAdd per workgroup reserves list storage
 //   fill     one thread per point: writes (depth bits << 32 | point index) into the lists of its pixels
 //   resolve  one thread per pixel: K rounds of "smallest key greater than the last one" -> sorted by (depth, index),
 //            recomputes the squared distance, pads with -1
@@ -79,11 +79,15 @@ points_scatter_kernel(const float* __restrict__ pts, const int64_t* __restrict__
   }
 }
 
+// Reserves list storage: wave prefix sums, combined across the 4 waves of the workgroup through LDS, ONE atomicAdd per
+// workgroup (the single counter is the serial resource of this pass).
 __global__ void __launch_bounds__(256)
 points_place_kernel(const int* __restrict__ pix_count, int64_t npix, int64_t* __restrict__ pix_offset,
                     unsigned long long* __restrict__ total) {
+  __shared__ int wave_sum[4];
+  __shared__ unsigned long long block_base;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & (kWave - 1);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int c = i < npix ? pix_count[i] : 0;
   int incl = c;
 #pragma unroll
@@ -91,11 +95,16 @@ points_place_kernel(const int* __restrict__ pix_count, int64_t npix, int64_t* __
     const int up = __shfl_up(incl, d, kWave);
     if (lane >= d) incl += up;
   }
-  const int wave_sum = __shfl(incl, kWave - 1, kWave);
-  unsigned long long base = 0;
-  if (lane == kWave - 1 && wave_sum > 0) base = atomicAdd(total, (unsigned long long)wave_sum);
-  base = __shfl(base, kWave - 1, kWave);
-  if (i < npix) pix_offset[i] = (int64_t)base + (incl - c);
+  if (lane == kWave - 1) wave_sum[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int s = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    block_base = s > 0 ? atomicAdd(total, (unsigned long long)s) : 0ull;
+  }
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += wave_sum[w];
+  if (i < npix) pix_offset[i] = (int64_t)block_base + before + (incl - c);
 }
 
 // idx / zbuf / dists arrive pre-filled with -1: only the listed points are written (4 of 5 pixels are empty).

@@ -70,12 +70,14 @@ def run(out_json):
     # ---- marching cubes (count + emit: classify / scan / emit kernels reported separately)
     from microbench import body_like_volume
     for n in (257, 385):
+        torch.sort(sep)                          # keep the set-up launches out of the previous case's segment
         vol3 = body_like_volume(n)
         step = 2.0 / (n - 1)
         v, f = MCGpu.mc_gpu(vol3, step, step, step, -1.0, -1.0, -1.0, 0.0)
         case(f"mc_gpu {n}^3 (V={v.shape[0]}, F={f.shape[0]}): volume + vertices + faces", 4 * n ** 3 + 12 * v.shape[0] + 24 * f.shape[0],
              lambda: MCGpu.mc_gpu(vol3, step, step, step, -1.0, -1.0, -1.0, 0.0))
     # ---- first-hit mesh rasteriser
+    torch.sort(sep)
     vol3 = body_like_volume(193)
     step = 2.0 / 192
     v, f = MCGpu.mc_gpu(vol3, step, step, step, -1.0, -1.0, -1.0, 0.0)

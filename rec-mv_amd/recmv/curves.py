@@ -1,0 +1,144 @@
+"""Feature-curve branch of the iteration (SURVEY.md §8f "next" row 3): explicit curves, their 2-D projection loss and
+z-buffer visibility.
+
+Restates, on torch ops + the HIP mesh rasteriser (no new kernels — the curves hold a few hundred points):
+  * `Intersect_Free_Curve`            engineer/utils/garment_structure.py:36-147 (forward / inference / regularization /
+                                      query_canosmpl_verts; the constructor takes the uniformly resampled curves directly —
+                                      the reference extracts them from template meshes with `extract_edge`, data path)
+  * `fl_proj_loss`                    engineer/core/fl_optimizer.py:72-110, with pytorch3d's `chamfer_distance(
+                                      point_reduction='sum')` restated (third party, parity unpinned)
+  * `zbuff_check` / `surface_depth_check`   the body of fl_visible_by_body_zbuff, OptimGarmentNetwork.py:1374-1448
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# utils/constant.py:65-74 (feature lines of a garment type) and :219-227 (visibility slack behind the body surface)
+FL_EXTRACT = {
+    'long_sleeve_upper': ['neck', 'left_cuff', 'right_cuff', 'upper_bottom'],
+    'dress': ['neck', 'left_cuff', 'right_cuff', 'bottom_curve'],
+    'long_pants': ['left_pant', 'right_pant'],
+    'short_pants': ['left_pant', 'right_pant'],
+    'short_sleeve_upper': ['neck', 'left_cuff', 'right_cuff', 'upper_bottom'],
+    'tube': ['neck', 'bottom_curve'],
+    'skirt': ['bottom_curve'],
+    'no_sleeve_upper': ['neck', 'left_cuff', 'right_cuff', 'bottom_curve'],
+}
+ZBUF_THRESHOLD = {'neck': 0.1, 'right_cuff': 0.05, 'left_cuff': 0.05, 'left_pant': 0.05, 'right_pant': 0.05,
+                  'upper_bottom': 0.08, 'bottom_curve': 0.1}
+
+
+def _legacy_cross(a, b):
+    """`torch.cross(a, b)` as the reference calls it (garment_structure.py:89, no `dim`): the legacy default is the
+    FIRST axis of size 3 — the line axis when there are exactly three feature lines, else the coordinate axis."""
+    dim = next(i for i, n in enumerate(a.shape) if n == 3)
+    return torch.linalg.cross(a, b, dim=dim)
+
+
+class Intersect_Free_Curve(nn.Module):
+    """Closed curves parametrised around their centre: every sample keeps its direction from the centre and learns a
+    radial scale (through a ReLU, so the curve cannot fold through its centre) plus an offset along the curve normal."""
+
+    def __init__(self, uni_curve_verts_list, cano_smpl_verts_list, fl_names):
+        super().__init__()
+        self.fl_names = list(fl_names)
+        self.register_buffer('cano_smpl_verts', torch.stack([v for v in cano_smpl_verts_list], dim=0))
+        cano_verts_tensor = torch.stack([v for v in uni_curve_verts_list], dim=0)                 # [L,S,3]
+        cano_verts_center = cano_verts_tensor.mean(1, keepdim=True)                                # :81
+        self.register_buffer('cano_verts_center', cano_verts_center)
+        rel = cano_verts_tensor - cano_verts_center
+        cano_v_dirs = rel / (rel.norm(dim=-1, keepdim=True) + 1e-6)                                 # :84
+        nx = _legacy_cross(cano_v_dirs[:, :-1, :], cano_v_dirs[:, 1:, :])                             # :85-87
+        nx = nx / nx.norm(dim=-1, keepdim=True)
+        nx = nx.mean(dim=1, keepdim=True)
+        self.register_buffer('cano_nx', nx)
+        self.register_buffer('cano_v_dirs', cano_v_dirs)
+        init_scale = torch.clamp_min((rel * cano_v_dirs).sum(dim=-1, keepdim=True), 0.)              # :93-94
+        self.register_buffer('init_scale', init_scale)
+        self.scale = nn.Parameter(torch.full(init_scale.shape, 1.0, device=init_scale.device))      # :98-99
+        self.nx_scale = nn.Parameter(torch.full(init_scale.shape, 0., device=init_scale.device))
+
+    def query_canosmpl_verts(self, query_names):                                                    # :50-63
+        table = {name: v for name, v in zip(self.fl_names, self.cano_smpl_verts)}
+        return [table[name] for name in query_names]
+
+    def forward(self):                                                                              # :104-109
+        v_dir_offset = self.cano_v_dirs * self.init_scale * F.relu(self.scale)
+        nx_offset = self.nx_scale * self.cano_nx
+        return self.cano_verts_center + v_dir_offset + nx_offset
+
+    def inference(self):
+        with torch.no_grad():
+            return self.forward()
+
+    def regularization(self, fl_masks):                                                             # :120-141
+        cano_verts = self.forward()
+        used_flag = (fl_masks.sum() > 0).float()
+        center_loss = used_flag * abs(cano_verts.mean(1, keepdim=True) - self.cano_verts_center).sum()
+        diff_a = cano_verts[:, :-1, :] - cano_verts[:, 1:, :]
+        diff_b = cano_verts[:, -1:, :] - cano_verts[:, 0:1, :]
+        diff_c = cano_verts[:, 0:1, :] - cano_verts[:, 1:2, :]
+        diff_a = torch.cat([diff_a, diff_b, diff_c], dim=1)
+        diff_a = diff_a / (diff_a.norm(dim=-1, keepdim=True) + 1e-6)
+        diff_a_loss = 1 - F.cosine_similarity(diff_a[:, :-1, :], diff_a[:, 1:, :], dim=-1)
+        return {'center_offset': 0 * center_loss, 'diff_a_loss': diff_a_loss.sum()}
+
+
+def chamfer_distance_sum(x, y):
+    """pytorch3d `chamfer_distance(x, y, point_reduction='sum')[0]` for one cloud pair x [1,n,D], y [1,m,D]: squared
+    distance of every point to its nearest neighbour in the other set, summed over both directions.  An empty side
+    contributes nothing (upstream: zero-length clouds give zero terms)."""
+    if x.shape[1] == 0 or y.shape[1] == 0:
+        return x.sum() * 0.
+    d = ((x[0, :, None, :] - y[0, None, :, :]) ** 2).sum(-1)                # [n,m]
+    return d.min(dim=1).values.sum() + d.min(dim=0).values.sum()
+
+
+def fl_proj_loss(fl_pts_list, gt_fl_pts_list, fl_masks, proj_fl_weights=None):
+    """engineer/core/fl_optimizer.py:72-110.  Per feature line: chamfer between the VISIBLE projected samples of each
+    frame and that frame's 2-D ground-truth curve, averaged over the frames that see the line and over the visible
+    samples, then over the lines."""
+    loss = torch.tensor(0.).to(fl_pts_list[0])
+    if proj_fl_weights is None:
+        proj_fl_weights = [1. for _ in range(len(fl_pts_list))]
+    for fl_pts, gt_fl_pts, fl_mask, w in zip(fl_pts_list, gt_fl_pts_list, fl_masks, proj_fl_weights):
+        screen_fl_pts = fl_pts[..., :2]
+        screen_fl_masks = fl_mask[..., :2]
+        valid_batch = (fl_mask[..., 0].sum(dim=-1) > 0).float().sum()
+        batch_loss = 0.
+        for screen_fl_pt, screen_fl_mask, gt_fl_pt in zip(screen_fl_pts, screen_fl_masks, gt_fl_pts):
+            screen_fl_pt = screen_fl_pt[screen_fl_mask == 1].view(1, -1, 2)
+            batch_loss = batch_loss + w * chamfer_distance_sum(screen_fl_pt, gt_fl_pt.view(1, -1, 2))
+        # the reference branches on `valid_batch != 0` / `masks.sum() != 0` through host reads; the same selection is
+        # made on the device here
+        batch_loss = torch.where(valid_batch != 0, batch_loss / valid_batch.clamp(min=1.), batch_loss)
+        n_vis = torch.div(screen_fl_masks.sum(), 2, rounding_mode='floor')
+        loss = loss + torch.where(n_vis != 0, batch_loss / n_vis.clamp(min=1.), batch_loss)
+    return loss / len(fl_pts_list)
+
+
+def zbuff_check(z_buff, uv):
+    """`z_buff_check` of OptimGarmentNetwork.py:1378-1387: bilinear read of a [B,H,W,1] depth image at uv in [-1,1]
+    (align_corners=True) -> [B,P]."""
+    zb = z_buff.permute(0, 3, 1, 2)
+    return F.grid_sample(zb, uv.unsqueeze(2), align_corners=True)[:, 0, :, 0]
+
+
+def surface_depth_check(cameras, image_size, frags_zbuf, verts_world, query_world):
+    """The depth test of fl_visible_by_body_zbuff (:1394-1420 for the garment, :1424-1446 for the body): how far
+    behind the rasterised surface (world z) each query point lies.  `frags_zbuf` [N,H,W,1] is the mesh rasteriser's
+    view-space depth with -1 = background, replaced by the farthest vertex depth of the frame; `verts_world` [N,V,3]
+    are the rasterised vertices, `query_world` [N,P,3] the curve samples."""
+    W, H = image_size
+    N = query_world.shape[0]
+    cam_z = cameras.cam_pos().detach()[-1]
+    zbuf = frags_zbuf.clone()
+    z_max = (verts_world[..., -1].detach() - cam_z).max(-1).values                    # [N]
+    z_max = z_max[:, None, None, None].expand_as(zbuf)
+    zbuf = torch.where(zbuf == -1., z_max, zbuf)
+    screen = cameras.project(query_world.reshape(-1, 3)).view(N, -1, 2)               # transform_points_screen xy
+    u = 2 * screen[..., 0] / W - 1
+    v = 2 * screen[..., 1] / H - 1
+    uv = torch.stack([u, v], dim=-1)
+    surf_depth = zbuff_check(zbuf, uv) + cam_z
+    return query_world[..., -1] - surf_depth

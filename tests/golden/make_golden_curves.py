@@ -1,0 +1,98 @@
+"""Golden vectors for the feature-curve branch, from the REAL reference classes imported from /root/reference:
+
+  curves.npz   engineer/utils/garment_structure.py `Intersect_Free_Curve` (initialize_parameters / forward /
+               regularization on seeded closed curves; constructed without its mesh-extraction front end) and
+               engineer/core/fl_optimizer.py `fl_proj_loss` (its loop / normalisation logic; pytorch3d's
+               chamfer_distance — absent here — is replaced by the restatement in recmv.curves, so the chamfer
+               arithmetic itself stays parity-unpinned)
+
+    python tests/golden/make_golden_curves.py
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(HERE))
+sys.path[:0] = [str(REPO / "rec-mv_amd"), str(REPO)]
+import ref_loader  # noqa: E402
+
+ref_loader.install()
+from make_golden import save  # noqa: E402
+
+
+def rings(seed, n_lines=3, n=40):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for k in range(n_lines):
+        t = torch.linspace(0, 2 * np.pi, n + 1)[:-1]
+        r = 0.3 + 0.1 * k + 0.02 * torch.randn(n, generator=g)
+        c = torch.tensor([0.05 * k, 0.4 - 0.3 * k, 0.02])
+        tilt = 0.2 * k
+        p = torch.stack([r * torch.cos(t), 0.05 * torch.sin(3 * t) + tilt * r * torch.cos(t), r * torch.sin(t)], -1)
+        out.append((p + c).float())
+    return out
+
+
+def main():
+    ref_loader.ref_module("model.network")       # the reference's own entry order (its packages import each other)
+    G = ref_loader.ref_module("engineer.utils.garment_structure")
+    Fo = ref_loader.ref_module("engineer.core.fl_optimizer")
+    from recmv import curves as ours
+    names = ['neck', 'left_cuff', 'upper_bottom']
+    curves = rings(3)
+    smpl = [0.93 * c for c in curves]
+    ref = object.__new__(G.Intersect_Free_Curve)
+    torch.nn.Module.__init__(ref)
+    ref.cano2canosmpl = lambda lst, nm: [0.93 * c for c in lst]
+    ref.fl_names = names
+    ref.sample_num = 40
+    ref.initialize_parameters([c.clone() for c in curves])
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        ref.scale.copy_(1.0 + 0.3 * torch.randn(ref.scale.shape, generator=g))      # some scales negative -> ReLU path
+        ref.scale[0, :5] = -0.2
+        ref.nx_scale.copy_(0.05 * torch.randn(ref.nx_scale.shape, generator=g))
+    verts = ref()
+    fl_masks = torch.tensor([[1., 1., 0.], [1., 0., 1.]])
+    reg = ref.regularization(fl_masks)
+    (reg['diff_a_loss'] + verts.sum()).backward()
+    q = ref.query_canosmpl_verts(['upper_bottom', 'neck'])
+    # 4 lines: torch.cross without `dim` (garment_structure.py:89) then acts on the last axis; with exactly 3 lines
+    # (above) its legacy default picks the FIRST axis of size 3, i.e. the line axis — both behaviours are pinned
+    curves4 = rings(4, n_lines=4, n=24)
+    ref4 = object.__new__(G.Intersect_Free_Curve)
+    torch.nn.Module.__init__(ref4)
+    ref4.cano2canosmpl = lambda lst, nm: [0.9 * c for c in lst]
+    ref4.fl_names = ['neck', 'left_cuff', 'right_cuff', 'upper_bottom']
+    ref4.sample_num = 24
+    ref4.initialize_parameters([c.clone() for c in curves4])
+    # ---- fl_proj_loss (reference loop, restated chamfer)
+    Fo.chamfer_distance = lambda a, b, point_reduction='sum': (ours.chamfer_distance_sum(a, b), None)
+    N, S, M = 2, 40, 25
+    pts = [torch.rand(N, S, 3, generator=g) * 100 for _ in range(3)]
+    gts = [torch.rand(N, M, 2, generator=g) * 100 for _ in range(3)]
+    masks = []
+    for k in range(3):
+        m = torch.rand(N, S, generator=g) > 0.4
+        if k == 1:
+            m[1] = False                                  # a frame that does not see the line
+        if k == 2:
+            m[:] = False                                  # a line nobody sees
+        masks.append(m[..., None].expand(N, S, 3).clone())
+    w = [1.0, 2.5, 0.7]
+    loss = Fo.fl_proj_loss(pts, gts, masks, w)
+    save("curves", curves=torch.stack(curves), smpl=torch.stack(smpl), scale=ref.scale,
+         nx_scale=ref.nx_scale, verts=verts, center=ref.cano_verts_center, nx=ref.cano_nx, dirs=ref.cano_v_dirs,
+         init_scale=ref.init_scale, fl_masks=fl_masks, reg_diff=reg['diff_a_loss'], reg_center=reg['center_offset'],
+         g_scale=ref.scale.grad, g_nx=ref.nx_scale.grad, q0=q[0], q1=q[1],
+         curves4=torch.stack(curves4), nx4=ref4.cano_nx, verts4=ref4(),
+         proj_pts=torch.stack(pts), proj_gts=torch.stack(gts), proj_masks=torch.stack(masks), proj_w=np.array(w),
+         proj_loss=loss)
+
+
+if __name__ == "__main__":
+    main()

@@ -145,3 +145,40 @@ def test_camera_ndc_matches_the_reference_calibration_matrix():
     pix = cam.project(g["pts"])
     torch.testing.assert_close(1 - (2 * pix[:, 0] + 1) / W, out[:, 0], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(1 - (2 * pix[:, 1] + 1) / H, out[:, 1], rtol=1e-4, atol=1e-5)
+
+
+def test_intersect_free_curve_matches_the_reference_class():
+    """engineer/utils/garment_structure.py:36-147 run for real (tests/golden/make_golden_curves.py)."""
+    from recmv.curves import Intersect_Free_Curve
+    g = load("curves")
+    names = ['neck', 'left_cuff', 'upper_bottom']
+    c = Intersect_Free_Curve(list(g["curves"]), list(g["smpl"]), names)
+    for got, key in ((c.cano_verts_center, "center"), (c.cano_nx, "nx"), (c.cano_v_dirs, "dirs"),
+                     (c.init_scale, "init_scale")):
+        torch.testing.assert_close(got, g[key], rtol=1e-6, atol=1e-7)
+    with torch.no_grad():
+        c.scale.copy_(g["scale"])
+        c.nx_scale.copy_(g["nx_scale"])
+    verts = c()
+    torch.testing.assert_close(verts, g["verts"], rtol=1e-6, atol=1e-7)
+    reg = c.regularization(g["fl_masks"])
+    torch.testing.assert_close(reg["diff_a_loss"], g["reg_diff"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(reg["center_offset"], g["reg_center"], rtol=0, atol=0)
+    (reg["diff_a_loss"] + verts.sum()).backward()
+    torch.testing.assert_close(c.scale.grad, g["g_scale"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(c.nx_scale.grad, g["g_nx"], rtol=1e-4, atol=1e-6)
+    q = c.query_canosmpl_verts(['upper_bottom', 'neck'])
+    assert torch.equal(q[0], g["q0"]) and torch.equal(q[1], g["q1"])
+    c4 = Intersect_Free_Curve(list(g["curves4"]), list(0.9 * g["curves4"]),
+                              ['neck', 'left_cuff', 'right_cuff', 'upper_bottom'])
+    torch.testing.assert_close(c4.cano_nx, g["nx4"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(c4(), g["verts4"], rtol=1e-6, atol=1e-7)
+
+
+def test_fl_proj_loss_matches_the_reference_function():
+    """engineer/core/fl_optimizer.py:72-110: visible-sample selection, per-frame chamfer, normalisation by the frames
+    that see a line and by its visible samples — incl. a frame without the line and a line nobody sees."""
+    from recmv.curves import fl_proj_loss
+    g = load("curves")
+    loss = fl_proj_loss(list(g["proj_pts"]), list(g["proj_gts"]), list(g["proj_masks"]), g["proj_w"].tolist())
+    torch.testing.assert_close(loss, g["proj_loss"], rtol=1e-5, atol=1e-6)

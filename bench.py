@@ -194,6 +194,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--stage", default="coarse")
+    ap.add_argument("--curves", action="store_true",
+                    help="also run the feature-curve branch (project_2d_loss, SURVEY.md §8f next row 3) every iteration")
     ap.add_argument("--settle-iters", type=int, default=240,
                     help="untimed iterations run once after building the loop, before the warm-up: state "
                          "preparation that takes the synthetic optimisation out of Adam's start-up transient, in "
@@ -230,7 +232,8 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     conf = ConfigFactory.parse_file(args.conf)
-    loop = HotLoop(conf, device, n_frames=64, H=512, W=512, stage=args.stage, world_size=world, rank=rank)
+    loop = HotLoop(conf, device, n_frames=64, H=512, W=512, stage=args.stage, world_size=world, rank=rank,
+                   curves=args.curves)
     rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters()))
     allreduce = rdist.GradAllReduce(world) if world > 1 else None
 
@@ -328,10 +331,11 @@ def main():
                 "workload": "configs[1]: PeopleSnapshot female-3-casual-like, 512x512, frames_per_step=%d per GPU, "
                             "2 garments, sample_pix_num=%d, stage=%s pyramid %s, remesh every %d iters (inside the "
                             "timed region when steps>=%d); surface points from the HIP first-hit mesh rasteriser + "
-                            "FindSurfacePs, the point-splat silhouette term replaced by a projection (recmv/loop.py "
-                            "docstring)" % (loop.batch_size, loop.sample_pix, args.stage,
+                            "FindSurfacePs, mask loss on the HIP point-splat silhouettes; feature-curve branch %s "
+                            "(recmv/loop.py docstring)" % (loop.batch_size, loop.sample_pix, args.stage,
                                                           tuple(int(v) for v in loop.engine.resolutions[-1]),
-                                                          loop.remesh_intersect, loop.remesh_intersect),
+                                                          loop.remesh_intersect, loop.remesh_intersect,
+                                                          "ON" if args.curves else "off (next row 3)"),
                 "parallelism": "frame-sharded dp%d, 1 RCCL all-reduce of shared grads / step" % world,
                 "mc_vertices": [int(v.shape[0]) for v in loop.garment_vs],
                 "rays_per_iter": int(loop.info.get('rays_total', 0)),

@@ -38,6 +38,7 @@ import torch
 import torch.nn.functional as F
 
 from . import MCGpu
+from . import curves as fl
 from . import raster
 from . import utils
 from .FastMinv import Fast3x3Minv
@@ -199,7 +200,7 @@ class HotLoop:
     """The per-frame optimisation inner loop (see module docstring)."""
 
     def __init__(self, conf, device, n_frames=64, H=512, W=512, stage='coarse', seed=0, resolutions=None,
-                 skin_grid=(65, 225, 129), bbox=None, world_size=1, rank=0):
+                 skin_grid=(65, 225, 129), bbox=None, world_size=1, rank=0, curves=False):
         self.conf_all = conf
         self.conf = conf.get_config('loss_' + stage)
         self.device = device
@@ -258,6 +259,10 @@ class HotLoop:
         self.dctnull = dct_nullspace(min(30, n_frames), min(10, max(n_frames // 3, 1)), device)
         self.info = {}
         self.world_size, self.rank = world_size, rank
+        # feature-curve branch (project_2d_loss, SURVEY.md §8f "next" row 3): off unless asked for
+        self.curves = bool(curves)
+        if self.curves:
+            self._init_curves(seed + 4)
         params = [p for p in self.netRender.parameters()] + [p for p in self.deformer.parameters()] + \
                  [p for p in self.garment_nets.parameters()]
         self.optimizer = torch.optim.Adam(self.dataset.learnable_weights() + params,
@@ -384,6 +389,151 @@ class HotLoop:
         for v in self.garment_vs:
             v.requires_grad = True
         self.garment_optimizer = torch.optim.SGD(self.garment_vs, lr=0.05, momentum=0.9)
+        if getattr(self, 'curves', False):
+            self.fl_optimizer = torch.optim.AdamW(self.inter_free_curve.parameters(), lr=1e-4)              # :712
+
+    # ------------------------------------------------------------------------------------------ feature curves
+    FL_GARMENT = {'upper': 'short_sleeve_upper', 'bottom': 'long_pants'}      # female-3-casual, utils/constant.py:116
+
+    def _init_curves(self, seed, samples=200, gt_samples=100):
+        """Synthetic stand-in for `align_fl` + the dataset's 2-D feature lines (OptimGarmentNetwork.py:3380-3546,
+        dataset/dataset.py:113-155): closed rings on the initial garment spheres as canonical curves, the same rings
+        shrunk onto the body as their canonical-SMPL counterparts, a coarse body mesh as the SMPL template, and the
+        projected rings (+ pixel noise) as per-frame 2-D ground truth."""
+        dev = self.device
+        g = torch.Generator().manual_seed(seed)
+        radii = [_zero_level_radius(n, dev) for n in self.garment_nets]
+        self.fl_extract = {name: fl.FL_EXTRACT[self.FL_GARMENT[name]] for name in self.garment_names}
+        self.fl_names = [n for name in self.garment_names for n in self.fl_extract[name]]
+        t = torch.linspace(0, 2 * math.pi, samples + 1)[:-1]
+        ring = {}
+        for name, r in zip(self.garment_names, radii):
+            for n in self.fl_extract[name]:
+                if n == 'neck':
+                    y = 0.75 * r
+                    rho = math.sqrt(r * r - y * y)
+                    p = torch.stack([rho * torch.cos(t), torch.full_like(t, y), rho * torch.sin(t)], -1)
+                elif n in ('upper_bottom', 'bottom_curve'):
+                    y = -0.6 * r
+                    rho = math.sqrt(r * r - y * y)
+                    p = torch.stack([rho * torch.cos(t), torch.full_like(t, y), rho * torch.sin(t)], -1)
+                elif n in ('left_cuff', 'right_cuff'):
+                    x = (0.8 if n == 'left_cuff' else -0.8) * r
+                    rho = math.sqrt(r * r - x * x)
+                    p = torch.stack([torch.full_like(t, x), rho * torch.cos(t), rho * torch.sin(t)], -1)
+                else:                                                   # left_pant / right_pant
+                    cx = (0.35 if n == 'left_pant' else -0.35) * r
+                    rho = 0.3 * r
+                    y = -math.sqrt(max(r * r - (abs(cx) + rho) ** 2, 0.0)) * 0.9
+                    p = torch.stack([cx + rho * torch.cos(t), torch.full_like(t, y), rho * torch.sin(t)], -1)
+                ring[n] = p.float()
+        curves_list = [ring[n] for n in self.fl_names]
+        self.inter_free_curve = fl.Intersect_Free_Curve(curves_list, [0.9 * c for c in curves_list],
+                                                        self.fl_names).to(dev)
+        # SMPL-template stand-in: a coarse extraction of the body SDF (the reference's tmpBodyVs has 6890 vertices)
+        res = 41
+        ax = [torch.linspace(float(self.engine.b_min.view(-1)[i]), float(self.engine.b_max.view(-1)[i]), res, device=dev)
+              for i in range(3)]
+        X, Y, Z = torch.meshgrid(*ax, indexing='ij')
+        with torch.no_grad():
+            vol = self.sdf(torch.stack([X, Y, Z], -1).view(-1, 3), 1.0, features=False).view(res, res, res).contiguous()
+        step = [float(a[1] - a[0]) for a in ax]
+        v, f = MCGpu.mc_gpu(vol, step[0], step[1], step[2], float(ax[0][0]), float(ax[1][0]), float(ax[2][0]), 0.0)
+        self.tmpBodyVs, self.tmpBodyFs = v, f
+        # 2-D ground truth per image slot: the rings seen without articulation, jittered by a pixel
+        cams = self._cameras()
+        idx = torch.linspace(0, samples - 1, gt_samples).long()
+        gt = torch.stack([cams.project(c[idx].to(dev)) for c in curves_list], 0)            # [L,M,2]
+        k = self.dataset.n_img
+        noise = torch.randn(k, gt.shape[0] * gt_samples, 2, generator=g).to(dev)
+        self.dataset.gt_fl_pts = (gt.reshape(1, -1, 2) + noise).detach()                     # [k, L*M, 2]
+        self.dataset.fl_masks = torch.ones(k, len(self.fl_names), device=dev)
+        self.dataset.fl_weights = {n: 1.0 for n in self.fl_names}
+        self.fl_optimizer = torch.optim.AdamW(self.inter_free_curve.parameters(), lr=1e-4)
+
+    def fl_visible_by_body_zbuff(self, cameras, d_cond, smpl_conds, ratio, def_fl_vs, cano_smpl_verts_list, g_i,
+                                 garment_name, N):
+        """OptimGarmentNetwork.py:1374-1448: [N,P,2] = how far each deformed curve sample lies behind the rasterised
+        garment surface, and how far its canonical-SMPL counterpart lies behind the rasterised body."""
+        H, W = self.dataset.H, self.dataset.W
+        rast = raster.MeshRasterizer(cameras, (H, W))
+        with torch.no_grad():                    # only depths / comparisons are taken from these (:1396-1403 detach)
+            def_garment_vs = self.deformer(self.garment_vs[g_i].detach()[None].expand(N, -1, 3), [d_cond, smpl_conds],
+                                           ratio=ratio, offset_type=garment_name)
+            gfrags = rast(def_garment_vs, self.garment_fs[g_i])
+            fl_cat = torch.cat(def_fl_vs, dim=1).detach()
+            garment_check = fl.surface_depth_check(cameras, (W, H), gfrags.zbuf, def_garment_vs, fl_cat)
+            def_smpl_fl = torch.cat([self.deformer.defs[1](v.expand(N, -1, 3), smpl_conds)
+                                     for v in cano_smpl_verts_list], dim=1)
+            body = self.deformer.defs[1](self.tmpBodyVs.view(1, -1, 3).expand(N, -1, 3), smpl_conds)
+            bfrags = rast(body, self.tmpBodyFs)
+            smpl_check = fl.surface_depth_check(cameras, (W, H), bfrags.zbuf, body, def_smpl_fl)
+        return torch.stack([garment_check, smpl_check], dim=-1)
+
+    def project_2d_loss(self, N, frame_ids, ratio, cameras):
+        """OptimGarmentNetwork.py:1772-1883 (deform_feature_line :1507-1603, compute_fl_proj_loss :1605-1711): deform
+        the explicit curves, keep the samples the body does not hide, chamfer them against the frame's 2-D feature
+        lines, tie the canonical curves to their garment's zero level, one AdamW step on the curve parameters.  The
+        gradients this leaves on the shared networks are cleared by the optimiser's zero_grad that follows."""
+        conf = self.conf
+        d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
+        smpl_conds = [poses, trans]
+        curves_now = self.inter_free_curve()                                             # [L,S,3]
+        fl_vs_dict = {n: curves_now[i] for i, n in enumerate(self.fl_names)}
+        slot = frame_ids % self.dataset.n_img
+        gt_all = self.dataset.gt_fl_pts[slot]                                            # [N, L*M, 2]
+        M = gt_all.shape[1] // len(self.fl_names)
+        gt_dict = {n: gt_all[:, i * M:(i + 1) * M] for i, n in enumerate(self.fl_names)}
+        mask_dict = {n: self.dataset.fl_masks[slot][:, i:i + 1] for i, n in enumerate(self.fl_names)}
+        project_loss, sdf_loss = 0., 0.
+        self.info['fl_loss'] = {}
+        for g_i, name in enumerate(self.garment_names):
+            names = self.fl_extract[name]
+            d_cond = d_cond_list[g_i + 1]
+            def_fl_vs = [self.deformer(fl_vs_dict[n].view(-1, 3).expand(N, -1, 3), [d_cond, smpl_conds], ratio=ratio,
+                                       offset_type=n) for n in names]                     # :1568
+            cano_smpl = self.inter_free_curve.query_canosmpl_verts(names)
+            checks = self.fl_visible_by_body_zbuff(cameras, d_cond, smpl_conds, ratio, def_fl_vs, cano_smpl, g_i,
+                                                   name, N)                               # [N,P,2]
+            split = [v.shape[1] for v in def_fl_vs]
+            fl_masks = torch.cat([mask_dict[n] for n in names], dim=-1)                   # [N, lines]
+            # ---- compute_fl_proj_loss
+            verts = torch.cat(def_fl_vs, dim=1)
+            flat = verts.reshape(-1, 3)
+            view_z = ((flat.unsqueeze(-1) * cameras.R[0].unsqueeze(0)).sum(-2) + cameras.T[0].view(1, 3))[:, 2]
+            screen = torch.cat([cameras.project(flat), (1.0 / view_z).view(-1, 1)], dim=1).view(N, -1, 3)
+            thr = torch.cat([torch.full((n_s,), fl.ZBUF_THRESHOLD[n], device=self.device)
+                             for n, n_s in zip(names, split)]).view(1, -1, 1)
+            body_visible = (checks < thr)[..., 1]                                         # :1644-1648
+            screen_list = list(torch.split(screen, split, dim=1))
+            vis_list = list(torch.split(body_visible, split, dim=1))
+            visible_masks = []
+            for i, (pts, vis) in enumerate(zip(screen_list, vis_list)):
+                fl_mask = fl_masks[:, None, i:i + 1].expand_as(pts)
+                visible_masks.append(torch.logical_and(fl_mask, vis[..., None].expand_as(pts)))
+            weights = [self.dataset.fl_weights[n] for n in names]
+            gt_list = [gt_dict[n] for n in names]
+            fl_loss = fl.fl_proj_loss(screen_list, gt_list, visible_masks, weights) * (
+                conf.get_float('fl_weight.weight') if 'fl_weight.weight' in conf else 1.)
+            reg = self.inter_free_curve.regularization(fl_masks)
+            center = reg['center_offset'] * (conf.get_float('alpha_weight.center_weight') if 'alpha_weight' in conf else 1.)
+            diff = reg['diff_a_loss'] * (conf.get_float('alpha_weight.diff_weight') if 'alpha_weight' in conf else 1.)
+            self.info['fl_loss']['{}_project loss'.format(name)] = fl_loss.detach()
+            self.info['fl_loss']['{}_visible'.format(name)] = body_visible.float().mean().detach()
+            project_loss = project_loss + fl_loss + center + diff
+            # ---- canonical curves on their garment's zero level (:1855-1858)
+            cano = torch.cat([fl_vs_dict[n].view(-1, 3) for n in names], dim=0)
+            cano_sdf = self.garment_nets[g_i](cano, ratio, features=False).view(-1)
+            s_loss = (cano_sdf + self.sdfShrinkRadius).abs().mean()
+            self.info['fl_loss']['pc_{}_loss_sdf'.format(name)] = s_loss.detach()
+            sdf_loss = sdf_loss + s_loss * (conf.get_float('fl_weight.sdf_weight') if 'fl_weight' in conf else 60.)
+        self.fl_optimizer.zero_grad()
+        loss = 10. * sdf_loss + 1. * project_loss                                         # :1865
+        loss.backward()
+        if getattr(self, '_allreduce', None) is not None:
+            self._allreduce(list(self.inter_free_curve.parameters()))     # curve gradients are shared across ranks (§8e)
+        self.fl_optimizer.step()
+        self.info['fl_loss']['total'] = loss.detach()
 
     # ------------------------------------------------------------------------------------------ mask loss
     def mask_loss(self, N, frame_ids, ratio, cameras):
@@ -616,6 +766,9 @@ class HotLoop:
             with self._phase('remesh'):
                 self.marching_cube_update(ratio)
         total_loss = 0.
+        if self.curves:
+            with self._phase('curves'):
+                self.project_2d_loss(N, frame_ids, ratio, cameras)                           # :1932
         self.optimizer.zero_grad()                                                         # :1934
         with self._phase('mask_loss'):
             def_vs, pc_sdf_loss = self.mask_loss(N, frame_ids, ratio, cameras)

@@ -66,3 +66,26 @@ def test_first_iteration_converges_every_ray():
     loop.step(0)
     conv = loop.info['rays_converged']
     assert len(conv) == 2 and sum(conv) >= 0.97 * loop.info['rays_total'], (conv, loop.info['rays_total'])
+
+
+def test_feature_curve_branch_on_gpu():
+    """project_2d_loss on the device: curves deform through the same kernels as the garment vertices, the z-buffer
+    visibility uses the HIP rasteriser, the AdamW step moves the curve parameters."""
+    from recmv.hocon import ConfigFactory
+    from recmv.loop import HotLoop
+    conf = ConfigFactory.parse_file(CONF)
+    conf.put('train.sample_pix_num', 256)
+    loop = HotLoop(conf, torch.device("cuda:0"), n_frames=12, H=160, W=128,
+                   resolutions=[(9, 13, 7), (17, 25, 13), (33, 49, 25), (65, 97, 49)], skin_grid=(17, 33, 17), curves=True)
+    before = [p.detach().clone() for p in loop.inter_free_curve.parameters()]
+    l0, _ = loop.step(0)
+    l1, _ = loop.step(1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(l0) and torch.isfinite(l1)
+    info = loop.info['fl_loss']
+    assert torch.isfinite(info['total'])
+    for name in loop.garment_names:
+        assert 0.05 < float(info[f'{name}_visible']) <= 1.0
+    moved = max(float((a - b.detach()).abs().max()) for a, b in zip(before, loop.inter_free_curve.parameters()))
+    assert 1e-5 < moved < 1e-2
+    assert loop.tmpBodyVs.shape[0] > 500 and loop.tmpBodyFs.shape[0] > 1000

@@ -14,13 +14,13 @@ REPO = Path(__file__).resolve().parent.parent
 CONF = str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf")
 
 
-def _tiny_loop(world=1, rank=0, seed=0):
+def _tiny_loop(world=1, rank=0, seed=0, curves=False):
     from recmv.hocon import ConfigFactory
     from recmv.loop import HotLoop
     conf = ConfigFactory.parse_file(CONF)
     conf.put('train.sample_pix_num', 32)
     return HotLoop(conf, 'cpu', n_frames=12, H=64, W=64, resolutions=[(9, 11, 7), (17, 21, 13)], skin_grid=(5, 9, 7),
-                   bbox=((-0.9, -1.2, -0.6), (0.9, 1.2, 0.6)), world_size=world, rank=rank, seed=seed)
+                   bbox=((-0.9, -1.2, -0.6), (0.9, 1.2, 0.6)), world_size=world, rank=rank, seed=seed, curves=curves)
 
 
 def test_loop_two_steps_on_cpu_port():
@@ -42,6 +42,34 @@ def test_loop_two_steps_on_cpu_port():
         changed = sum(int(not torch.equal(a, b.detach())) for a, b in zip(before, loop.shared_parameters()))
         assert changed > 10, "Adam updated the shared parameters"
         assert loop.forward_time == 2 and loop.opt_times == 2.0
+    finally:
+        cpu_port.uninstall()
+
+
+def test_feature_curve_branch_on_cpu_port():
+    """project_2d_loss (OptimGarmentNetwork.py:1772-1883) inside the iteration: curves deform, part of their samples
+    is visible, the AdamW step moves the curve parameters, and the rest of the iteration is unaffected by the
+    gradients the branch leaves behind (they are cleared by the optimiser's zero_grad)."""
+    from oracle import cpu_port
+    cpu_port.install()
+    try:
+        loop = _tiny_loop(curves=True)
+        assert loop.fl_names == ['neck', 'left_cuff', 'right_cuff', 'upper_bottom', 'left_pant', 'right_pant']
+        before = [p.detach().clone() for p in loop.inter_free_curve.parameters()]
+        l0, _ = loop.step(0)
+        l1, _ = loop.step(1)
+        assert torch.isfinite(l0) and torch.isfinite(l1)
+        info = loop.info['fl_loss']
+        assert torch.isfinite(info['total']) and info['total'] > 0
+        for name in loop.garment_names:
+            assert 0.05 < float(info[f'{name}_visible']) <= 1.0          # the body hides the far side of every ring
+            assert float(info[f'{name}_project loss']) >= 0
+        moved = [float((a - b.detach()).abs().max()) for a, b in zip(before, loop.inter_free_curve.parameters())]
+        assert max(moved) > 1e-5 and max(moved) < 1e-2, moved              # two AdamW steps of lr 1e-4
+        plain = _tiny_loop(curves=False)
+        pl0, _ = plain.step(0)
+        # same seeds, same frames: the first iteration's loss does not depend on the curve branch
+        assert abs(float(pl0) - float(l0)) < 5e-2 * max(1.0, abs(float(pl0)))
     finally:
         cpu_port.uninstall()
 
@@ -72,14 +100,16 @@ def _dp_worker(rank, world, port, out_dir):
     from recmv import dist as rdist
     cpu_port.install()
     r, _, w = rdist.init_distributed("gloo")
-    loop = _tiny_loop(world=w, rank=r, seed=r)            # different seeds: broadcast must make them agree
-    rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters()))
+    loop = _tiny_loop(world=w, rank=r, seed=r, curves=True)   # different seeds: broadcast must make them agree
+    rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters())
+                          + list(loop.inter_free_curve.parameters()) + list(loop.inter_free_curve.buffers()))
     allreduce = rdist.GradAllReduce(w)
     for it in range(2):
         loop.step(it, allreduce)
     flat = torch.cat([p.detach().reshape(-1) for p in loop.shared_parameters()])
     verts = torch.cat([v.detach().reshape(-1) for v in loop.garment_vs])
-    torch.save({"params": flat, "verts": verts}, os.path.join(out_dir, f"rank{r}.pt"))
+    curv = torch.cat([p.detach().reshape(-1) for p in loop.inter_free_curve.parameters()])
+    torch.save({"params": flat, "verts": verts, "curves": curv}, os.path.join(out_dir, f"rank{r}.pt"))
     rdist.barrier()
     torch.distributed.destroy_process_group()
 
@@ -93,6 +123,7 @@ def test_data_parallel_world2_gloo(tmp_path):
     a, b = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(a["params"], b["params"]), "shared parameters diverged across ranks"
     assert torch.equal(a["verts"], b["verts"]), "MC vertices diverged across ranks (needs deterministic MC order)"
+    assert torch.equal(a["curves"], b["curves"]), "feature-curve parameters diverged across ranks"
 
 
 def test_grad_allreduce_handles_missing_grads_single_process():

@@ -428,8 +428,12 @@ class HotLoop:
                     p = torch.stack([cx + rho * torch.cos(t), torch.full_like(t, y), rho * torch.sin(t)], -1)
                 ring[n] = p.float()
         curves_list = [ring[n] for n in self.fl_names]
-        self.inter_free_curve = fl.Intersect_Free_Curve(curves_list, [0.9 * c for c in curves_list],
-                                                        self.fl_names).to(dev)
+        # canonical-SMPL counterparts: the same rings pulled radially onto the body's zero level, so that the body
+        # z-buffer test sees them ON the surface where it faces the camera and a body-thickness behind it elsewhere
+        r_body = _zero_level_radius(self.sdf, dev)
+        owner = {n: r for name, r in zip(self.garment_names, radii) for n in self.fl_extract[name]}
+        smpl_list = [ring[n] * (r_body / owner[n]) for n in self.fl_names]
+        self.inter_free_curve = fl.Intersect_Free_Curve(curves_list, smpl_list, self.fl_names).to(dev)
         # SMPL-template stand-in: a coarse extraction of the body SDF (the reference's tmpBodyVs has 6890 vertices)
         res = 41
         ax = [torch.linspace(float(self.engine.b_min.view(-1)[i]), float(self.engine.b_max.view(-1)[i]), res, device=dev)

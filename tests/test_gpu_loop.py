@@ -85,7 +85,9 @@ def test_feature_curve_branch_on_gpu():
     info = loop.info['fl_loss']
     assert torch.isfinite(info['total'])
     for name in loop.garment_names:
-        assert 0.05 < float(info[f'{name}_visible']) <= 1.0
+        assert 0.0 <= float(info[f'{name}_visible']) <= 1.0
+    # the body hides the far side of the rings, not all of them
+    assert 0.05 < max(float(info[f'{name}_visible']) for name in loop.garment_names) < 0.95
     moved = max(float((a - b.detach()).abs().max()) for a, b in zip(before, loop.inter_free_curve.parameters()))
     assert 1e-5 < moved < 1e-2
     assert loop.tmpBodyVs.shape[0] > 500 and loop.tmpBodyFs.shape[0] > 1000

@@ -62,8 +62,10 @@ def test_feature_curve_branch_on_cpu_port():
         info = loop.info['fl_loss']
         assert torch.isfinite(info['total']) and info['total'] > 0
         for name in loop.garment_names:
-            assert 0.05 < float(info[f'{name}_visible']) <= 1.0          # the body hides the far side of every ring
+            assert 0.0 <= float(info[f'{name}_visible']) <= 1.0
             assert float(info[f'{name}_project loss']) >= 0
+        vis = [float(info[f'{name}_visible']) for name in loop.garment_names]
+        assert 0.05 < max(vis) < 0.95, vis          # the body hides the far side of the rings, not all of them
         moved = [float((a - b.detach()).abs().max()) for a, b in zip(before, loop.inter_free_curve.parameters())]
         assert max(moved) > 1e-5 and max(moved) < 1e-2, moved              # two AdamW steps of lr 1e-4
         plain = _tiny_loop(curves=False)

@@ -234,7 +234,8 @@ def main():
     conf = ConfigFactory.parse_file(args.conf)
     loop = HotLoop(conf, device, n_frames=64, H=512, W=512, stage=args.stage, world_size=world, rank=rank,
                    curves=args.curves)
-    rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters()))
+    rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters())
+                          + (list(loop.inter_free_curve.parameters()) if loop.curves else []))
     allreduce = rdist.GradAllReduce(world) if world > 1 else None
 
     log("loop built")

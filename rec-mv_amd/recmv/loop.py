@@ -14,15 +14,16 @@ OptimGarmentNetwork.py:1885-1969) -> `loss.backward()` -> `propagateTmpPsGrad` (
   dct_poses_loss        :1221-1250 (pose smoothness on 30-frame windows)
   propagateTmpPsGrad    :2159-2313 implicit differentiation of the surface point
 
-What is NOT here, and why: nothing of `OptimGarmentNetwork.forward` except the
-feature-curve branch below.  The two pytorch3d renderers on the path are restated on HIP kernels (recmv/raster.py):
+Everything of `OptimGarmentNetwork.forward` is here.  The two pytorch3d renderers on the path are restated on HIP
+kernels (recmv/raster.py):
   * `pcRender` (point splat, 50 points per pixel, alpha compositor, :937) -> csrc/rasterize_points.hip, forward and
     backward; the IoU mask loss of compute_garment_pc_loss (:621-667) runs on its silhouettes;
   * `maskRender` (first-hit mesh rasteriser, :767) -> csrc/rasterize_meshes.hip; the visible canonical surface points
     come from its fragments + `utils.FindSurfacePs`, and `sample_train_ray` draws its Bernoulli subset of them with the
     host RNG exactly like the reference (:1020).
-Frames are synthetic (SyntheticFrames): images, normals and garment segmentations are generated, not loaded.
-The feature-curve branch (`project_2d_loss`, "next" row 3) is likewise outside this tier.
+The feature-curve branch (`project_2d_loss` :1772-1883, recmv/curves.py) is optional (`curves=True`): SURVEY.md §8f
+"next" row 3.  Frames are synthetic (SyntheticFrames): images, normals, garment segmentations and 2-D feature lines are
+generated, not loaded.
 The CPU SVD of the deformer Jacobians (:1148, a host round trip per garment per iteration) is replaced by
 closed-form singular values on the device (`singular_values_3x3`).
 """
@@ -288,13 +289,16 @@ class HotLoop:
         self.forward_time = 0                      # forces a re-mesh at the new resolution on the next iteration
 
     def _modules(self):
-        return {'sdf': self.sdf, 'garment_nets': self.garment_nets, 'deformer': self.deformer,
+        mods = {'sdf': self.sdf, 'garment_nets': self.garment_nets, 'deformer': self.deformer,
                 'netRender': self.netRender, 'engine': self.engine}
+        if getattr(self, 'curves', False):
+            mods['inter_free_curve'] = self.inter_free_curve          # optNet.inter_free_curve of the reference
+        return mods
 
     def state_dict(self):
         """Keys as `optNet.state_dict()` of the reference names them (getOptNet, model/network.py:182-361): `sdf.*`,
         `garment_nets.{i}.*`, `deformer.defs.0.*` (offset MLP), `deformer.defs.1.*` (skinner buffers), `netRender.*`,
-        `engine.*`."""
+        `engine.*`, and `inter_free_curve.*` when the feature-curve branch is on."""
         out = {}
         for prefix, mod in self._modules().items():
             for k, v in mod.state_dict().items():

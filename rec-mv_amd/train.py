@@ -40,6 +40,8 @@ def build_parser():
     parser.add_argument('--curve_sampling', type=int, default=1, help='the type of dataset')
     parser.add_argument('--resume', default=None, metavar='M', help='pretrained scene model')
     # extensions
+    parser.add_argument('--no-curves', action='store_true',
+                        help='skip the feature-curve branch (project_2d_loss) the reference runs every iteration')
     parser.add_argument('--frames', type=int, default=64, help='number of synthetic frames')
     parser.add_argument('--max-iters', type=int, default=-1, help='stop after this many optimiser iterations (smoke runs)')
     return parser
@@ -87,8 +89,10 @@ def main(argv=None):
     if rank == 0:
         os.makedirs(osp.join(save_root, 'debug'), exist_ok=True)
 
-    loop = HotLoop(config, device, n_frames=args.frames, H=512, W=512, stage='coarse', world_size=world, rank=rank)
-    rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters()))
+    loop = HotLoop(config, device, n_frames=args.frames, H=512, W=512, stage='coarse', world_size=world, rank=rank,
+                   curves=not args.no_curves)
+    rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters())
+                          + (list(loop.inter_free_curve.parameters()) if loop.curves else []))
     allreduce = rdist.GradAllReduce(world) if world > 1 else None
     dataset = loop.dataset
     start_epoch = 0

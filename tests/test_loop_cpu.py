@@ -68,7 +68,13 @@ def test_feature_curve_branch_on_cpu_port():
         assert 0.05 < max(vis) < 0.95, vis          # the body hides the far side of the rings, not all of them
         moved = [float((a - b.detach()).abs().max()) for a, b in zip(before, loop.inter_free_curve.parameters())]
         assert max(moved) > 1e-5 and max(moved) < 1e-2, moved              # two AdamW steps of lr 1e-4
+        sd = loop.state_dict()
+        assert 'inter_free_curve.scale' in sd and 'inter_free_curve.cano_smpl_verts' in sd   # reference key names
+        other = _tiny_loop(curves=True)
+        other.load_state_dict(sd)
+        assert torch.equal(other.inter_free_curve.scale, loop.inter_free_curve.scale)
         plain = _tiny_loop(curves=False)
+        assert not any(k.startswith('inter_free_curve') for k in plain.state_dict())
         pl0, _ = plain.step(0)
         # same seeds, same frames: the first iteration's loss does not depend on the curve branch
         assert abs(float(pl0) - float(l0)) < 5e-2 * max(1.0, abs(float(pl0)))

@@ -396,6 +396,34 @@ class HotLoop:
         if getattr(self, 'curves', False):
             self.fl_optimizer = torch.optim.AdamW(self.inter_free_curve.parameters(), lr=1e-4)              # :712
 
+    def _deform_garments(self, N, frame_ids, ratio):
+        """The deformed garment vertices of this iteration, with their autograd graph (mask_loss :910).  The reference
+        evaluates the same expression a second time per garment inside fl_visible_by_body_zbuff (:1396) — same
+        vertices, same deformer parameters, only depths are read from it — so the curve branch shares this one."""
+        hit = getattr(self, '_def_cache', None)         # cleared at the start of every forward()
+        if hit is not None:
+            return hit
+        d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
+        def_vs = [self.deformer(gv[None, :, :].expand(N, -1, 3), [d_cond_list[g_i + 1], [poses, trans]], ratio=ratio,
+                                offset_type=name)
+                  for g_i, (gv, name) in enumerate(zip(self.garment_vs, self.garment_names))]
+        self._def_cache = def_vs
+        self._frag_cache = {}
+        return def_vs
+
+    def _garment_fragments(self, g_i, def_v, cameras):
+        """First-hit fragments of garment g_i's deformed meshes, rasterised once per iteration (the z-buffer of the
+        curve branch :1399 and the surface points of find_surface_ps :767 are the same image)."""
+        cache = getattr(self, '_frag_cache', None)
+        if cache is None:
+            cache = self._frag_cache = {}
+        if g_i not in cache:
+            rast = raster.MeshRasterizer(cameras, (self.dataset.H, self.dataset.W), blur_radius=0.,
+                                         perspective_correct=True, cull_backfaces=False)           # :2336-2347
+            with torch.no_grad():
+                cache[g_i] = rast(def_v.detach(), self.garment_fs[g_i])
+        return cache[g_i]
+
     # ------------------------------------------------------------------------------------------ feature curves
     FL_GARMENT = {'upper': 'short_sleeve_upper', 'bottom': 'long_pants'}      # female-3-casual, utils/constant.py:116
 
@@ -465,10 +493,9 @@ class HotLoop:
         garment surface, and how far its canonical-SMPL counterpart lies behind the rasterised body."""
         H, W = self.dataset.H, self.dataset.W
         rast = raster.MeshRasterizer(cameras, (H, W))
-        with torch.no_grad():                    # only depths / comparisons are taken from these (:1396-1403 detach)
-            def_garment_vs = self.deformer(self.garment_vs[g_i].detach()[None].expand(N, -1, 3), [d_cond, smpl_conds],
-                                           ratio=ratio, offset_type=garment_name)
-            gfrags = rast(def_garment_vs, self.garment_fs[g_i])
+        def_garment_vs = self._shared_def_vs[g_i].detach()   # only depths / comparisons are read (:1396-1403 detach)
+        gfrags = self._garment_fragments(g_i, def_garment_vs, cameras)
+        with torch.no_grad():
             fl_cat = torch.cat(def_fl_vs, dim=1).detach()
             garment_check = fl.surface_depth_check(cameras, (W, H), gfrags.zbuf, def_garment_vs, fl_cat)
             def_smpl_fl = torch.cat([self.deformer.defs[1](v.expand(N, -1, 3), smpl_conds)
@@ -486,6 +513,7 @@ class HotLoop:
         conf = self.conf
         d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
         smpl_conds = [poses, trans]
+        self._shared_def_vs = self._deform_garments(N, frame_ids, ratio)
         curves_now = self.inter_free_curve()                                             # [L,S,3]
         fl_vs_dict = {n: curves_now[i] for i, n in enumerate(self.fl_names)}
         slot = frame_ids % self.dataset.n_img
@@ -551,9 +579,7 @@ class HotLoop:
         d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
         conf = self.conf
         H, W = self.dataset.H, self.dataset.W
-        def_vs = [self.deformer(gv[None, :, :].expand(N, -1, 3), [d_cond_list[g_i + 1], [poses, trans]], ratio=ratio,
-                                offset_type=name)                                          # :910
-                  for g_i, (gv, name) in enumerate(zip(self.garment_vs, self.garment_names))]
+        def_vs = self._deform_garments(N, frame_ids, ratio)                                # :910
         whole = torch.cat(def_vs, dim=1) if len(def_vs) > 1 else def_vs[0]                 # :925-935
         pc_render = raster.PointsRendererWithFrags_Split(cameras, (H, W), radius=self.pc_radius, points_per_pixel=50)
         garment_masks_list, _frags = pc_render(whole, split_size=self.garment_vs[0].shape[0])   # :937
@@ -600,12 +626,10 @@ class HotLoop:
     def find_surface_ps(self, def_vs, tmp_vs, cameras):
         """OptimGarmentNetwork.py:742-767: per garment, rasterise the N deformed meshes and turn the first-hit
         fragments into (batch, row, col, canonical point, face) of every covered pixel."""
-        rast = raster.MeshRasterizer(cameras, (self.dataset.H, self.dataset.W), blur_radius=0.,
-                                     perspective_correct=True, cull_backfaces=False)             # :2336-2347
         out = []
         with torch.no_grad():
-            for def_v, gv, gf in zip(def_vs, tmp_vs, self.garment_fs):
-                out.append(utils.FindSurfacePs(gv, gf, rast(def_v, gf)))
+            for g_i, (def_v, gv, gf) in enumerate(zip(def_vs, tmp_vs, self.garment_fs)):
+                out.append(utils.FindSurfacePs(gv, gf, self._garment_fragments(g_i, def_v, cameras)))
         return out
 
     def sample_train_ray(self, N, frame_ids, cameras):
@@ -769,6 +793,7 @@ class HotLoop:
     def forward(self, frame_ids, ratio):
         N = frame_ids.numel()
         self.info = {}
+        self._def_cache, self._frag_cache = None, {}      # per-iteration caches (shared deformation / fragments)
         cameras = self._cameras()
         if self.body_vs is None or self.forward_time % self.remesh_intersect == 0:
             with self._phase('remesh'):

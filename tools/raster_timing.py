@@ -61,6 +61,7 @@ loop._surface_ready.record()
 
 
 def srays():
+    loop._frag_cache = {}
     loop._surface_inputs = (def_vs, [v.detach().clone() for v in loop.garment_vs])
     loop.sample_train_ray(N, frame_ids, cams)
 
@@ -88,6 +89,7 @@ tm = T()
 REP = 5
 for _ in range(REP):
     tmp_vs = [v.detach().clone() for v in loop.garment_vs]
+    loop._frag_cache = {}
     with tm("find_surface_ps"):
         found = loop.find_surface_ps(def_vs, tmp_vs, cams)
     for g_i, (b, r, c, p0, _f) in enumerate(found):

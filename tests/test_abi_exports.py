@@ -52,3 +52,28 @@ def test_product_has_no_cpu_fallback():
         interp2x_boundary3d.forward(torch.randn(1, 1, 3, 3, 3), 0.0)
     with pytest.raises(RuntimeError):
         ops.gemm_nt(torch.randn(4, 4), torch.randn(4, 4))
+    from recmv import raster
+    first, num = torch.tensor([0]), torch.tensor([4])
+    with pytest.raises(RuntimeError):
+        raster.rasterize_meshes(torch.zeros(4, 3, 3), first, num, (8, 8))
+    with pytest.raises(RuntimeError):
+        raster.rasterize_points(torch.zeros(4, 3), first, num, (8, 8), 0.1, 4)
+    with pytest.raises(RuntimeError):
+        raster.alpha_composite(torch.zeros(1, 2, 2, 3, dtype=torch.int32), torch.zeros(1, 2, 2, 3), torch.zeros(1, 4))
+
+
+def test_rasteriser_argument_errors_through_the_c_abi():
+    from recmv import _lib
+    lib = _lib.lib()
+    assert lib.recmv_rasterize_meshes_workspace_bytes(3, 512, 512, 1000) == 3 * 512 * 512 * 8 + 1000 * 16 + 64
+    assert lib.recmv_rasterize_meshes_workspace_bytes(-1, 8, 8, 0) == -1
+    assert lib.recmv_rasterize_meshes(None, None, None, 1, 0, 0, 0, 8, 0.0, 1, 0, None, None, None, None, None, 0,
+                                      None) == -1                                   # H = 0
+    assert b"bad sizes" in lib.recmv_last_error()
+    assert lib.recmv_rasterize_meshes(None, None, None, 1, 0, 0, 8, 8, -1.0, 1, 0, None, None, None, None, None, 0,
+                                      None) == -1
+    assert b"blur_radius" in lib.recmv_last_error()
+    assert lib.recmv_rasterize_points_workspace_bytes(1, 8, 8, 10, -0.5) == -1
+    assert lib.recmv_rasterize_points(None, None, None, 1, 10, 10, 8, 8, 0.0, 4, None, None, None, None, 0, None) == -1
+    assert b"radius" in lib.recmv_last_error()
+    assert lib.recmv_alpha_composite_forward(None, None, None, 1, 8, 8, 0, 1, 4, 0.0, None, None) == -1

@@ -182,3 +182,22 @@ def test_fl_proj_loss_matches_the_reference_function():
     g = load("curves")
     loss = fl_proj_loss(list(g["proj_pts"]), list(g["proj_gts"]), list(g["proj_masks"]), g["proj_w"].tolist())
     torch.testing.assert_close(loss, g["proj_loss"], rtol=1e-5, atol=1e-6)
+
+
+def test_propagate_tmp_ps_grad_matches_the_reference_method():
+    """OptimGarmentNetwork.propagateTmpPsGrad (:2159-2313) run for real (tests/golden/make_golden_propagate.py) vs
+    HotLoop.propagateTmpPsGrad on the CPU port: the gradients injected into the SDF net, the offset MLP, the per-frame
+    codes, the poses / translations and the camera (focal, principal point, T) agree."""
+    from oracle import cpu_port
+    import propagate_case as pc
+    from recmv.model import CompositeDeformer, LBSkinner, MLPTranslator, getTmpSdf
+    g = load("propagate")
+    cpu_port.install()
+    try:
+        sdf, tr = cs.build_sdf(getTmpSdf), cs.build_translator(MLPTranslator)
+        comp = CompositeDeformer([tr, cs.build_skinner(LBSkinner)])
+        out, n_total, n_ok = pc.run(g, sdf, tr, comp, "cpu")
+    finally:
+        cpu_port.uninstall()
+    assert (n_total, n_ok) == (int(g["inv_total"]), int(g["inv_ok"]))
+    pc.compare(out, g, rtol=2e-3, atol_rel=2e-4)

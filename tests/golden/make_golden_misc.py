@@ -1,0 +1,55 @@
+"""Golden vectors for small host-side pieces of the iteration, from the REAL reference code:
+
+  misc.npz   utils/utils.py:293-305 DCTNullSpace; OptimGarmentNetwork.dct_poses_loss (:1221-1250) with the reference
+             LBSkinner.posedSkeleton and the reference dataset's get_batchframe_data (dataset/dataset.py:438-457) on a
+             stand-in `self`; utils.GMRobustError
+
+    python tests/golden/make_golden_misc.py
+"""
+import sys
+import types
+from pathlib import Path
+
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(HERE))
+sys.path[:0] = [str(REPO / "rec-mv_amd"), str(REPO)]
+import ref_loader  # noqa: E402
+
+ref_loader.install()
+import common_setup as cs  # noqa: E402
+from make_golden import save  # noqa: E402
+
+
+def main():
+    ref_loader.ref_module("model.network")
+    Dref = ref_loader.ref_module("model.Deformer")
+    Uref = ref_loader.ref_module("utils.utils")
+    OGN = ref_loader.ref_module("engineer.networks.OptimGarmentNetwork")
+    DS = ref_loader.ref_module("dataset.dataset")
+    null = Uref.DCTNullSpace(10, 30)
+    sk = cs.build_skinner(Dref.LBSkinner, Dref.batch_rodrigues)
+    F = 40
+    g = torch.Generator().manual_seed(31)
+    poses = (0.15 * torch.randn(F, 24, 3, generator=g)).requires_grad_(True)
+    trans = (0.02 * torch.randn(F, 3, generator=g)).requires_grad_(True)
+    ds_cls = [v for v in vars(DS).values() if isinstance(v, type) and getattr(v, "__module__", "") == DS.__name__
+              and "get_batchframe_data" in vars(v)][0]
+    fake_ds = types.SimpleNamespace(video_segmented_index=[], frame_num=F, poses=poses, trans=trans)
+    fake_ds.get_batchframe_data = lambda name, fids, bs: ds_cls.get_batchframe_data(fake_ds, name, fids, bs)
+    fake = types.SimpleNamespace(dctnull=null, dataset=fake_ds, deformer=types.SimpleNamespace(defs=[None, sk]),
+                                 info={}, conf=types.SimpleNamespace(get_float=lambda k: 2.0))
+    frame_ids = torch.tensor([0, 17, 39])                      # window clamped at both ends and free in the middle
+    loss = OGN.OptimGarmentNetwork.dct_poses_loss(fake, poses[frame_ids], trans[frame_ids], frame_ids.clone(), 3)
+    gp, gt = torch.autograd.grad(loss, [poses, trans], allow_unused=True)
+    gt = torch.zeros_like(trans) if gt is None else gt
+    win, rel = fake_ds.get_batchframe_data('poses', torch.tensor([0, 17, 39]), 30)
+    x = torch.linspace(0, 0.3, 50)
+    save("misc", dctnull=null, poses=poses, trans=trans, frame_ids=frame_ids, dct_loss=loss, g_poses=gp, g_trans=gt,
+         window=win, rel=rel, gm_x=x, gm_true=Uref.GMRobustError(x, 0.01, True), gm_false=Uref.GMRobustError(x, 0.5, False))
+
+
+if __name__ == "__main__":
+    main()

@@ -201,3 +201,31 @@ def test_propagate_tmp_ps_grad_matches_the_reference_method():
         cpu_port.uninstall()
     assert (n_total, n_ok) == (int(g["inv_total"]), int(g["inv_ok"]))
     pc.compare(out, g, rtol=2e-3, atol_rel=2e-4)
+
+
+def test_dct_pose_loss_and_small_host_pieces_match_the_reference():
+    """tests/golden/make_golden_misc.py: DCTNullSpace (utils/utils.py:293-305), the frame windows of
+    get_batchframe_data (dataset/dataset.py:438-457), dct_poses_loss (:1221-1250) with its gradients, GMRobustError."""
+    import types
+    from recmv.loop import HotLoop, SyntheticFrames, dct_nullspace
+    from recmv.model import LBSkinner
+    from recmv.utils import GMRobustError
+    g = load("misc")
+    torch.testing.assert_close(dct_nullspace(30, 10), g["dctnull"], rtol=0, atol=2e-6)
+    poses, trans = g["poses"].clone().requires_grad_(True), g["trans"].clone().requires_grad_(True)
+    ds = types.SimpleNamespace(F=40, poses=poses, trans=trans)
+    ds.get_batchframe_data = lambda name, fids, nlen: SyntheticFrames.get_batchframe_data(ds, name, fids, nlen)
+    win, idx = ds.get_batchframe_data('poses', g["frame_ids"], 30)
+    assert torch.equal(win.detach(), g["window"])
+    assert torch.equal(g["frame_ids"] - idx[:, 0], g["rel"])            # the reference returns fids - starts
+    fake = types.SimpleNamespace(dctnull=g["dctnull"], dataset=ds, info={},
+                                 deformer=types.SimpleNamespace(defs=[None, cs.build_skinner(LBSkinner)]),
+                                 conf=types.SimpleNamespace(get_float=lambda k: 2.0))
+    fid = g["frame_ids"]
+    loss = HotLoop.dct_poses_loss(fake, poses[fid], trans[fid], fid, 3)
+    torch.testing.assert_close(loss, g["dct_loss"], rtol=1e-5, atol=1e-7)
+    gp, gt = torch.autograd.grad(loss, [poses, trans], allow_unused=True)
+    torch.testing.assert_close(gp, g["g_poses"], rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(torch.zeros_like(trans) if gt is None else gt, g["g_trans"], rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(GMRobustError(g["gm_x"], 0.01, True), g["gm_true"], rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(GMRobustError(g["gm_x"], 0.5, False), g["gm_false"], rtol=1e-6, atol=1e-8)

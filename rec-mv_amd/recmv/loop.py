@@ -572,6 +572,26 @@ class HotLoop:
         self.info['fl_loss']['total'] = loss.detach()
 
     # ------------------------------------------------------------------------------------------ mask loss
+    def compute_garment_pc_loss(self, def_verts, defconds, imgs, gtMs, garment_type, garment_vs):
+        """OptimGarmentNetwork.py:621-667: 1 - IoU of the splatted silhouette against the (dilated) ground-truth mask,
+        plus the robust distance between the full deformation and skinning alone.  (The Laplacian / edge / normal
+        terms have negative weights in every config of the reference — disabled, :633-650.)"""
+        conf = self.conf
+        N = gtMs.shape[0]
+        masks = imgs[..., -1]                                                             # :624-629
+        mask_loss = (1. - (masks * gtMs).view(N, -1).sum(1)
+                     / (masks + gtMs - masks * gtMs).abs().view(N, -1).sum(1)).mean()
+        self.info['pc_{}_mask_loss'.format(garment_type)] = mask_loss.detach()
+        loss = mask_loss * (conf.get_float('pc_weight.mask_weight') if 'pc_weight.mask_weight' in conf else 1.)
+        cw = conf.get_float('pc_weight.def_consistent.weight') if 'pc_weight.def_consistent' in conf else -1.
+        if cw > 0.:                                                                       # :651-662
+            offset2 = def_verts - self.deformer.defs[1](garment_vs.view(1, -1, 3).expand(N, -1, 3), defconds[1])
+            offset2 = (offset2 * offset2).sum(-1)
+            cc = conf.get_float('pc_weight.def_consistent.c')
+            closs = utils.GMRobustError(offset2, cc, True).mean() if cc > 0. else torch.sqrt(offset2).mean()
+            loss = loss + closs * cw
+        return loss
+
     def mask_loss(self, N, frame_ids, ratio, cameras):
         """OptimGarmentNetwork.py:841-981: deform the explicit garment meshes, splat the merged point cloud into one
         alpha-composited silhouette per garment (pcRender, :937), IoU loss against the dilated ground-truth masks +
@@ -589,20 +609,9 @@ class HotLoop:
             gt = self.dataset.garment_masks(g_i, frame_ids)
             if rpx > 0:                                                                   # :947
                 gt = F.max_pool2d(gt, kernel_size=2 * rpx + 1, stride=1, padding=rpx)
-            masks = garment_masks_list[g_i][..., -1]                                      # :624-629
-            mask_loss = (1. - (masks * gt).view(N, -1).sum(1)
-                         / (masks + gt - masks * gt).abs().view(N, -1).sum(1)).mean()
-            self.info['pc_{}_mask_loss'.format(name)] = mask_loss.detach()
-            loss = mask_loss * (conf.get_float('pc_weight.mask_weight') if 'pc_weight.mask_weight' in conf else 1.)
-            gv, defv = self.garment_vs[g_i], def_vs[g_i]
-            cw = conf.get_float('pc_weight.def_consistent.weight')
-            if cw > 0.:                                                                   # :651-662
-                offset2 = defv - self.deformer.defs[1](gv.view(1, -1, 3).expand(N, -1, 3), [poses, trans])
-                offset2 = (offset2 * offset2).sum(-1)
-                cc = conf.get_float('pc_weight.def_consistent.c')
-                closs = utils.GMRobustError(offset2, cc, True).mean() if cc > 0. else torch.sqrt(offset2).mean()
-                loss = loss + closs * cw
-            garment_loss = garment_loss + loss
+            garment_loss = garment_loss + self.compute_garment_pc_loss(
+                def_vs[g_i], [d_cond_list[g_i + 1], [poses, trans]], garment_masks_list[g_i], gt, name,
+                self.garment_vs[g_i])
         # find_surface_ps reads the deformed meshes and the PRE-step vertices (:918 runs before the SGD step): take
         # the snapshot here, rasterise later on a side stream while the backward below keeps the device busy
         self._surface_inputs = ([d.detach() for d in def_vs], [v.detach().clone() for v in self.garment_vs])

@@ -46,9 +46,26 @@ def main():
     gp, gt = torch.autograd.grad(loss, [poses, trans], allow_unused=True)
     gt = torch.zeros_like(trans) if gt is None else gt
     win, rel = fake_ds.get_batchframe_data('poses', torch.tensor([0, 17, 39]), 30)
+    # ---- compute_garment_pc_loss (:621-667) on a stand-in self: IoU of a soft silhouette + LBS-consistency term
+    from recmv.hocon import ConfigFactory
+    conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf")).get_config('loss_coarse')
+    gg = torch.Generator().manual_seed(32)
+    Np, V, Hh, Ww = 3, 64, 20, 24
+    imgs = torch.rand(Np, Hh, Ww, 1, generator=gg).requires_grad_(True)
+    gtM = (torch.rand(Np, Hh, Ww, generator=gg) > 0.5).float()
+    gverts = (0.4 * torch.randn(V, 3, generator=gg)).requires_grad_(True)
+    pz, tz = cs.poses_trans(Np, seed=33)
+    pz, tz = pz.detach(), tz.detach()
+    defv = (sk(gverts.view(1, -1, 3).expand(Np, -1, 3), [pz, tz]) + 0.02 * torch.randn(Np, V, 3, generator=gg))
+    fake2 = types.SimpleNamespace(conf=conf, info={'pc_loss': {}}, deformer=types.SimpleNamespace(defs=[None, sk]))
+    fake_mesh = types.SimpleNamespace(verts_padded=lambda: defv)
+    pc = OGN.OptimGarmentNetwork.compute_garment_pc_loss(fake2, fake_mesh, [None, [pz, tz]], imgs, gtM, None, 'upper',
+                                                         gverts, torch.zeros(4, 3, dtype=torch.long), 0)
+    g_img, g_v = torch.autograd.grad(pc, [imgs, gverts])
     x = torch.linspace(0, 0.3, 50)
     save("misc", dctnull=null, poses=poses, trans=trans, frame_ids=frame_ids, dct_loss=loss, g_poses=gp, g_trans=gt,
-         window=win, rel=rel, gm_x=x, gm_true=Uref.GMRobustError(x, 0.01, True), gm_false=Uref.GMRobustError(x, 0.5, False))
+         window=win, rel=rel, pc_imgs=imgs, pc_gt=gtM, pc_verts=gverts, pc_poses=pz, pc_trans=tz, pc_def=defv,
+         pc_loss=pc, pc_g_img=g_img, pc_g_verts=g_v, gm_x=x, gm_true=Uref.GMRobustError(x, 0.01, True), gm_false=Uref.GMRobustError(x, 0.5, False))
 
 
 if __name__ == "__main__":

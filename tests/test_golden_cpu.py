@@ -268,3 +268,58 @@ def _pc_loss_body(g, fake, sk, imgs, verts, N):
     torch.testing.assert_close(g_img, g["pc_g_img"], rtol=1e-4, atol=1e-8)
     # d(def - skin)/d verts cancels exactly in both implementations
     torch.testing.assert_close(torch.zeros_like(verts) if g_v is None else g_v, g["pc_g_verts"], rtol=1e-4, atol=1e-6)
+
+
+def test_surface_render_loss_matches_the_reference_method():
+    """OptimGarmentNetwork.surface_render_loss (:1083-1219) run for real (tests/golden/make_golden_render_loss.py) vs
+    HotLoop.surface_render_loss on the CPU port with the same seed: value, per-term info, and the gradients that
+    `backward()` leaves on the SDF net, the offset MLP, the colour net, the per-frame codes, the poses and the surface
+    points.  (Differences by construction: closed-form singular values instead of the CPU SVD, jet pass instead of
+    double backward.)"""
+    import types
+    from oracle import cpu_port
+    from recmv.hocon import ConfigFactory
+    from recmv.loop import HotLoop
+    from recmv.model import (CompositeDeformer, LBSkinner, MLPTranslator, RenderingNetwork_view_norm, getTmpSdf)
+    g = load("render_loss")
+    conf = ConfigFactory.parse_file(str(GOLD.parent.parent / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    cpu_port.install()
+    try:
+        sdf, tr = cs.build_sdf(getTmpSdf), cs.build_translator(MLPTranslator)
+        comp = CompositeDeformer([tr, cs.build_skinner(LBSkinner)])
+        rn = cs.build_render(RenderingNetwork_view_norm)
+        leaf = lambda t: t.detach().clone().requires_grad_(True)
+        leaves = dict(conds=leaf(g["conds"]), poses=leaf(g["poses"]), trans=leaf(g["trans"]),
+                      rendcond=leaf(g["in_rendcond"]))
+        fake = types.SimpleNamespace(conf=conf.get_config('loss_coarse'), device='cpu', garment_size=1,
+                                     garment_names=['upper'], garment_nets=[sdf], deformer=comp, netRender=rn, info={})
+        fake.garment_vs = [g["in_verts"].clone().requires_grad_(True)]
+        fake.dataset = types.SimpleNamespace(images=lambda fids: (g["in_gtC"], g["in_gtN"]))
+        fake.get_grad_parameters = lambda fids, dev: ([None, leaves["conds"]], leaves["poses"], leaves["trans"],
+                                                      leaves["rendcond"])
+        fake._ray_valid = [g["in_check"].sum()]
+        cameras = types.SimpleNamespace(R=g["in_R"])
+        samples = [(g["in_binds"], g["in_row"], g["in_col"], None, g["in_rays"])]
+        torch.manual_seed(int(g["seed"]))
+        loss = HotLoop.surface_render_loss(fake, 3, cameras, torch.arange(3), {"sdfRatio": 0.8, "deformerRatio": 0.7,
+                                                                               "renderRatio": 1.0},
+                                           [g["in_check"]], [g["in_init"].clone()], samples)
+        loss.backward()
+    finally:
+        cpu_port.uninstall()
+    torch.testing.assert_close(loss.detach(), g["loss"], rtol=2e-4, atol=1e-5)
+    for key, ours in (("upper_grad_loss", "upper_grad_loss"), ("def_upper_loss", "def_upper_loss"),
+                      ("upper_color_loss", "upper_color_loss"), ("upper_normal_loss", "upper_normal_loss")):
+        torch.testing.assert_close(fake.info[ours].detach().float(), g["info_" + key], rtol=5e-4, atol=1e-6)
+    sp, tp, rp = dict(sdf.named_parameters()), dict(tr.named_parameters()), dict(rn.named_parameters())
+    got = {"g_sdf_" + k.replace(".", "_"): sp[k].grad for k in ["lin0.weight_v", "lin4.weight_g", "lin8.bias", "lin8.weight_v"]}
+    got.update({"g_tr_" + k.replace(".", "_"): tp[k].grad for k in ["lin0.weight", "lin4.weight"]})
+    got.update({"g_rn_" + k.replace(".", "_"): rp[k].grad for k in ["lin0.weight_v", "lin4.bias"]})
+    for k, v in leaves.items():
+        if "g_" + k in g:
+            got["g_" + k] = v.grad
+        else:           # the reference leaves no gradient on this leaf (translation, per-frame colour code): neither do we
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+    got["g_TmpPs"] = fake.TmpPs[0].grad
+    import propagate_case as pc
+    pc.compare(got, g, rtol=5e-3, atol_rel=5e-4)

@@ -68,5 +68,40 @@ def main():
          pc_loss=pc, pc_g_img=g_img, pc_g_verts=g_v, gm_x=x, gm_true=Uref.GMRobustError(x, 0.01, True), gm_false=Uref.GMRobustError(x, 0.5, False))
 
 
+
+
+def sample_rays_fixture():
+    """OptimGarmentNetwork.sample_train_ray (:983-1055) for real: ground-truth-mask selection, host-RNG Bernoulli
+    subset, rays of the kept pixels (camera: recmv's restatement, see make_golden_propagate.py)."""
+    ref_loader.ref_module("model.network")
+    OGN = ref_loader.ref_module("engineer.networks.OptimGarmentNetwork")
+    from recmv.model import RectifiedPerspectiveCameras as OurCameras
+    OGN.RectifiedPerspectiveCameras = OurCameras
+    g = torch.Generator().manual_seed(51)
+    N, H, W = 3, 48, 40
+    lists = []
+    for P in (2500, 900):                                          # garment 0 is subsampled, garment 1 is not
+        lists.append(dict(b=torch.randint(0, N, (P,), generator=g), r=torch.randint(0, H, (P,), generator=g),
+                          c=torch.randint(0, W, (P,), generator=g), p=torch.randn(P, 3, generator=g)))
+    masks = [(torch.rand(N, H, W, generator=g) > 0.3).float() for _ in range(2)]
+    focal, pp = torch.tensor([[80., 78.]]), torch.tensor([[20., 24.]])
+    R, T = torch.diag(torch.tensor([-1., -1., 1.])).view(1, 3, 3), torch.tensor([[0.1, -0.2, 3.0]])
+    fake = types.SimpleNamespace(conf={}, garment_size=2, pcRender=None,
+                                 dataset=types.SimpleNamespace(get_camera_parameters=lambda n, d: (focal, pp, R, T, H, W)),
+                                 maskRender=types.SimpleNamespace(rasterizer=types.SimpleNamespace(cameras=None)))
+    torch.manual_seed(52)
+    out = OGN.OptimGarmentNetwork.sample_train_ray(
+        fake, N, 1024, masks, [l["b"] for l in lists], [l["r"] for l in lists], [l["c"] for l in lists],
+        [l["p"] for l in lists], torch.arange(N), "cpu")
+    sb, sr, sc, sp, rays, _cams = out
+    arrs = dict(masks=torch.stack(masks), focal=focal, pp=pp, R=R, T=T)
+    for i, l in enumerate(lists):
+        arrs.update({f"in{i}_{k}": v for k, v in l.items()})
+        arrs.update({f"out{i}_b": sb[i], f"out{i}_r": sr[i], f"out{i}_c": sc[i], f"out{i}_p": sp[i], f"out{i}_rays": rays[i]})
+    print("sample_train_ray: kept", [int(t.numel()) for t in sb])
+    save("sample_rays", **arrs)
+
+
 if __name__ == "__main__":
     main()
+    sample_rays_fixture()

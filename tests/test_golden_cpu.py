@@ -323,3 +323,24 @@ def test_surface_render_loss_matches_the_reference_method():
     got["g_TmpPs"] = fake.TmpPs[0].grad
     import propagate_case as pc
     pc.compare(got, g, rtol=5e-3, atol_rel=5e-4)
+
+
+def test_sample_train_ray_matches_the_reference_method():
+    """OptimGarmentNetwork.sample_train_ray (:983-1055) run for real with a seeded host generator: same pixels kept
+    (mask selection + Bernoulli subset drawn by torch's CPU generator), same rays."""
+    import types
+    from recmv.loop import HotLoop
+    from recmv.model import RectifiedPerspectiveCameras
+    g = load("sample_rays")
+    found = [(g[f"in{i}_b"], g[f"in{i}_r"], g[f"in{i}_c"], g[f"in{i}_p"], None) for i in range(2)]
+    fake = types.SimpleNamespace(conf={}, sample_pix=1024, garment_size=2, device='cpu', info={},
+                                 _surface_inputs=(None, None), find_surface_ps=lambda d, t, c: found,
+                                 dataset=types.SimpleNamespace(garment_masks=lambda g_i, fids: g["masks"][g_i]))
+    cams = RectifiedPerspectiveCameras(g["focal"], g["pp"], g["R"], g["T"], image_size=[(40, 48)])
+    torch.manual_seed(52)
+    out = HotLoop.sample_train_ray(fake, 3, torch.arange(3), cams)
+    for i, (b, r, c, p, rays) in enumerate(out):
+        assert torch.equal(b, g[f"out{i}_b"]) and torch.equal(r, g[f"out{i}_r"]) and torch.equal(c, g[f"out{i}_c"])
+        assert torch.equal(p, g[f"out{i}_p"])
+        torch.testing.assert_close(rays, g[f"out{i}_rays"], rtol=1e-6, atol=1e-7)
+    assert out[0][0].numel() < found[0][0].numel() and out[1][0].numel() > 500

@@ -505,6 +505,36 @@ class HotLoop:
             smpl_check = fl.surface_depth_check(cameras, (W, H), bfrags.zbuf, body, def_smpl_fl)
         return torch.stack([garment_check, smpl_check], dim=-1)
 
+    def compute_fl_proj_loss(self, def_fl_meshes, check_values, fl_masks, gt_fl_pts, garment_name, fl_vs_split, cameras):
+        """OptimGarmentNetwork.py:1605-1711 (fl_visible_method = zbuff): project the deformed curve samples, keep those
+        whose canonical-SMPL counterpart is at most ZBUF_THRESHOLD behind the body surface and whose feature line is
+        labelled in the frame, chamfer them against the frame's 2-D curve, add the curve regulariser."""
+        conf = self.conf
+        names = self.fl_extract[garment_name]
+        n_fl = len(names)
+        H, W = self.dataset.H, self.dataset.W
+        def_fl_verts = torch.cat(def_fl_meshes, dim=1)
+        screen_pts = cameras.transform_points_screen(def_fl_verts, (W, H))
+        thr = torch.cat([torch.full((n_s,), fl.ZBUF_THRESHOLD[n], device=def_fl_verts.device)
+                         for n, n_s in zip(names, fl_vs_split)]).view(1, -1, 1)
+        body_visible = (check_values < thr)[..., 1]                                       # :1644-1648
+        gt_list = list(torch.split(gt_fl_pts, [gt_fl_pts.shape[1] // n_fl for _ in range(n_fl)], dim=1))
+        screen_list = list(torch.split(screen_pts, fl_vs_split, dim=1))
+        vis_list = list(torch.split(body_visible, fl_vs_split, dim=1))
+        visible_masks = []
+        for i, (pts, vis) in enumerate(zip(screen_list, vis_list)):
+            fl_mask = fl_masks[:, None, i:i + 1].expand_as(pts)
+            visible_masks.append(torch.logical_and(fl_mask, vis[..., None].expand_as(pts)))
+        weights = [self.dataset.fl_weights[n] for n in names]
+        fl_loss = fl.fl_proj_loss(screen_list, gt_list, visible_masks, weights) * (
+            conf.get_float('fl_weight.weight') if 'fl_weight.weight' in conf else 1.)
+        reg = self.inter_free_curve.regularization(fl_masks)
+        center = reg['center_offset'] * (conf.get_float('alpha_weight.center_weight') if 'alpha_weight' in conf else 1.)
+        diff = reg['diff_a_loss'] * (conf.get_float('alpha_weight.diff_weight') if 'alpha_weight' in conf else 1.)
+        self.info['fl_loss']['{}_project loss'.format(garment_name)] = fl_loss.detach()
+        self.info['fl_loss']['{}_visible'.format(garment_name)] = body_visible.float().mean().detach()
+        return fl_loss + center + diff
+
     def project_2d_loss(self, N, frame_ids, ratio, cameras):
         """OptimGarmentNetwork.py:1772-1883 (deform_feature_line :1507-1603, compute_fl_proj_loss :1605-1711): deform
         the explicit curves, keep the samples the body does not hide, chamfer them against the frame's 2-D feature
@@ -533,30 +563,10 @@ class HotLoop:
                                                    name, N)                               # [N,P,2]
             split = [v.shape[1] for v in def_fl_vs]
             fl_masks = torch.cat([mask_dict[n] for n in names], dim=-1)                   # [N, lines]
-            # ---- compute_fl_proj_loss
-            verts = torch.cat(def_fl_vs, dim=1)
-            flat = verts.reshape(-1, 3)
-            view_z = ((flat.unsqueeze(-1) * cameras.R[0].unsqueeze(0)).sum(-2) + cameras.T[0].view(1, 3))[:, 2]
-            screen = torch.cat([cameras.project(flat), (1.0 / view_z).view(-1, 1)], dim=1).view(N, -1, 3)
-            thr = torch.cat([torch.full((n_s,), fl.ZBUF_THRESHOLD[n], device=self.device)
-                             for n, n_s in zip(names, split)]).view(1, -1, 1)
-            body_visible = (checks < thr)[..., 1]                                         # :1644-1648
-            screen_list = list(torch.split(screen, split, dim=1))
-            vis_list = list(torch.split(body_visible, split, dim=1))
-            visible_masks = []
-            for i, (pts, vis) in enumerate(zip(screen_list, vis_list)):
-                fl_mask = fl_masks[:, None, i:i + 1].expand_as(pts)
-                visible_masks.append(torch.logical_and(fl_mask, vis[..., None].expand_as(pts)))
-            weights = [self.dataset.fl_weights[n] for n in names]
-            gt_list = [gt_dict[n] for n in names]
-            fl_loss = fl.fl_proj_loss(screen_list, gt_list, visible_masks, weights) * (
-                conf.get_float('fl_weight.weight') if 'fl_weight.weight' in conf else 1.)
-            reg = self.inter_free_curve.regularization(fl_masks)
-            center = reg['center_offset'] * (conf.get_float('alpha_weight.center_weight') if 'alpha_weight' in conf else 1.)
-            diff = reg['diff_a_loss'] * (conf.get_float('alpha_weight.diff_weight') if 'alpha_weight' in conf else 1.)
-            self.info['fl_loss']['{}_project loss'.format(name)] = fl_loss.detach()
-            self.info['fl_loss']['{}_visible'.format(name)] = body_visible.float().mean().detach()
-            project_loss = project_loss + fl_loss + center + diff
+            garment_proj_loss = self.compute_fl_proj_loss(def_fl_vs, checks, fl_masks,
+                                                          torch.cat([gt_dict[n] for n in names], dim=1), name, split,
+                                                          cameras)
+            project_loss = project_loss + garment_proj_loss
             # ---- canonical curves on their garment's zero level (:1855-1858)
             cano = torch.cat([fl_vs_dict[n].view(-1, 3) for n in names], dim=0)
             cano_sdf = self.garment_nets[g_i](cano, ratio, features=False).view(-1)

@@ -57,6 +57,18 @@ class RectifiedPerspectiveCameras:
         z = v[:, 2]
         return torch.stack([(fx * v[:, 0] + px * z) / z, (fy * v[:, 1] + py * z) / z, z], dim=1)
 
+    def transform_points_screen(self, points, image_size=None, cam_id=0):
+        """World points [N,P,3] (or [P,3]) -> (screen_x, screen_y, ndc_z) with the reference's override of the
+        pytorch3d method (model/CameraMine.py:104-142): screen = (S-1)/2 - S * ndc / 2, so that screen_x / screen_y are
+        the pixel coordinates `view_rays` shoots through; ndc_z is the projective depth 1 / z_view."""
+        W = float(self.image_size[cam_id, 0])
+        H = float(self.image_size[cam_id, 1])
+        flat = points.reshape(-1, 3)
+        ndc = self.transform_points_ndc(flat, cam_id)
+        sx = (W - 1.) / 2. - W * ndc[:, 0] / 2.
+        sy = (H - 1.) / 2. - H * ndc[:, 1] / 2.
+        return torch.stack((sx, sy, 1.0 / ndc[:, 2]), dim=1).view(points.shape)
+
     def angThreshold(self, pixoffset=0.4, cam_id=0):
         """Smallest angle (degrees) subtended by `pixoffset` pixels at the image border
         (CameraMine.py:176-205)."""

@@ -94,5 +94,49 @@ def main():
          proj_loss=loss)
 
 
+
+
+def proj_loss_fixture():
+    """OptimGarmentNetwork.compute_fl_proj_loss (:1605-1711) for real on a stand-in self: screen projection, z-buffer
+    thresholds per feature line, label masks, fl_proj_loss (restated chamfer), curve regulariser with config weights."""
+    import types
+    ref_loader.ref_module("model.network")
+    G = ref_loader.ref_module("engineer.utils.garment_structure")
+    OGN = ref_loader.ref_module("engineer.networks.OptimGarmentNetwork")
+    from recmv import curves as ours
+    from recmv.hocon import ConfigFactory
+    from recmv.model import RectifiedPerspectiveCameras as OurCameras
+    OGN.fl_proj_loss.__globals__["chamfer_distance"] = lambda a, b, point_reduction='sum': (ours.chamfer_distance_sum(a, b), None)
+    conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf")).get_config('loss_coarse')
+    names = ['neck', 'left_cuff', 'right_cuff', 'upper_bottom']          # FL_EXTRACT['short_sleeve_upper']
+    cur = rings(8, n_lines=4, n=30)
+    ref = object.__new__(G.Intersect_Free_Curve)
+    torch.nn.Module.__init__(ref)
+    ref.cano2canosmpl = lambda lst, nm: [0.9 * c for c in lst]
+    ref.fl_names, ref.sample_num = names, 30
+    ref.initialize_parameters([c.clone() for c in cur])
+    g = torch.Generator().manual_seed(61)
+    N, S, M = 3, 30, 20
+    cam = OurCameras(torch.tensor([[300., 295.]]), torch.tensor([[64., 60.]]),
+                     torch.diag(torch.tensor([-1., -1., 1.])).view(1, 3, 3), torch.tensor([[0.05, -0.1, 2.5]]),
+                     image_size=[(128, 120)])
+    base = ref()                                                                                  # [4,S,3]
+    defs = [(base[i][None] + 0.03 * torch.randn(N, S, 3, generator=g)).detach().requires_grad_(True) for i in range(4)]
+    checks = [torch.rand(N, S, 2, generator=g) * 0.2 - 0.05 for _ in range(4)]                      # around the thresholds
+    fl_masks = torch.tensor([[1., 1., 0., 1.], [1., 1., 1., 1.], [0., 1., 1., 0.]])
+    gt = torch.rand(N, 4 * M, 2, generator=g) * 100 + 10
+    fake = types.SimpleNamespace(conf=conf, info={'fl_loss': {}}, inter_free_curve=ref,
+                                 dataset=types.SimpleNamespace(fl_weights={'neck': 1.0, 'left_cuff': 2.0,
+                                                                           'right_cuff': 0.5, 'upper_bottom': 1.5}))
+    proj_size = torch.tensor([[128., 120.]]).repeat(N, 1)
+    loss, vis, lab = OGN.OptimGarmentNetwork.compute_fl_proj_loss(
+        fake, defs, checks, None, fl_masks, gt, None, 'short_sleeve_upper', None, None, [S] * 4, 0, cam, proj_size)
+    grads = torch.autograd.grad(loss, defs + [ref.scale, ref.nx_scale])
+    save("curve_proj", curves=torch.stack(cur), defs=torch.stack([d.detach() for d in defs]), checks=torch.stack(checks),
+         fl_masks=fl_masks, gt=gt, loss=loss, g_defs=torch.stack(grads[:4]), g_scale=grads[4], g_nx=grads[5],
+         vis=torch.stack([v[..., 0] for v in vis]))
+
+
 if __name__ == "__main__":
     main()
+    proj_loss_fixture()

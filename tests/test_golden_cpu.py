@@ -344,3 +344,37 @@ def test_sample_train_ray_matches_the_reference_method():
         assert torch.equal(p, g[f"out{i}_p"])
         torch.testing.assert_close(rays, g[f"out{i}_rays"], rtol=1e-6, atol=1e-7)
     assert out[0][0].numel() < found[0][0].numel() and out[1][0].numel() > 500
+
+
+def test_compute_fl_proj_loss_matches_the_reference_method():
+    """OptimGarmentNetwork.compute_fl_proj_loss (:1605-1711) run for real: which samples count as visible (per-line
+    z-buffer thresholds x label masks), the weighted chamfer normalisation, the curve regulariser with the config's
+    weights — value and gradients w.r.t. the deformed samples and the curve parameters."""
+    import types
+    from recmv import curves as fl
+    from recmv.hocon import ConfigFactory
+    from recmv.loop import HotLoop
+    from recmv.model import RectifiedPerspectiveCameras
+    g = load("curve_proj")
+    conf = ConfigFactory.parse_file(str(GOLD.parent.parent / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    names = ['neck', 'left_cuff', 'right_cuff', 'upper_bottom']
+    curve = fl.Intersect_Free_Curve(list(g["curves"]), list(0.9 * g["curves"]), names)
+    cam = RectifiedPerspectiveCameras(torch.tensor([[300., 295.]]), torch.tensor([[64., 60.]]),
+                                      torch.diag(torch.tensor([-1., -1., 1.])).view(1, 3, 3),
+                                      torch.tensor([[0.05, -0.1, 2.5]]), image_size=[(128, 120)])
+    fake = types.SimpleNamespace(conf=conf.get_config('loss_coarse'), info={'fl_loss': {}}, inter_free_curve=curve,
+                                 fl_extract={'upper': names},
+                                 dataset=types.SimpleNamespace(H=120, W=128, fl_weights={'neck': 1.0, 'left_cuff': 2.0,
+                                                                                          'right_cuff': 0.5,
+                                                                                          'upper_bottom': 1.5}))
+    defs = [d.clone().requires_grad_(True) for d in g["defs"]]
+    checks = torch.cat(list(g["checks"]), dim=1)
+    loss = HotLoop.compute_fl_proj_loss(fake, defs, checks, g["fl_masks"], g["gt"], 'upper', [30] * 4, cam)
+    torch.testing.assert_close(loss, g["loss"], rtol=2e-5, atol=1e-6)
+    grads = torch.autograd.grad(loss, defs + [curve.scale, curve.nx_scale])
+    torch.testing.assert_close(torch.stack(grads[:4]), g["g_defs"], rtol=1e-3, atol=1e-8)
+    torch.testing.assert_close(grads[4], g["g_scale"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(grads[5], g["g_nx"], rtol=1e-4, atol=1e-8)
+    vis = float(fake.info['fl_loss']['upper_visible'])
+    assert 0.2 < vis < 0.95 and abs(vis - float((checks[..., 1] < torch.tensor(
+        [fl.ZBUF_THRESHOLD[n] for n in names]).repeat_interleave(30).view(1, -1)).float().mean())) < 1e-6

@@ -21,6 +21,7 @@ sys.path[:0] = [str(REPO / "rec-mv_amd"), str(REPO)]
 import ref_loader  # noqa: E402
 
 ref_loader.install()
+import common_setup as cs  # noqa: E402
 from make_golden import save  # noqa: E402
 
 
@@ -137,6 +138,81 @@ def proj_loss_fixture():
          vis=torch.stack([v[..., 0] for v in vis]))
 
 
+
+
+def visibility_fixture():
+    """OptimGarmentNetwork.fl_visible_by_body_zbuff (:1374-1448) for real on a stand-in self: reference deformer and
+    skinner, reference depth logic (background fill, uv mapping, bilinear z-buffer read, sign conventions).  The
+    rasteriser behind `maskRender` is the C oracle (pytorch3d is absent) and `Meshes` a plain holder."""
+    import types
+    ref_loader.ref_module("model.network")
+    Dref = ref_loader.ref_module("model.Deformer")
+    OGN = ref_loader.ref_module("engineer.networks.OptimGarmentNetwork")
+    from oracle import oracle as orc
+    from recmv.model import RectifiedPerspectiveCameras as OurCameras
+
+    class Meshes:
+        def __init__(self, verts, faces):
+            self.verts, self.faces = verts, faces
+
+    OGN.Meshes = Meshes
+    H, W, N = 60, 48, 3
+    cam = OurCameras(torch.tensor([[70., 68.]]), torch.tensor([[24., 30.]]),
+                     torch.diag(torch.tensor([-1., -1., 1.])).view(1, 3, 3), torch.tensor([[0.02, -0.05, 2.4]]),
+                     image_size=[(W, H)])
+
+    def mask_render(meshes):
+        verts = torch.stack([v.detach() for v in meshes.verts])                      # [N,V,3]
+        faces = meshes.faces[0]
+        ndc = cam.transform_points_ndc(verts.reshape(-1, 3)).view(N, -1, 3)
+        F = faces.shape[0]
+        fv = ndc[:, faces.reshape(-1)].reshape(-1, 3, 3)
+        p2f, zbuf, bary, dists = orc.rasterize_meshes(fv, torch.arange(N) * F, torch.full((N,), F), (H, W))
+        return None, types.SimpleNamespace(zbuf=zbuf, pix_to_face=p2f)
+
+    tr = cs.build_translator(Dref.MLPTranslator)
+    sk = cs.build_skinner(Dref.LBSkinner, Dref.batch_rodrigues)
+    comp = Dref.CompositeDeformer([tr, sk])
+
+    def sphere(res, radius):
+        ax = torch.linspace(-0.6, 0.6, res)
+        x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+        step = 1.2 / (res - 1)
+        return orc.mc(((x * x + y * y + z * z).sqrt() - radius).contiguous(), step, step, step, -0.6, -0.6, -0.6, 0.0)
+
+    gv, gf = sphere(21, 0.42)
+    bv, bf = sphere(17, 0.36)
+    conds, _ = cs.conds_and_inds(8, nframes=N, condlen=128, seed=4)
+    poses, trans = cs.poses_trans(N, seed=7)
+    conds, poses, trans = conds.detach(), poses.detach(), trans.detach()
+    t = torch.linspace(0, 2 * 3.14159265, 41)[:-1]
+    ring = lambda y, r: torch.stack([r * torch.cos(t), torch.full_like(t, y), r * torch.sin(t)], -1)
+    curves = [ring(0.25, 0.33), ring(-0.2, 0.37)]
+    smpl_curves = [c * (0.36 / 0.42) for c in curves]
+    ratio = {"sdfRatio": 0.8, "deformerRatio": 0.7, "renderRatio": 1.0}
+    with torch.no_grad():
+        def_fl = [comp(c.view(-1, 3).expand(N, -1, 3), [conds, [poses, trans]], ratio=ratio, offset_type=n)
+                  for c, n in zip(curves, ("neck", "upper_bottom"))]
+    fake = types.SimpleNamespace(deformer=comp, garment_vs=[gv], garment_fs=[gf], tmpBodyVs=bv, tmpBodyFs=bf,
+                                 maskRender=mask_render)
+    fake.maskRender = types.SimpleNamespace(__call__=None)
+    class MR:
+        rasterizer = types.SimpleNamespace(cameras=cam)
+        def __call__(self, meshes):
+            return mask_render(meshes)
+    fake.maskRender = MR()
+    proj_size = torch.tensor([[float(W), float(H)]]).repeat(N, 1)
+    with torch.no_grad():
+        out = OGN.OptimGarmentNetwork.fl_visible_by_body_zbuff(
+            fake, cam, [None, conds], [poses, trans], ratio, None, [d.clone() for d in def_fl],
+            [c.view(1, -1, 3) for c in smpl_curves], ["neck", "upper_bottom"], 0, "upper", proj_size, N)
+    print("visibility checks: garment %.3f..%.3f  body %.3f..%.3f" % (out[..., 0].min(), out[..., 0].max(),
+                                                                     out[..., 1].min(), out[..., 1].max()))
+    save("curve_vis", gv=gv, gf=gf, bv=bv, bf=bf, conds=conds, poses=poses, trans=trans, curves=torch.stack(curves),
+         smpl=torch.stack(smpl_curves), def_fl=torch.stack(def_fl), checks=out, H=H, W=W)
+
+
 if __name__ == "__main__":
     main()
     proj_loss_fixture()
+    visibility_fixture()

@@ -378,3 +378,39 @@ def test_compute_fl_proj_loss_matches_the_reference_method():
     vis = float(fake.info['fl_loss']['upper_visible'])
     assert 0.2 < vis < 0.95 and abs(vis - float((checks[..., 1] < torch.tensor(
         [fl.ZBUF_THRESHOLD[n] for n in names]).repeat_interleave(30).view(1, -1)).float().mean())) < 1e-6
+
+
+def test_fl_visibility_by_body_zbuffer_matches_the_reference_method():
+    """OptimGarmentNetwork.fl_visible_by_body_zbuff (:1374-1448) run for real (reference deformer + depth logic, oracle
+    rasteriser behind maskRender): [N,P,2] signed depth of every curve sample behind the garment surface and of its
+    canonical-SMPL counterpart behind the body surface."""
+    import types
+    from oracle import cpu_port
+    from recmv.loop import HotLoop
+    from recmv.model import CompositeDeformer, LBSkinner, MLPTranslator, RectifiedPerspectiveCameras
+    g = load("curve_vis")
+    H, W, N = int(g["H"]), int(g["W"]), 3
+    cam = RectifiedPerspectiveCameras(torch.tensor([[70., 68.]]), torch.tensor([[24., 30.]]),
+                                      torch.diag(torch.tensor([-1., -1., 1.])).view(1, 3, 3),
+                                      torch.tensor([[0.02, -0.05, 2.4]]), image_size=[(W, H)])
+    ratio = {"sdfRatio": 0.8, "deformerRatio": 0.7, "renderRatio": 1.0}
+    cpu_port.install()
+    try:
+        comp = CompositeDeformer([cs.build_translator(MLPTranslator), cs.build_skinner(LBSkinner)])
+        smpl_conds = [g["poses"], g["trans"]]
+        fake = types.SimpleNamespace(deformer=comp, garment_fs=[g["gf"]], tmpBodyVs=g["bv"], tmpBodyFs=g["bf"],
+                                     dataset=types.SimpleNamespace(H=H, W=W), _frag_cache={})
+        fake._garment_fragments = types.MethodType(HotLoop._garment_fragments, fake)
+        with torch.no_grad():
+            fake._shared_def_vs = [comp(g["gv"][None].expand(N, -1, 3), [g["conds"], smpl_conds], ratio=ratio,
+                                        offset_type="upper")]
+            out = HotLoop.fl_visible_by_body_zbuff(fake, cam, g["conds"], smpl_conds, ratio, list(g["def_fl"]),
+                                                   [c.view(1, -1, 3) for c in g["smpl"]], 0, "upper", N)
+    finally:
+        cpu_port.uninstall()
+    assert out.shape == g["checks"].shape
+    # a sample whose pixel sits on a silhouette edge reads a different mix of surface / background depth when the
+    # deformed vertices differ in the last bits: allow a handful of such samples
+    diff = (out - g["checks"]).abs()
+    assert float((diff > 2e-4).float().mean()) < 0.03, float((diff > 2e-4).float().mean())
+    assert float(diff.median()) < 1e-5

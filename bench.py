@@ -194,8 +194,11 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--stage", default="coarse")
-    ap.add_argument("--curves", action="store_true",
-                    help="also run the feature-curve branch (project_2d_loss, SURVEY.md §8f next row 3) every iteration")
+    ap.add_argument("--no-curves", dest="curves", action="store_false",
+                    help="skip the feature-curve branch (project_2d_loss + curve_aware_loss) the reference runs every "
+                         "iteration (OptimGarmentNetwork.py:1932, :972); ON by default")
+    ap.add_argument("--curves", dest="curves", action="store_true", help=argparse.SUPPRESS)
+    ap.set_defaults(curves=True)
     ap.add_argument("--settle-iters", type=int, default=240,
                     help="untimed iterations run once after building the loop, before the warm-up: state "
                          "preparation that takes the synthetic optimisation out of Adam's start-up transient, in "
@@ -336,7 +339,7 @@ def main():
                             "(recmv/loop.py docstring)" % (loop.batch_size, loop.sample_pix, args.stage,
                                                           tuple(int(v) for v in loop.engine.resolutions[-1]),
                                                           loop.remesh_intersect, loop.remesh_intersect,
-                                                          "ON" if args.curves else "off (next row 3)"),
+                                                          "ON (project_2d_loss + curve_aware_loss)" if args.curves else "OFF (--no-curves)"),
                 "parallelism": "frame-sharded dp%d, 1 RCCL all-reduce of shared grads / step" % world,
                 "mc_vertices": [int(v.shape[0]) for v in loop.garment_vs],
                 "rays_per_iter": int(loop.info.get('rays_total', 0)),

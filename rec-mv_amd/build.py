@@ -58,20 +58,36 @@ def _compile(src: Path, force: bool, verbose: bool, hdr_mtime: float) -> Path:
     if (not force and obj.exists() and obj.stat().st_mtime > src.stat().st_mtime
             and obj.stat().st_mtime > hdr_mtime):
         return obj
-    cmd = [hipcc(), *COMMON_FLAGS, "-c", str(src), "-o", str(obj)]
+    tmp = obj.with_suffix(f".o.tmp{os.getpid()}")
+    cmd = [hipcc(), *COMMON_FLAGS, "-c", str(src), "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        tmp.unlink(missing_ok=True)
         raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, obj)
     if verbose and r.stderr.strip():
         print(r.stderr)
     return obj
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
+    """One builder at a time (every rank of a torchrun job may call this at once): an exclusive file lock around the
+    whole build, objects and the library written to temporary names and renamed atomically, so that a concurrent
+    reader never sees a truncated file."""
+    import fcntl
     OBJ.mkdir(exist_ok=True)
     LIBDIR.mkdir(exist_ok=True)
+    with open(OBJ / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> Path:
     srcs = sorted(CSRC.glob("*.hip"))
     if not srcs:
         raise RuntimeError(f"no .hip sources under {CSRC}")
@@ -80,13 +96,16 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         objs = list(ex.map(lambda s: _compile(s, force, verbose, hdr_mtime), srcs))
     newest_obj = max(o.stat().st_mtime for o in objs)
     if force or not LIB.exists() or LIB.stat().st_mtime < newest_obj:
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs),
+        tmp = LIB.with_suffix(f".so.tmp{os.getpid()}")
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(tmp), *map(str, objs),
                f"-Wl,--version-script={VERSION_SCRIPT}"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            tmp.unlink(missing_ok=True)
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        os.replace(tmp, LIB)
     return LIB
 
 

@@ -207,6 +207,8 @@ class HotLoop:
         self.device = device
         self.stage = stage
         self.garment_names = ['upper', 'bottom']
+        self.garment_type = conf.get_string('train.garment_type') if 'train.garment_type' in conf else None
+        self.isfine = False                                   # train.py:239,312 set it with the fine stage
         self.garment_size = len(self.garment_names)
         torch.manual_seed(seed)
         mult = conf.get_int('sdf_net.multires')
@@ -255,6 +257,7 @@ class HotLoop:
         self.sdfShrinkRadius = 0.0
         self.forward_time = 0
         self.opt_times = 0.0
+        self.next_conf = self.next_train_conf = None
         self.body_vs = self.body_fs = None
         self.garment_vs, self.garment_fs = [], []
         self.dctnull = dct_nullspace(min(30, n_frames), min(10, max(n_frames // 3, 1)), device)
@@ -273,20 +276,30 @@ class HotLoop:
 
     # ------------------------------------------------------------------------------------------ stages / state
     def set_stage(self, stage, resolutions=None):
-        """utils.set_hierarchical_config (utils/utils.py:330-348): next stage's loss weights, batch size, re-mesh period
-        and Seg3dLossless pyramid (same box)."""
+        """utils.set_hierarchical_config (utils/utils.py:330-348): the batch size and the Seg3dLossless pyramid (same
+        box) change NOW; the stage's loss weights, point radius and re-mesh period are only parked in `next_conf` /
+        `next_train_conf` and take effect at the next scheduled re-mesh (update_hierarchical_config)."""
         conf = self.conf_all
         self.stage = stage
-        self.conf = conf.get_config('loss_' + stage)
-        self.remesh_intersect = conf.get_int(f'train.{stage}.point_render.remesh_intersect')
-        self.pc_radius = conf.get_float(f'train.{stage}.point_render.radius')
         self.batch_size = conf.get_int(f'train.{stage}.point_render.batch_size')
+        self.next_conf = conf.get_config('loss_' + stage)
+        self.next_train_conf = conf.get_config('train.' + stage)
         old = self.engine
         self.engine = Seg3dLossless(query_func=None, b_min=old.b_min.view(-1).tolist(), b_max=old.b_max.view(-1).tolist(),
                                     resolutions=resolutions if resolutions is not None else RESOLUTIONS[stage],
                                     align_corners=False, balance_value=0.0, use_cuda_impl=True,
                                     faster=False).to(self.device)
-        self.forward_time = 0                      # forces a re-mesh at the new resolution on the next iteration
+
+    def update_hierarchical_config(self):
+        """OptimNetwork.update_hierarchical_config (engineer/networks/OptimNetwork.py:79-117), called from
+        marching_cube_update (:697): apply the parked stage configuration and restart the re-mesh counter."""
+        if getattr(self, 'next_conf', None) is not None:
+            self.conf = self.next_conf
+            self.forward_time = 0
+            self.pc_radius = self.next_train_conf.get_float('point_render.radius')
+            self.remesh_intersect = self.next_train_conf.get_int('point_render.remesh_intersect')
+            self.sdfShrinkRadius = 0.0
+            self.next_conf = self.next_train_conf = None
 
     def _modules(self):
         mods = {'sdf': self.sdf, 'garment_nets': self.garment_nets, 'deformer': self.deformer,
@@ -386,6 +399,7 @@ class HotLoop:
         vs_list, fs_list = self.discretizeSDF(ratio, None, -self.sdfShrinkRadius)
         self.body_vs, self.body_fs = vs_list[0], fs_list[0]
         self.garment_vs, self.garment_fs = vs_list[1:], fs_list[1:]
+        self.update_hierarchical_config()                                                  # :697
         if self.body_vs.shape[0] == 0:
             raise AssertionError('tmp sdf vanished...')
         if any(v.shape[0] == 0 for v in self.garment_vs):
@@ -639,7 +653,44 @@ class HotLoop:
             sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
             self.info['pc_{}_loss_sdf'.format(name)] = sdf_loss.detach()
             pc_sdf_loss = pc_sdf_loss + sdf_loss * conf.get_float('pc_weight.weight')
+        pc_sdf_loss = pc_sdf_loss + self.curve_aware_loss(ratio)                          # :972
         return [d.detach() for d in def_vs], pc_sdf_loss
+
+    CURVE_AWARE = {'female_outfit1': 'bottom_curve', 'female_outfit3': 'bottom_curve',
+                   'anran_dance': 'bottom_curve'}                                          # utils/constant.py:228-232
+    CURVE_AWARE_SAMPLES = 50000                                                            # :808, :833
+
+    def curve_aware_loss(self, ratio, sampler=None):
+        """OptimGarmentNetwork.py:787-839: the disc spanned by the `upper_bottom` curve (the waist opening of the upper
+        garment) must lie ON the zero level of the LAST garment net (the bottom garment closes there): a triangle fan
+        from the curve to its centroid, 50 000 area-weighted uniform samples on it, |SDF| of garment_nets[-1].  The
+        samples are constants (the reference takes them through numpy), so the term only reaches the SDF parameters.
+        Fires whenever 'upper_bottom' is a feature line of the garment set (female-3-casual: yes) and the weight is
+        non-zero; datasets listed in CURVE_AWARE add the same term for their `bottom_curve` in the fine stage.
+
+        The reference samples with trimesh 3.10.5 `Trimesh.sample` on the host from numpy's global RNG and uploads the
+        points every iteration (:807-808); here `sample_fan_mesh` draws them on the device from torch's generator —
+        same distribution, no host round trip.  `sampler(verts, faces, n)` overrides the draw (parity tests)."""
+        conf = self.conf
+        weight = conf.get_float('pc_weight.curve_aware_weight') if 'pc_weight.curve_aware_weight' in conf else 60.
+        if weight == 0. or not getattr(self, 'curves', False):
+            return 0.
+        targets = []
+        if 'upper_bottom' in self.fl_names:
+            targets.append('upper_bottom')
+        extra = self.CURVE_AWARE.get(getattr(self, 'garment_type', None))
+        if extra is not None and getattr(self, 'isfine', False) and extra in self.fl_names:
+            targets.append(extra)
+        ca_loss = 0.
+        for name in targets:
+            curve_pts = self.inter_free_curve()[self.fl_names.index(name)].detach()         # [S,3]
+            verts, faces = fan_mesh(curve_pts)
+            pts = (sampler or sample_fan_mesh)(verts, faces, self.CURVE_AWARE_SAMPLES)
+            pred = self.garment_nets[-1](pts, ratio, features=False).view(-1)
+            circle = (pred + self.sdfShrinkRadius).abs().mean()
+            self.info['pc_{}_circle_loss_sdf'.format(name)] = circle.detach()
+            ca_loss = ca_loss + circle * weight
+        return ca_loss
 
     # ------------------------------------------------------------------------------------------ rays
     def find_surface_ps(self, def_vs, tmp_vs, cameras):
@@ -908,14 +959,21 @@ class HotLoop:
 
     # ------------------------------------------------------------------------------------------ one step
     def iters_per_epoch(self):
-        return max(self.dataset.F // (self.batch_size * self.world_size), 1)
+        """ceil(F / (batch_size * world_size)): the reference's DataLoader keeps the short last batch (drop_last=False,
+        dataset/dataset.py:1159-1183; train.py:250-260 counts ceil(len/bs) iterations per epoch)."""
+        return iters_per_epoch(self.dataset.F, self.batch_size, self.world_size)
 
     def frame_batch_at(self, epoch, pos):
         """Frames of this rank for position `pos` of `epoch`: a seeded permutation of all frames dealt round-robin over
-        ranks (the reference's RandomSampler, dataset/dataset.py:1135-1157, sharded — SURVEY.md §8e)."""
+        ranks (the reference's RandomSampler, dataset/dataset.py:1135-1157, sharded — SURVEY.md §8e).  The last
+        position of an epoch holds the remaining F mod (batch_size*world_size) frames; when that is fewer than one
+        frame per rank, the permutation wraps so that every rank still has a frame (all ranks must enter the
+        collectives)."""
         per_it = self.batch_size * self.world_size
         perm = torch.randperm(self.dataset.F, generator=torch.Generator().manual_seed(1234 + epoch))
         ids = perm[pos * per_it:(pos + 1) * per_it]
+        if ids.numel() < self.world_size:
+            ids = torch.cat([ids, perm[:self.world_size - ids.numel()]])
         return ids[self.rank::self.world_size][:self.batch_size].to(self.device)
 
     def frame_batch(self, it):
@@ -946,6 +1004,36 @@ class HotLoop:
             self.optimizer.step()
         self.opt_times += 1.
         return loss.detach(), self.info['rays_total']
+
+
+def fan_mesh(curve_pts):
+    """Closed curve [S,3] -> (vertices [S+1,3] = curve + centroid, faces [S,3] = (i, i+1, centre), the last one
+    wrapping) — OptimGarmentNetwork.py:797-806."""
+    S = curve_pts.shape[0]
+    verts = torch.cat([curve_pts, curve_pts.mean(0, keepdim=True)], dim=0)
+    i = torch.arange(S, device=curve_pts.device)
+    faces = torch.stack([i, (i + 1) % S, torch.full_like(i, S)], dim=1)
+    return verts, faces
+
+
+def sample_fan_mesh(verts, faces, count, generator=None):
+    """`trimesh.sample.sample_surface` (trimesh 3.10.5, third party — restated from its published algorithm, parity
+    unpinned) on the device: faces picked with probability proportional to their area (inverse CDF), a uniform point
+    of each picked triangle from two uniforms reflected into the lower-left half of the unit square."""
+    tri = verts[faces]                                                                     # [F,3,3]
+    e1, e2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    area = 0.5 * torch.linalg.cross(e1, e2, dim=-1).norm(dim=-1)
+    cum = torch.cumsum(area, 0)
+    u = torch.rand(count, device=verts.device, generator=generator) * cum[-1]
+    f = torch.searchsorted(cum, u).clamp_(max=faces.shape[0] - 1)
+    r = torch.rand(count, 2, device=verts.device, generator=generator)
+    r = torch.where((r.sum(1, keepdim=True) > 1.0), r - 1.0, r).abs()
+    return tri[f, 0] + e1[f] * r[:, 0:1] + e2[f] * r[:, 1:2]
+
+
+def iters_per_epoch(n_frames, batch_size, world_size=1):
+    """Optimiser iterations per epoch — the ONE formula behind HotLoop.iters_per_epoch and train.resumed_opt_times."""
+    return max(-(-n_frames // (batch_size * world_size)), 1)
 
 
 def _inject_gradients(targets, grads):

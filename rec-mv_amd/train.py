@@ -57,15 +57,18 @@ def stage_of_epoch(config, epoch):
     return 'coarse'
 
 
-def resumed_opt_times(config, n_frames, start_epoch):
-    """Optimiser iterations already done when resuming after `start_epoch` (train.py:250-260, formulas kept)."""
+def resumed_opt_times(config, n_frames, start_epoch, world_size=1):
+    """Optimiser iterations already done when resuming after `start_epoch` (train.py:250-260, formulas kept; the
+    per-epoch count is the loop's own `iters_per_epoch`, i.e. ceil(F / (batch * ranks)) — the reference's formula at
+    one rank)."""
+    from recmv.loop import iters_per_epoch
     coarse_epoch = config.get_int('train.coarse.start_epoch')
     medium_epoch = config.get_int('train.medium.start_epoch')
     fine_epoch = config.get_int('train.fine.start_epoch')
     bs = {s: config.get_int(f'train.{s}.point_render.batch_size') for s in ('coarse', 'medium', 'fine')}
-    coarse_time = math.ceil(n_frames / bs['coarse']) * (medium_epoch - coarse_epoch)
-    medium_time = math.ceil(n_frames / bs['medium']) * (fine_epoch - medium_epoch)
-    fine_time = math.ceil(n_frames / bs['fine']) * (start_epoch - medium_epoch + 1)
+    coarse_time = iters_per_epoch(n_frames, bs['coarse'], world_size) * (medium_epoch - coarse_epoch)
+    medium_time = iters_per_epoch(n_frames, bs['medium'], world_size) * (fine_epoch - medium_epoch)
+    fine_time = iters_per_epoch(n_frames, bs['fine'], world_size) * (start_epoch - medium_epoch + 1)
     return float(coarse_time + medium_time + fine_time)
 
 
@@ -109,12 +112,13 @@ def main(argv=None):
         stage = stage_of_epoch(config, start_epoch)
         if stage != 'coarse':
             loop.set_stage(stage)
+            loop.isfine = stage == 'fine'
             print('enable %s hierarchical' % stage)
         optimizer = loop.rebuild_optimizer()
         scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma=gamma)
         for __ in range(start_epoch + 1):
             scheduler.step()
-        loop.opt_times += resumed_opt_times(config, len(dataset), start_epoch)
+        loop.opt_times += resumed_opt_times(config, len(dataset), start_epoch, world)
         start_epoch += 1
 
     nepochs = config.get_int('train.nepoch')
@@ -125,6 +129,7 @@ def main(argv=None):
             if rank == 0:
                 utils.save_model(osp.join(save_root, stage + ".pth"), epoch, loop, dataset)   # coarse.pth / medium.pth
             loop.set_stage(new_stage)
+            loop.isfine = new_stage == 'fine'                  # train.py:312
             stage = new_stage
             torch.cuda.empty_cache()
             print('enable %s hierarchical' % stage)

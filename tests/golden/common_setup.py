@@ -108,3 +108,39 @@ def rootfind_init(sdf, n, seed):
         g = torch.autograd.grad(f.sum(), p)[0]
         p = (p - f * g / (g * g).sum(1, keepdim=True)).detach()
     return p
+
+
+class TrimeshStandIn:
+    """Stand-in for `trimesh.Trimesh(vertices, faces, process=False)` with the one method the hot path calls,
+    `.sample(count)` = trimesh.sample.sample_surface (trimesh 3.10.5 — third party, absent from /root/reference and from
+    this image; restated from its published algorithm: numpy, float64, area-weighted inverse-CDF face pick, two
+    uniforms per sample reflected into the triangle).  Draws from `rng` (a numpy RandomState) instead of numpy's global
+    state so that both sides of a parity test see the same points."""
+
+    rng = None
+
+    def __init__(self, vertices, faces, process=False):
+        self.vertices = np.asarray(vertices, dtype=np.float64)
+        self.faces = np.asarray(faces, dtype=np.int64)
+
+    def sample(self, count):
+        rng = TrimeshStandIn.rng
+        tri = self.vertices[self.faces]
+        area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+        weight_cum = np.cumsum(area)
+        face_index = np.searchsorted(weight_cum, rng.random_sample(count) * weight_cum[-1])
+        tri_origins = tri[:, 0][face_index]
+        tri_vectors = (tri[:, 1:] - tri[:, :1])[face_index]
+        random_lengths = rng.random_sample((count, 2, 1))
+        random_test = random_lengths.sum(axis=1).reshape(-1) > 1.0
+        random_lengths[random_test] -= 1.0
+        random_lengths = np.abs(random_lengths)
+        return (tri_vectors * random_lengths).sum(axis=1) + tri_origins
+
+
+def curve_aware_ring(n=200):
+    """The `upper_bottom` ring of the curve-aware fixture: a wobbly closed curve close to the zero level of
+    build_sdf's net (radius ~0.6)."""
+    t = torch.linspace(0, 2 * np.pi, n + 1)[:-1]
+    rho = 0.52 + 0.03 * torch.sin(3 * t)
+    return torch.stack([rho * torch.cos(t), -0.3 + 0.02 * torch.cos(2 * t), rho * torch.sin(t)], -1).float()

@@ -186,21 +186,14 @@ def test_fl_proj_loss_matches_the_reference_function():
 
 def test_propagate_tmp_ps_grad_matches_the_reference_method():
     """OptimGarmentNetwork.propagateTmpPsGrad (:2159-2313) run for real (tests/golden/make_golden_propagate.py) vs
-    HotLoop.propagateTmpPsGrad on the CPU port: the gradients injected into the SDF net, the offset MLP, the per-frame
-    codes, the poses / translations and the camera (focal, principal point, T) agree."""
+    HotLoop.propagateTmpPsGrad on the CPU port (tests/composite_cases.py; the same driver runs on the GPU)."""
     from oracle import cpu_port
-    import propagate_case as pc
-    from recmv.model import CompositeDeformer, LBSkinner, MLPTranslator, getTmpSdf
-    g = load("propagate")
+    import composite_cases as cc
     cpu_port.install()
     try:
-        sdf, tr = cs.build_sdf(getTmpSdf), cs.build_translator(MLPTranslator)
-        comp = CompositeDeformer([tr, cs.build_skinner(LBSkinner)])
-        out, n_total, n_ok = pc.run(g, sdf, tr, comp, "cpu")
+        cc.run_propagate("cpu")
     finally:
         cpu_port.uninstall()
-    assert (n_total, n_ok) == (int(g["inv_total"]), int(g["inv_ok"]))
-    pc.compare(out, g, rtol=2e-3, atol_rel=2e-4)
 
 
 def test_dct_pose_loss_and_small_host_pieces_match_the_reference():
@@ -233,184 +226,73 @@ def test_dct_pose_loss_and_small_host_pieces_match_the_reference():
 
 def test_compute_garment_pc_loss_matches_the_reference_method():
     """OptimGarmentNetwork.compute_garment_pc_loss (:621-667) run for real: silhouette IoU + LBS-consistency term and
-    their gradients w.r.t. the silhouette and the explicit vertices."""
-    import types
-    from recmv.hocon import ConfigFactory
-    from recmv.loop import HotLoop
-    from recmv.model import LBSkinner
-    g = load("misc")
-    conf = ConfigFactory.parse_file(str(GOLD.parent.parent / "configs" / "synthetic" / "people_snapshot_like.conf"))
-    sk = cs.build_skinner(LBSkinner)
-    fake = types.SimpleNamespace(conf=conf.get_config('loss_coarse'), info={},
-                                 deformer=types.SimpleNamespace(defs=[None, sk]))
-    imgs, verts = g["pc_imgs"].clone().requires_grad_(True), g["pc_verts"].clone().requires_grad_(True)
-    N = imgs.shape[0]
+    their gradients (tests/composite_cases.py)."""
     from oracle import cpu_port
-    cpu_port.install()              # the skinner's weight sampler runs on the C oracle here
+    import composite_cases as cc
+    cpu_port.install()
     try:
-        _pc_loss_body(g, fake, sk, imgs, verts, N)
+        cc.run_pc_loss("cpu")
     finally:
         cpu_port.uninstall()
-
-
-def _pc_loss_body(g, fake, sk, imgs, verts, N):
-    from recmv.loop import HotLoop
-    # the fixture's deformed vertices = skinning + a fixed perturbation; rebuild them on our skinner so that the
-    # consistency term differentiates through the same expression
-    base = sk(verts.view(1, -1, 3).expand(N, -1, 3), [g["pc_poses"], g["pc_trans"]])
-    with torch.no_grad():
-        ref_base = sk(g["pc_verts"].view(1, -1, 3).expand(N, -1, 3), [g["pc_poses"], g["pc_trans"]])
-        noise = g["pc_def"] - ref_base
-    loss = HotLoop.compute_garment_pc_loss(fake, base + noise, [None, [g["pc_poses"], g["pc_trans"]]], imgs,
-                                           g["pc_gt"], 'upper', verts)
-    torch.testing.assert_close(loss, g["pc_loss"], rtol=1e-5, atol=1e-6)
-    g_img, g_v = torch.autograd.grad(loss, [imgs, verts], allow_unused=True)
-    torch.testing.assert_close(g_img, g["pc_g_img"], rtol=1e-4, atol=1e-8)
-    # d(def - skin)/d verts cancels exactly in both implementations
-    torch.testing.assert_close(torch.zeros_like(verts) if g_v is None else g_v, g["pc_g_verts"], rtol=1e-4, atol=1e-6)
 
 
 def test_surface_render_loss_matches_the_reference_method():
     """OptimGarmentNetwork.surface_render_loss (:1083-1219) run for real (tests/golden/make_golden_render_loss.py) vs
-    HotLoop.surface_render_loss on the CPU port with the same seed: value, per-term info, and the gradients that
-    `backward()` leaves on the SDF net, the offset MLP, the colour net, the per-frame codes, the poses and the surface
-    points.  (Differences by construction: closed-form singular values instead of the CPU SVD, jet pass instead of
-    double backward.)"""
-    import types
+    HotLoop.surface_render_loss on the CPU port with the same seed: value, per-term info, gradients
+    (tests/composite_cases.py).  Differences by construction: closed-form singular values instead of the CPU SVD,
+    jet pass instead of double backward."""
     from oracle import cpu_port
-    from recmv.hocon import ConfigFactory
-    from recmv.loop import HotLoop
-    from recmv.model import (CompositeDeformer, LBSkinner, MLPTranslator, RenderingNetwork_view_norm, getTmpSdf)
-    g = load("render_loss")
-    conf = ConfigFactory.parse_file(str(GOLD.parent.parent / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    import composite_cases as cc
     cpu_port.install()
     try:
-        sdf, tr = cs.build_sdf(getTmpSdf), cs.build_translator(MLPTranslator)
-        comp = CompositeDeformer([tr, cs.build_skinner(LBSkinner)])
-        rn = cs.build_render(RenderingNetwork_view_norm)
-        leaf = lambda t: t.detach().clone().requires_grad_(True)
-        leaves = dict(conds=leaf(g["conds"]), poses=leaf(g["poses"]), trans=leaf(g["trans"]),
-                      rendcond=leaf(g["in_rendcond"]))
-        fake = types.SimpleNamespace(conf=conf.get_config('loss_coarse'), device='cpu', garment_size=1,
-                                     garment_names=['upper'], garment_nets=[sdf], deformer=comp, netRender=rn, info={})
-        fake.garment_vs = [g["in_verts"].clone().requires_grad_(True)]
-        fake.dataset = types.SimpleNamespace(images=lambda fids: (g["in_gtC"], g["in_gtN"]))
-        fake.get_grad_parameters = lambda fids, dev: ([None, leaves["conds"]], leaves["poses"], leaves["trans"],
-                                                      leaves["rendcond"])
-        fake._ray_valid = [g["in_check"].sum()]
-        cameras = types.SimpleNamespace(R=g["in_R"])
-        samples = [(g["in_binds"], g["in_row"], g["in_col"], None, g["in_rays"])]
-        torch.manual_seed(int(g["seed"]))
-        loss = HotLoop.surface_render_loss(fake, 3, cameras, torch.arange(3), {"sdfRatio": 0.8, "deformerRatio": 0.7,
-                                                                               "renderRatio": 1.0},
-                                           [g["in_check"]], [g["in_init"].clone()], samples)
-        loss.backward()
+        cc.run_render_loss("cpu")
     finally:
         cpu_port.uninstall()
-    torch.testing.assert_close(loss.detach(), g["loss"], rtol=2e-4, atol=1e-5)
-    for key, ours in (("upper_grad_loss", "upper_grad_loss"), ("def_upper_loss", "def_upper_loss"),
-                      ("upper_color_loss", "upper_color_loss"), ("upper_normal_loss", "upper_normal_loss")):
-        torch.testing.assert_close(fake.info[ours].detach().float(), g["info_" + key], rtol=5e-4, atol=1e-6)
-    sp, tp, rp = dict(sdf.named_parameters()), dict(tr.named_parameters()), dict(rn.named_parameters())
-    got = {"g_sdf_" + k.replace(".", "_"): sp[k].grad for k in ["lin0.weight_v", "lin4.weight_g", "lin8.bias", "lin8.weight_v"]}
-    got.update({"g_tr_" + k.replace(".", "_"): tp[k].grad for k in ["lin0.weight", "lin4.weight"]})
-    got.update({"g_rn_" + k.replace(".", "_"): rp[k].grad for k in ["lin0.weight_v", "lin4.bias"]})
-    for k, v in leaves.items():
-        if "g_" + k in g:
-            got["g_" + k] = v.grad
-        else:           # the reference leaves no gradient on this leaf (translation, per-frame colour code): neither do we
-            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
-    got["g_TmpPs"] = fake.TmpPs[0].grad
-    import propagate_case as pc
-    pc.compare(got, g, rtol=5e-3, atol_rel=5e-4)
 
 
 def test_sample_train_ray_matches_the_reference_method():
-    """OptimGarmentNetwork.sample_train_ray (:983-1055) run for real with a seeded host generator: same pixels kept
-    (mask selection + Bernoulli subset drawn by torch's CPU generator), same rays."""
-    import types
-    from recmv.loop import HotLoop
-    from recmv.model import RectifiedPerspectiveCameras
-    g = load("sample_rays")
-    found = [(g[f"in{i}_b"], g[f"in{i}_r"], g[f"in{i}_c"], g[f"in{i}_p"], None) for i in range(2)]
-    fake = types.SimpleNamespace(conf={}, sample_pix=1024, garment_size=2, device='cpu', info={},
-                                 _surface_inputs=(None, None), find_surface_ps=lambda d, t, c: found,
-                                 dataset=types.SimpleNamespace(garment_masks=lambda g_i, fids: g["masks"][g_i]))
-    cams = RectifiedPerspectiveCameras(g["focal"], g["pp"], g["R"], g["T"], image_size=[(40, 48)])
-    torch.manual_seed(52)
-    out = HotLoop.sample_train_ray(fake, 3, torch.arange(3), cams)
-    for i, (b, r, c, p, rays) in enumerate(out):
-        assert torch.equal(b, g[f"out{i}_b"]) and torch.equal(r, g[f"out{i}_r"]) and torch.equal(c, g[f"out{i}_c"])
-        assert torch.equal(p, g[f"out{i}_p"])
-        torch.testing.assert_close(rays, g[f"out{i}_rays"], rtol=1e-6, atol=1e-7)
-    assert out[0][0].numel() < found[0][0].numel() and out[1][0].numel() > 500
+    """OptimGarmentNetwork.sample_train_ray (:983-1055) run for real with a seeded host generator: same pixels kept,
+    same rays (tests/composite_cases.py)."""
+    from oracle import cpu_port
+    import composite_cases as cc
+    cpu_port.install()
+    try:
+        cc.run_sample_rays("cpu")
+    finally:
+        cpu_port.uninstall()
 
 
 def test_compute_fl_proj_loss_matches_the_reference_method():
-    """OptimGarmentNetwork.compute_fl_proj_loss (:1605-1711) run for real: which samples count as visible (per-line
-    z-buffer thresholds x label masks), the weighted chamfer normalisation, the curve regulariser with the config's
-    weights — value and gradients w.r.t. the deformed samples and the curve parameters."""
-    import types
-    from recmv import curves as fl
-    from recmv.hocon import ConfigFactory
-    from recmv.loop import HotLoop
-    from recmv.model import RectifiedPerspectiveCameras
-    g = load("curve_proj")
-    conf = ConfigFactory.parse_file(str(GOLD.parent.parent / "configs" / "synthetic" / "people_snapshot_like.conf"))
-    names = ['neck', 'left_cuff', 'right_cuff', 'upper_bottom']
-    curve = fl.Intersect_Free_Curve(list(g["curves"]), list(0.9 * g["curves"]), names)
-    cam = RectifiedPerspectiveCameras(torch.tensor([[300., 295.]]), torch.tensor([[64., 60.]]),
-                                      torch.diag(torch.tensor([-1., -1., 1.])).view(1, 3, 3),
-                                      torch.tensor([[0.05, -0.1, 2.5]]), image_size=[(128, 120)])
-    fake = types.SimpleNamespace(conf=conf.get_config('loss_coarse'), info={'fl_loss': {}}, inter_free_curve=curve,
-                                 fl_extract={'upper': names},
-                                 dataset=types.SimpleNamespace(H=120, W=128, fl_weights={'neck': 1.0, 'left_cuff': 2.0,
-                                                                                          'right_cuff': 0.5,
-                                                                                          'upper_bottom': 1.5}))
-    defs = [d.clone().requires_grad_(True) for d in g["defs"]]
-    checks = torch.cat(list(g["checks"]), dim=1)
-    loss = HotLoop.compute_fl_proj_loss(fake, defs, checks, g["fl_masks"], g["gt"], 'upper', [30] * 4, cam)
-    torch.testing.assert_close(loss, g["loss"], rtol=2e-5, atol=1e-6)
-    grads = torch.autograd.grad(loss, defs + [curve.scale, curve.nx_scale])
-    torch.testing.assert_close(torch.stack(grads[:4]), g["g_defs"], rtol=1e-3, atol=1e-8)
-    torch.testing.assert_close(grads[4], g["g_scale"], rtol=1e-4, atol=1e-8)
-    torch.testing.assert_close(grads[5], g["g_nx"], rtol=1e-4, atol=1e-8)
-    vis = float(fake.info['fl_loss']['upper_visible'])
-    assert 0.2 < vis < 0.95 and abs(vis - float((checks[..., 1] < torch.tensor(
-        [fl.ZBUF_THRESHOLD[n] for n in names]).repeat_interleave(30).view(1, -1)).float().mean())) < 1e-6
+    """OptimGarmentNetwork.compute_fl_proj_loss (:1605-1711) run for real: value and gradients
+    (tests/composite_cases.py)."""
+    from oracle import cpu_port
+    import composite_cases as cc
+    cpu_port.install()
+    try:
+        cc.run_fl_proj("cpu")
+    finally:
+        cpu_port.uninstall()
 
 
 def test_fl_visibility_by_body_zbuffer_matches_the_reference_method():
-    """OptimGarmentNetwork.fl_visible_by_body_zbuff (:1374-1448) run for real (reference deformer + depth logic, oracle
-    rasteriser behind maskRender): [N,P,2] signed depth of every curve sample behind the garment surface and of its
-    canonical-SMPL counterpart behind the body surface."""
-    import types
+    """OptimGarmentNetwork.fl_visible_by_body_zbuff (:1374-1448) run for real (tests/composite_cases.py)."""
     from oracle import cpu_port
-    from recmv.loop import HotLoop
-    from recmv.model import CompositeDeformer, LBSkinner, MLPTranslator, RectifiedPerspectiveCameras
-    g = load("curve_vis")
-    H, W, N = int(g["H"]), int(g["W"]), 3
-    cam = RectifiedPerspectiveCameras(torch.tensor([[70., 68.]]), torch.tensor([[24., 30.]]),
-                                      torch.diag(torch.tensor([-1., -1., 1.])).view(1, 3, 3),
-                                      torch.tensor([[0.02, -0.05, 2.4]]), image_size=[(W, H)])
-    ratio = {"sdfRatio": 0.8, "deformerRatio": 0.7, "renderRatio": 1.0}
+    import composite_cases as cc
     cpu_port.install()
     try:
-        comp = CompositeDeformer([cs.build_translator(MLPTranslator), cs.build_skinner(LBSkinner)])
-        smpl_conds = [g["poses"], g["trans"]]
-        fake = types.SimpleNamespace(deformer=comp, garment_fs=[g["gf"]], tmpBodyVs=g["bv"], tmpBodyFs=g["bf"],
-                                     dataset=types.SimpleNamespace(H=H, W=W), _frag_cache={})
-        fake._garment_fragments = types.MethodType(HotLoop._garment_fragments, fake)
-        with torch.no_grad():
-            fake._shared_def_vs = [comp(g["gv"][None].expand(N, -1, 3), [g["conds"], smpl_conds], ratio=ratio,
-                                        offset_type="upper")]
-            out = HotLoop.fl_visible_by_body_zbuff(fake, cam, g["conds"], smpl_conds, ratio, list(g["def_fl"]),
-                                                   [c.view(1, -1, 3) for c in g["smpl"]], 0, "upper", N)
+        cc.run_fl_visibility("cpu")
     finally:
         cpu_port.uninstall()
-    assert out.shape == g["checks"].shape
-    # a sample whose pixel sits on a silhouette edge reads a different mix of surface / background depth when the
-    # deformed vertices differ in the last bits: allow a handful of such samples
-    diff = (out - g["checks"]).abs()
-    assert float((diff > 2e-4).float().mean()) < 0.03, float((diff > 2e-4).float().mean())
-    assert float(diff.median()) < 1e-5
+
+
+def test_curve_aware_loss_matches_the_reference_method():
+    """OptimGarmentNetwork.curve_aware_loss (:787-839) run for real (tests/golden/make_golden_curve_aware.py): the fan
+    mesh of the `upper_bottom` curve, 50 000 samples, |SDF| of the last garment net — value, info, gradients; plus the
+    product's device-side sampler against the trimesh stand-in (tests/composite_cases.py)."""
+    from oracle import cpu_port
+    import composite_cases as cc
+    cpu_port.install()
+    try:
+        cc.run_curve_aware("cpu")
+    finally:
+        cpu_port.uninstall()

@@ -1,0 +1,41 @@
+"""The composite methods of the iteration ON THE GPU against the fixtures produced by the reference's own methods
+(tests/golden/make_golden_{render_loss,propagate,misc,curves,curve_aware}.py): `HotLoop.surface_render_loss`,
+`propagateTmpPsGrad`, `compute_garment_pc_loss`, `sample_train_ray`, `compute_fl_proj_loss`,
+`fl_visible_by_body_zbuff`, `curve_aware_loss`.  On `cuda:0` these methods take the product's fused branches (MFMA
+layers, jet pass, launch chains, fused LBS, HIP rasteriser) — the branches the CPU port never sees.  Same drivers and
+tolerances as the CPU tests (tests/composite_cases.py); f32 tolerances are written next to each driver's defaults.
+"""
+import pytest
+
+import composite_cases as cc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_surface_render_loss_on_gpu_matches_the_reference_method():
+    cc.run_render_loss(DEV)
+
+
+def test_propagate_tmp_ps_grad_on_gpu_matches_the_reference_method():
+    cc.run_propagate(DEV)
+
+
+def test_compute_garment_pc_loss_on_gpu_matches_the_reference_method():
+    cc.run_pc_loss(DEV)
+
+
+def test_sample_train_ray_on_gpu_matches_the_reference_method():
+    cc.run_sample_rays(DEV)
+
+
+def test_compute_fl_proj_loss_on_gpu_matches_the_reference_method():
+    cc.run_fl_proj(DEV)
+
+
+def test_fl_visibility_on_gpu_matches_the_reference_method():
+    cc.run_fl_visibility(DEV)
+
+
+def test_curve_aware_loss_on_gpu_matches_the_reference_method():
+    cc.run_curve_aware(DEV)

@@ -20,7 +20,10 @@ def test_schema_accessors_on_shipped_config():
     assert c.get_string('loss_coarse.fl_visible_method') == "zbuff"
     sub = c.get_config('loss_coarse')
     assert sub.get_float('def_regu.c') == 0.5 and 'def_regu' in sub and 'nope' not in sub
-    assert 'loss_coarse.pc_weight.def_consistent' in c and 'loss_fine' not in c
+    assert 'loss_coarse.pc_weight.def_consistent' in c and 'loss_extra' not in c
+    for stage in ('coarse', 'medium', 'fine'):             # every stage train.py switches to has its loss block
+        assert c.get_float(f'loss_{stage}.pc_weight.curve_aware_weight') > 0
+    assert c.get_int('loss_fine.sample_pix_num') == 6144
     assert c.get_int('train.coarse.point_render.remesh_intersect') == 30
     with pytest.raises(ConfigMissingException):
         c.get_int('train.missing')

@@ -14,11 +14,13 @@ REPO = Path(__file__).resolve().parent.parent
 CONF = str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf")
 
 
-def _tiny_loop(world=1, rank=0, seed=0, curves=False):
+def _tiny_loop(world=1, rank=0, seed=0, curves=False, lr=None):
     from recmv.hocon import ConfigFactory
     from recmv.loop import HotLoop
     conf = ConfigFactory.parse_file(CONF)
     conf.put('train.sample_pix_num', 32)
+    if lr is not None:
+        conf.put('train.learning_rate', lr)
     return HotLoop(conf, 'cpu', n_frames=12, H=64, W=64, resolutions=[(9, 11, 7), (17, 21, 13)], skin_grid=(5, 9, 7),
                    bbox=((-0.9, -1.2, -0.6), (0.9, 1.2, 0.6)), world_size=world, rank=rank, seed=seed, curves=curves)
 
@@ -57,8 +59,9 @@ def test_feature_curve_branch_on_cpu_port():
         assert loop.fl_names == ['neck', 'left_cuff', 'right_cuff', 'upper_bottom', 'left_pant', 'right_pant']
         before = [p.detach().clone() for p in loop.inter_free_curve.parameters()]
         l0, _ = loop.step(0)
+        circle0 = float(loop.info['pc_upper_bottom_circle_loss_sdf'])     # curve_aware_loss (:787-813) ran
         l1, _ = loop.step(1)
-        assert torch.isfinite(l0) and torch.isfinite(l1)
+        assert torch.isfinite(l0) and torch.isfinite(l1) and circle0 > 0
         info = loop.info['fl_loss']
         assert torch.isfinite(info['total']) and info['total'] > 0
         for name in loop.garment_names:
@@ -76,8 +79,62 @@ def test_feature_curve_branch_on_cpu_port():
         plain = _tiny_loop(curves=False)
         assert not any(k.startswith('inter_free_curve') for k in plain.state_dict())
         pl0, _ = plain.step(0)
-        # same seeds, same frames: the first iteration's loss does not depend on the curve branch
-        assert abs(float(pl0) - float(l0)) < 5e-2 * max(1.0, abs(float(pl0)))
+        # same seeds, same frames: the curve branch changes the first iteration's loss only by the curve-aware term
+        # (pc_weight.curve_aware_weight x |SDF| on the `upper_bottom` fan); project_2d_loss has its own backward
+        assert 'pc_upper_bottom_circle_loss_sdf' not in plain.info
+        w = loop.conf.get_float('pc_weight.curve_aware_weight')
+        assert abs(float(l0) - w * circle0 - float(pl0)) < 5e-2 * max(1.0, abs(float(pl0)))
+    finally:
+        cpu_port.uninstall()
+
+
+def test_stage_switch_is_applied_at_the_next_remesh():
+    """utils.set_hierarchical_config + OptimNetwork.update_hierarchical_config (utils/utils.py:330-348,
+    OptimNetwork.py:79-117): batch size and pyramid change at once, loss weights / point radius / re-mesh period at the
+    next scheduled re-mesh, which also restarts the re-mesh counter.  Both later stages of the shipped config load."""
+    from oracle import cpu_port
+    cpu_port.install()
+    try:
+        loop = _tiny_loop(lr=1e-6)        # Adam's first steps at 1e-4 move the SDF by more than this tiny box holds
+        loop.step(0)
+        assert loop.remesh_intersect == 30 and loop.batch_size == 3 and loop.forward_time == 1
+        w_coarse = loop.conf.get_float('pc_weight.weight')
+        loop.set_stage('medium', resolutions=[(9, 11, 7), (17, 21, 13)])
+        assert loop.batch_size == 2 and loop.next_conf is not None
+        assert loop.remesh_intersect == 30 and loop.conf.get_float('pc_weight.weight') == w_coarse   # still parked
+        loop.step(1)
+        assert loop.forward_time == 2 and loop.next_conf is not None          # no re-mesh yet: nothing applied
+        loop.forward_time = 30                                                # the next scheduled re-mesh
+        loop.step(2)
+        assert loop.next_conf is None and loop.remesh_intersect == 60 and loop.forward_time == 1
+        assert loop.conf.get_float('pc_weight.weight') == 30. and abs(loop.pc_radius - 0.00465) < 1e-9
+        loop.set_stage('fine', resolutions=[(9, 11, 7), (17, 21, 13)])
+        loop.forward_time = 60
+        l, _ = loop.step(3)
+        assert torch.isfinite(l) and loop.batch_size == 1 and loop.remesh_intersect == 120
+        assert loop.conf.get_int('sample_pix_num') == 6144
+    finally:
+        cpu_port.uninstall()
+
+
+def test_epoch_keeps_the_short_last_batch():
+    """DataLoader(drop_last=False): ceil(F / batch) iterations per epoch, the last one short; the same count feeds
+    train.resumed_opt_times.  With ranks, the last position still gives every rank a frame."""
+    from recmv.loop import iters_per_epoch
+    from oracle import cpu_port
+    cpu_port.install()
+    try:
+        loop = _tiny_loop()
+        loop.dataset.F = 11
+        assert loop.iters_per_epoch() == 4 == iters_per_epoch(11, 3, 1)
+        seen = torch.cat([loop.frame_batch_at(0, pos) for pos in range(4)])
+        assert sorted(seen.tolist()) == list(range(11)) and loop.frame_batch_at(0, 3).numel() == 2
+        pair = [_tiny_loop(world=2, rank=r) for r in range(2)]
+        for lp in pair:
+            lp.dataset.F = 13                       # 13 = 2 * 6 + 1: the last position has one frame for two ranks
+        assert pair[0].iters_per_epoch() == 3
+        a, b = pair[0].frame_batch_at(0, 2), pair[1].frame_batch_at(0, 2)
+        assert a.numel() == 1 and b.numel() == 1 and a.item() != b.item()
     finally:
         cpu_port.uninstall()
 

@@ -11,21 +11,28 @@
  *   oracle_interp2x_*    <- MCAcc/cuda/interp2x_boundary3d_kernel.cu:11-239
  *   oracle_mc_*          <- MCGpu/CudaKernels.cu:304-521 (tables :4-298, re-encoded in mc_tables.inc)
  *
- * Why a restatement and not the reference itself: the reference kernels are CUDA-only (every binding
- * asserts a CUDA tensor: FastMinv/M3x3Inv.cpp:4-6, MCGpu/MCGpu.cpp:3-5, interp2x_boundary3d.cpp:12-14)
- * and this environment has no nvcc; they cannot be compiled with gcc, so there is no oracle/_ref.
+ * Why a restatement and not the reference itself: the reference's extensions are CUDA-only (every binding asserts a
+ * CUDA tensor: FastMinv/M3x3Inv.cpp:4-6, MCGpu/MCGpu.cpp:3-5, interp2x_boundary3d.cpp:12-14), their host side
+ * launches with `<<<...>>>` and this environment has no nvcc.  Where the KERNEL BODIES are plain C they are compiled
+ * for the host as they lie in the reference tree and used to pin this file: oracle/_ref (oracle/Makefile `ref`,
+ * oracle/ref/*.cpp) holds MCGpu/CudaKernels.cu:4-521 and FastMinv/Matrix3x3InvKernels.cu:18-104 run serially through
+ * a CUDA-spelling shim; tests/test_oracle_ref.py asserts bit equality with oracle_mc / oracle_inv3x3_*.
  *
- * Pinning (tests/test_oracle_pins.py):
- *   inv3x3   — inv*m == I on randn(10000,3,3) as FastMinv/check.py:7-20 does; torch.linalg.inv (f64);
- *              backward vs autograd of torch.linalg.inv.
+ * Pinning (tests/test_oracle_pins.py, tests/test_oracle_ref.py):
+ *   inv3x3   — PINNED TO THE REFERENCE KERNELS (oracle/_ref, f32 and f64, forward + backward, bit-exact, incl. det=0
+ *              and |det| straddling 1e-4); also inv*m == I on randn(10000,3,3) as FastMinv/check.py:7-20 does;
+ *              torch.linalg.inv (f64); backward vs autograd of torch.linalg.inv.
  *   sampler  — equality with torch.nn.functional.grid_sample(bilinear, border, align_corners=False) and its
  *              autograd on the reference's own check shapes (MCAcc/check_grid_sampler_mine.py:5-9);
  *              gradcheck of the backward Function in f64 (ibid. :11-16) -> pins the double backward.
  *   interp2x — F.interpolate(trilinear, align_corners=True) + (0<valid<1), MCAcc/seg3d_lossless.py:273-282.
- *   MC       — PARITY UNPINNED against the reference binary: the reference holds no test or golden mesh for
- *              MCGpu and no marching-cubes library exists in this image.  Pinned only by invariants
- *              (closed 2-manifold, Euler characteristic 2 on a sphere, vertices on the iso-surface of the
- *              trilinear field, table SHA-256 equal to the one generated from the reference's table).
+ *   MC       — PINNED TO THE REFERENCE KERNELS (oracle/_ref): the reference's d_mc_get_mesh_on_gpu /
+ *              d_conver_ijkd_to_pindex / d_scale_vertices run on 13 volumes (white noise with shifted iso values,
+ *              sphere, surface touching the box, exact ties with the iso value) x 2 spacings; their output,
+ *              canonicalised by SURVEY.md §8a-E keys read from the reference's own edge->vertex table, equals
+ *              oracle_mc bit for bit (vertex f32 bits, face ids incl. -1, winding, face order), also when the
+ *              reference's ids are handed out in a scrambled order.  Plus the invariants (closed 2-manifold, Euler
+ *              characteristic 2 on a sphere) and the table SHA-256 equal to the one generated from the reference.
  *
  * Floating point: compiled with -ffp-contract=off; the places where the reference's nvcc build contracts
  * a*b+c into an fma that matters for last-bit equality are written with explicit fma()/fmaf().

@@ -115,21 +115,31 @@ int recmv_interp2x_boundary3d_backward(const void* grad_output, void* grad_input
  * corner order reversed exactly as the reference (CudaKernels.cu:502).  An edge whose owner voxel is
  * outside the grid has no vertex and is referenced as -1, as in the reference.
  *
- * Two-phase: recmv_mc_count classifies + scans and returns the sizes through `counts_host`
- * (3 x int32 {n_vertices, n_faces, n_active_segments}, HOST pointer, written after an internal stream sync —
- * the same D2H round trip as the reference's cudaMemcpy at CudaKernels.cu:628).  The caller allocates
- * vertices [V,3] f32 and faces [F,3] i64 and calls recmv_mc_emit with the same workspace and n_active_segments
- * (the number of 64-voxel segments that own a vertex or a triangle; recmv_mc_emit launches one wave per such
- * segment from the compacted list the scan left in the workspace).
- * recmv_mc_workspace_bytes gives the workspace size for a volume.
+ * recmv_mc_run is the whole extraction on the stream with NO host round trip (the reference reads its counters
+ * back between its two kernels, CudaKernels.cu:628): the caller passes output buffers with capacities, the
+ * kernels never write past them, and `counts_device` (3 x int32 {n_vertices, n_faces, n_active_voxels}, DEVICE
+ * pointer) receives the true sizes — if one exceeds its capacity the caller re-allocates and calls
+ * recmv_mc_emit with the same workspace (the classification is still in it).
+ * Two-phase form: recmv_mc_count classifies + scans and returns the sizes through `counts_host` (HOST pointer,
+ * written after an internal stream sync — the same D2H round trip as the reference's); the caller allocates
+ * vertices [V,3] f32 and faces [F,3] i64 and calls recmv_mc_emit with the same workspace and n_active_voxels
+ * (the number of voxels that own a vertex or a triangle: recmv_mc_emit runs one lane per such voxel from the
+ * list the scan left in the workspace).
+ * recmv_mc_workspace_bytes gives the workspace size for a volume (0 if the volume is not supported).
+ * Limits: at most 2^28 lattice points, every dimension < 32768.
  * ---------------------------------------------------------------------------------------------- */
 int64_t recmv_mc_workspace_bytes(int64_t nx, int64_t ny, int64_t nz);
 int recmv_mc_count(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float iso,
                    void* workspace, int64_t workspace_bytes, int32_t* counts_host, void* stream);
 int recmv_mc_emit(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float iso,
                   float xstep, float ystep, float zstep, float xmin, float ymin, float zmin,
-                  const void* workspace, int64_t workspace_bytes, int64_t n_active_segments,
-                  float* vertices, int64_t* faces, void* stream);
+                  const void* workspace, int64_t workspace_bytes, int64_t n_active_voxels,
+                  float* vertices, int64_t vertex_capacity, int64_t* faces, int64_t face_capacity, void* stream);
+int recmv_mc_run(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float iso,
+                 float xstep, float ystep, float zstep, float xmin, float ymin, float zmin,
+                 void* workspace, int64_t workspace_bytes,
+                 float* vertices, int64_t vertex_capacity, int64_t* faces, int64_t face_capacity,
+                 int32_t* counts_device, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A/B/D. Dense f32 contractions of the three MLPs (SDF model/network.py:98-111, deformer

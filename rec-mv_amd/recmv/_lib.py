@@ -16,7 +16,7 @@ _PKG = Path(__file__).resolve().parent.parent          # rec-mv_amd/
 LIB_PATH = _PKG / "lib" / "librecmv_hip.so"
 
 RECMV_OK = 0
-ABI_VERSION = 3          # include/recmv_hip.h; bumped when a signature changes (v2: recmv_mc_count / recmv_mc_emit)
+ABI_VERSION = 4          # include/recmv_hip.h; bumped when a signature changes (v4: recmv_mc_run, capacities in recmv_mc_emit)
 F32, F64 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = 0, 1, 2, 3
 
@@ -74,7 +74,10 @@ def _declare(lib):
         "recmv_interp2x_boundary3d_backward": (C.c_int, [vp, vp, i64, i64, i64, i64, i32, vp]),
         "recmv_mc_workspace_bytes": (i64, [i64, i64, i64]),
         "recmv_mc_count": (C.c_int, [vp, i64, i64, i64, f32, vp, i64, vp, vp]),
-        "recmv_mc_emit": (C.c_int, [vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, f32, vp, i64, i64, vp, vp, vp]),
+        "recmv_mc_emit": (C.c_int, [vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, f32, vp, i64, i64, vp, i64, vp, i64,
+                                    vp]),
+        "recmv_mc_run": (C.c_int, [vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, f32, vp, i64, vp, i64, vp, i64, vp,
+                                   vp]),
         "recmv_gemm_nt": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, f32, f32, vp]),
         "recmv_gemm_nt_actgrad": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, f32, f32, f32, vp]),
         "recmv_set_gemm_mode": (C.c_int, [i32]),

@@ -195,9 +195,10 @@ def run_fl_proj(device):
     loss = HotLoop.compute_fl_proj_loss(fake, defs, checks, g["fl_masks"], g["gt"], 'upper', [30] * 4, cam)
     torch.testing.assert_close(loss, g["loss"], rtol=2e-5, atol=1e-6)
     grads = torch.autograd.grad(loss, defs + [curve.scale, curve.nx_scale])
-    torch.testing.assert_close(torch.stack(grads[:4]), g["g_defs"], rtol=1e-3, atol=1e-8)
-    torch.testing.assert_close(grads[4], g["g_scale"], rtol=1e-4, atol=1e-8)
-    torch.testing.assert_close(grads[5], g["g_nx"], rtol=1e-4, atol=1e-8)
+    # f32: elements that are a difference of nearly equal chamfer pulls carry the summation-order error of the whole
+    # tensor, so the absolute tolerance is relative to the tensor's scale (1e-4 of max|g|)
+    for got, key, rtol in ((torch.stack(grads[:4]), "g_defs", 1e-3), (grads[4], "g_scale", 1e-4), (grads[5], "g_nx", 1e-4)):
+        torch.testing.assert_close(got, g[key], rtol=rtol, atol=1e-4 * float(g[key].abs().max()))
     vis = float(fake.info['fl_loss']['upper_visible'])
     thr = T([fl.ZBUF_THRESHOLD[n] for n in names]).repeat_interleave(30).view(1, -1)
     assert 0.2 < vis < 0.95 and abs(vis - float((checks[..., 1] < thr).float().mean())) < 1e-6

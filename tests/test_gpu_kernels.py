@@ -202,6 +202,63 @@ def test_mc_bit_exact_vs_oracle(oracle, shape, seed):
     assert torch.equal(v_g.cpu(), v_o), "vertex positions must be bit-exact"
 
 
+def test_mc_single_pass_route_capacity_overflow_and_unaligned_base(oracle):
+    """mc_gpu's second call for a grid takes the no-round-trip route (recmv_mc_run into buffers sized from the previous
+    extraction); a surface that outgrows the margin repeats the emit pass with exact sizes; a volume whose base pointer
+    is only 4-byte aligned (a slice) goes through the staging tile's alignment peel.  All bit-exact vs the oracle."""
+    import ctypes as C
+    from recmv import MCGpu, _lib as L
+    args = (0.013, 0.021, 0.017, -0.5, -0.6, -0.4, 0.0)
+    shape = (21, 19, 70)
+    small = _noise_volume(shape, 11) + 1.2          # few sign changes
+    dense = _noise_volume(shape, 12)                # many more: overflows the capacity guessed from `small`
+    MCGpu._last_sizes.clear()
+    for vol in (small, small, dense, dense, small):
+        v_o, f_o = oracle.mc(vol, *args)
+        v_g, f_g = MCGpu.mc_gpu(gpu(vol), *args)
+        assert torch.equal(f_g.cpu(), f_o) and torch.equal(v_g.cpu(), v_o)
+    assert oracle.mc(dense, *args)[0].shape[0] > 1.25 * oracle.mc(small, *args)[0].shape[0] + 4096
+    # capacities are never exceeded: run with room for 10 vertices / 7 faces and check the guard words behind them
+    lib = L.lib()
+    vol = gpu(dense)
+    ws = torch.empty(int(lib.recmv_mc_workspace_bytes(*shape)), dtype=torch.uint8, device=DEV)
+    vbuf = torch.full((40, 3), -7.0, device=DEV)
+    fbuf = torch.full((40, 3), -7, dtype=torch.int64, device=DEV)
+    cdev = torch.zeros(3, dtype=torch.int32, device=DEV)
+    L.check(lib.recmv_mc_run(L.ptr(vol), *shape, args[6], *args[:6], L.ptr(ws), ws.numel(), L.ptr(vbuf), 10,
+                             L.ptr(fbuf), 7, L.ptr(cdev), L.stream_ptr(vol.device)), "mc_run")
+    torch.cuda.synchronize()
+    v_o, f_o = oracle.mc(dense, *args)
+    assert cdev[:2].tolist() == [v_o.shape[0], f_o.shape[0]]
+    assert torch.equal(vbuf[:10].cpu(), v_o[:10]) and torch.equal(fbuf[:7].cpu(), f_o[:7])
+    assert (vbuf[10:] == -7.0).all() and (fbuf[7:] == -7).all()
+    # base pointer misaligned by 1, 2, 3 floats
+    for shift in (1, 2, 3):
+        flat = torch.zeros(dense.numel() + 8, device=DEV)
+        flat[shift:shift + dense.numel()] = gpu(dense).reshape(-1)
+        view = flat[shift:shift + dense.numel()].view(*shape)
+        assert view.data_ptr() % 16 == 4 * shift and view.is_contiguous()
+        v_g, f_g = MCGpu.mc_gpu(view, *args)
+        assert torch.equal(f_g.cpu(), f_o) and torch.equal(v_g.cpu(), v_o)
+
+
+@pytest.mark.parametrize("shape", [(70, 37, 129), (37, 70, 257), (9, 140, 31), (12, 10, 515)])
+def test_mc_tile_shapes_bit_exact_vs_oracle(oracle, shape):
+    """Volumes that exercise every staging-tile shape of the classify pass (rows of 31 ... 515 floats, clipped tiles in
+    i and j, several tiles per slab): a smooth field with a few thousand faces, bit-exact vs the oracle."""
+    from recmv import MCGpu
+    ax = [torch.linspace(-1, 1, n) for n in shape]
+    X, Y, Z = torch.meshgrid(*ax, indexing="ij")
+    vol = (torch.sqrt(X ** 2 + (0.9 * Y) ** 2 + (1.1 * Z) ** 2) - 0.83 + 0.05 * torch.sin(5 * X + 3 * Y) * torch.cos(4 * Z)
+           ).float().contiguous()
+    args = (0.02, 0.03, 0.01, -1.0, -1.0, -1.0, 0.0)
+    v_o, f_o = oracle.mc(vol, *args)
+    assert f_o.shape[0] > 1000
+    for _ in range(2):                                        # two-phase route, then the single-pass route
+        v_g, f_g = MCGpu.mc_gpu(gpu(vol), *args)
+        assert torch.equal(f_g.cpu(), f_o) and torch.equal(v_g.cpu(), v_o)
+
+
 def test_mc_sphere_and_degenerate(oracle):
     from recmv import MCGpu
     from test_mc_oracle import mesh_invariants, sphere_volume

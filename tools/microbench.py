@@ -131,8 +131,13 @@ def bench_mc(quick):
         verts = torch.empty(V, 3, device=DEV)
         faces = torch.empty(Fc, 3, dtype=torch.int64, device=DEV)
         t, b = timeit(lambda: lib.recmv_mc_emit(L.ptr(vol), n, n, n, 0.0, step, step, step, -1.0, -1.0, -1.0,
-                                                L.ptr(ws), ws.numel(), int(counts[2]), L.ptr(verts), L.ptr(faces), st))
+                                                L.ptr(ws), ws.numel(), int(counts[2]), L.ptr(verts), V, L.ptr(faces), Fc,
+                                                st))
         report(f"mc_emit {n}^3", t, b, nbytes=12 * V + 24 * Fc)
+        cdev = torch.empty(3, dtype=torch.int32, device=DEV)
+        t, b = timeit(lambda: lib.recmv_mc_run(L.ptr(vol), n, n, n, 0.0, step, step, step, -1.0, -1.0, -1.0, L.ptr(ws),
+                                               ws.numel(), L.ptr(verts), V, L.ptr(faces), Fc, L.ptr(cdev), st))
+        report(f"mc_run (classify+scan+emit, no host round trip) {n}^3", t, b, nbytes=4 * n ** 3 + 12 * V + 24 * Fc)
 
 
 def bench_raster(quick):

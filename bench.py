@@ -12,12 +12,23 @@ over ranks (weak scaling: every rank works on its own N frames) with one RCCL al
 gradients per optimiser step.  W untimed warm-up steps, then exactly K steps between barrier +
 torch.cuda.synchronize() on both sides; the elapsed time is the MAX over ranks; rank 0 prints ONE JSON line.
 
+The timed iteration is the reference's WHOLE iteration: feature-curve branch (project_2d_loss, curve_aware_loss) on, and
+a re-mesh (Seg3dLossless + marching cubes for the body and both garments) always inside the timed region: when K is
+shorter than the re-mesh period the phase of the re-mesh counter is set so that one re-mesh falls in the middle of the
+K steps (re-meshing MORE often than the reference's cadence: `value` is then conservative; `remesh` carries the
+per-step split and the rate at the reference's cadence).
+
 Extra objects on the line:
   roofline     — the dominant kernel (gemm_nt, the fused MFMA layer): algorithmic FLOPs of every launch in the
-                 timed region / their HIP-event durations (events recorded on torch's current stream = the
-                 stream the kernel is launched on) against the dense f32 MFMA peak (157.3 TFLOP/s).
-  cpu_baseline — the same loop code on the host cores through oracle/cpu_port.py (torch-CPU + C oracle) on a
-                 bounded, smaller sample of the same workload; rank 0, N=1 only.
+                 timed region / their HIP-event durations (events recorded on the stream each kernel is launched on)
+                 against the dense f32 MFMA peak (157.3 TFLOP/s); `traffic` = HBM bytes per launch from the committed
+                 rocprofv3 PMC passes over this same loop (profiles/r02_pmc_loop.json, FETCH_SIZE x2 per the guide).
+  hbm_kernels  — the HBM-bound kernels at the loop's shapes, each timed with HIP events around a captured hipGraph of
+                 identical launches (kernel time + the ~1.5 us dependent-launch gap; no Python between launches).
+  remesh       — per-step GPU times from events recorded at the step boundaries of the timed region.
+  cpu_baseline — ONE iteration of the SAME scene in the SAME state (the GPU loop's parameters, per-frame tensors and
+                 explicit meshes after the timed region, handed to a child process) on host cores through
+                 oracle/cpu_port.py (torch-CPU sgemm + C/OpenMP oracle kernels); rank 0, N=1 only.
 """
 from __future__ import annotations
 
@@ -129,44 +140,80 @@ def mc_extract_timing(device):
                                       unit="GB/s", frac=round(alg / mc_s / HBM_PEAK, 4)))
 
 
-CPU_BASELINE_CORES = 16      # cap: the GPU boxes expose 256 host threads; tiny per-op work does not scale past a socket slice
-CPU_BASELINE_LIMIT_S = 150   # hard wall-clock bound of the whole leg (it runs in a child process)
+CPU_BASELINE_CORES = 32      # cap: the GPU boxes expose 256 host threads; the loop's small ops do not scale past a socket slice
+CPU_BASELINE_LIMIT_S = 240   # hard wall-clock bound of the whole leg (it runs in a child process)
+HOTLOOP_KW = dict(n_frames=64, H=512, W=512)
 
 
-def _cpu_baseline_child(conf_path):
-    """Runs in a child process (see cpu_baseline): the same loop on host cores via oracle/cpu_port (torch-CPU
-    sgemm + C/OpenMP oracle kernels).  Bounded sample: 1/16 of the rays, a (57,81,33) pyramid instead of
-    (225,321,129) and a 24x33x57x33 skinning grid; the per-iteration point counts (MC vertices, rays) are reported
-    so the number can be scaled."""
+def export_state(loop, path, frame_ids, it):
+    """Everything the CPU child needs to repeat the GPU loop's NEXT iteration: parameters, per-frame tensors, the
+    synthetic targets, the explicit meshes and their SGD state stay out (momentum buffers are re-created: one step)."""
+    ds = loop.dataset
+    cpu = lambda t: t.detach().cpu()
+    st = dict(model={k: cpu(v) for k, v in loop.state_dict().items()},
+              dataset={k: cpu(getattr(ds, k)) for k in ("poses", "trans", "d_cond", "rendcond", "focal", "pp", "T", "img",
+                                                        "normal")},
+              masks=[cpu(m) for m in ds._masks], garment_vs=[cpu(v) for v in loop.garment_vs],
+              garment_fs=[cpu(f) for f in loop.garment_fs], body_vs=cpu(loop.body_vs), body_fs=cpu(loop.body_fs),
+              frame_ids=cpu(frame_ids), it=int(it), opt_times=float(loop.opt_times), forward_time=int(loop.forward_time),
+              stage=loop.stage, curves=bool(loop.curves))
+    if loop.curves:
+        st.update(gt_fl_pts=cpu(ds.gt_fl_pts), fl_masks=cpu(ds.fl_masks), tmpBodyVs=cpu(loop.tmpBodyVs),
+                  tmpBodyFs=cpu(loop.tmpBodyFs))
+    torch.save(st, path)
+
+
+def _cpu_baseline_child(conf_path, state_path):
+    """Runs in a child process (see cpu_baseline): the same loop code on host cores via oracle/cpu_port (torch-CPU sgemm
+    + C/OpenMP oracle kernels), SAME scene and SAME state as the GPU run: one optimiser iteration on the exported
+    frames, then (time permitting) one re-mesh."""
     cores = int(os.environ.get("OMP_NUM_THREADS", min(os.cpu_count() or 1, CPU_BASELINE_CORES)))
     torch.set_num_threads(cores)
     from oracle import cpu_port
     from recmv.hocon import ConfigFactory
     from recmv.loop import HotLoop
     cpu_port.install()
+    t_start = time.perf_counter()
+    st = torch.load(state_path)
     conf = ConfigFactory.parse_file(conf_path)
-    conf.put('train.sample_pix_num', 128)
-    loop = HotLoop(conf, 'cpu', n_frames=9, H=512, W=512, resolutions=[(15, 21, 9), (29, 41, 17), (57, 81, 33)],
-                   skin_grid=(33, 57, 33))
-    loop.step(0)                       # includes the re-mesh
+    loop = HotLoop(conf, 'cpu', stage=st["stage"], curves=st["curves"], **HOTLOOP_KW)
+    loop.load_state_dict(st["model"], strict=False)
+    ds = loop.dataset
+    with torch.no_grad():
+        for k, v in st["dataset"].items():
+            getattr(ds, k).data = v.clone()
+    ds._masks = st["masks"]
+    if st["curves"]:
+        ds.gt_fl_pts, ds.fl_masks = st["gt_fl_pts"], st["fl_masks"]
+        loop.tmpBodyVs, loop.tmpBodyFs = st["tmpBodyVs"], st["tmpBodyFs"]
+        loop.fl_optimizer = torch.optim.AdamW(loop.inter_free_curve.parameters(), lr=1e-4)
+    loop.body_vs, loop.body_fs = st["body_vs"], st["body_fs"]
+    loop.garment_vs = [v.clone().requires_grad_(True) for v in st["garment_vs"]]
+    loop.garment_fs = st["garment_fs"]
+    loop.garment_optimizer = torch.optim.SGD(loop.garment_vs, lr=0.05, momentum=0.9)
+    loop.opt_times = st["opt_times"]
+    loop.forward_time = 1                       # no re-mesh inside the timed iteration
     t0 = time.perf_counter()
-    n = 0
-    while n < 2 or time.perf_counter() - t0 < 10.0:
-        loop.step(1 + n)
-        n += 1
-        if time.perf_counter() - t0 > 30.0:
-            break
-    dt = (time.perf_counter() - t0) / n
-    verts = sum(int(v.shape[0]) for v in loop.garment_vs)
+    loop.step(st["it"], frame_ids=st["frame_ids"])
+    dt = time.perf_counter() - t0
+    remesh_s = None
+    if time.perf_counter() - t_start + 1.5 * dt < CPU_BASELINE_LIMIT_S - 60:
+        t0 = time.perf_counter()
+        loop.marching_cube_update({'sdfRatio': 1., 'deformerRatio': loop.opt_times / 2500. + 0.5, 'renderRatio': 1.})
+        remesh_s = time.perf_counter() - t0
+    verts = [int(v.shape[0]) for v in st["garment_vs"]]
     print("CPU_BASELINE " + json.dumps(dict(
-        value=round(1.0 / dt, 4), unit="iters/s", cores=cores, kind="port",
-        sample=f"{n} iterations of the same loop on a reduced scene: 3 frames, {verts} MC vertices "
-               f"(GPU run: see config.mc_vertices), {loop.info['rays_total']} rays/iter (GPU: "
-               f"config.rays_per_iter), pyramid (57,81,33), skinning grid 24x33x57x33, "
-               f"torch-CPU f32 + C/OpenMP oracle kernels on {cores} threads")), flush=True)
+        value=round(1.0 / dt, 5), unit="iters/s", cores=cores, kind="port", seconds_per_iter=round(dt, 2),
+        remesh_seconds=None if remesh_s is None else round(remesh_s, 2),
+        rays_per_iter=int(loop.info.get('rays_total', 0)), rays_converged=loop.info.get('rays_converged'),
+        sample=f"1 iteration (no re-mesh inside) of the SAME scene in the SAME state as the GPU run — its parameters, "
+               f"per-frame tensors, targets and explicit meshes ({verts} MC vertices) after the timed region, the same "
+               f"3 frames x 512x512, curve branch {'on' if st['curves'] else 'off'} — then one re-mesh (pyramid "
+               f"{tuple(int(v) for v in loop.engine.resolutions[-1])}, 3 nets) timed separately; torch-CPU f32 + "
+               f"C/OpenMP oracle kernels on {cores} threads")), flush=True)
 
 
-def cpu_baseline(conf_path):
+def cpu_baseline(conf_path, state_path):
     """CPU leg of the bench line, in a child process with a hard time limit so that a slow host can never keep the
     JSON line from being printed.  Threads are capped at CPU_BASELINE_CORES (`cores` reports what was used)."""
     import subprocess
@@ -176,8 +223,8 @@ def cpu_baseline(conf_path):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     try:
-        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-child", "--conf", conf_path],
-                           env=env, capture_output=True, text=True, timeout=CPU_BASELINE_LIMIT_S)
+        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cpu-baseline-child", "--conf", conf_path,
+                            "--state", state_path], env=env, capture_output=True, text=True, timeout=CPU_BASELINE_LIMIT_S)
         for ln in r.stdout.splitlines():
             if ln.startswith("CPU_BASELINE "):
                 return json.loads(ln[len("CPU_BASELINE "):])
@@ -186,6 +233,115 @@ def cpu_baseline(conf_path):
     except subprocess.TimeoutExpired:
         return dict(value=None, unit="iters/s", cores=cores, kind="port",
                     sample=f"child exceeded {CPU_BASELINE_LIMIT_S} s and was stopped")
+
+
+def _graph_time(fn, reps=20, trips=5):
+    """Average time of one `fn()` launch sequence: `reps` of them captured in a hipGraph, replayed `trips` times between
+    two HIP events (no Python between launches).  Falls back to eager launches if the capture is refused."""
+    torch.cuda.synchronize()
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    try:
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(reps):
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(trips):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / (reps * trips), "hipGraph"
+    except Exception as exc:                                   # noqa: BLE001 — timing aid only
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps, "eager (%s)" % type(exc).__name__
+
+
+def hbm_kernel_block(loop, device):
+    """The HBM-bound kernels at the loop's own shapes (SURVEY.md §8d byte counts): sampler forward / backward /
+    double backward on the loop's skinning grid at its MC vertices (one garment, one frame and all three), marching
+    cubes at 257^3 and at the loop's pyramid, the 2x boundary upsampler, the 3x3 inverse."""
+    import ctypes as C
+    from recmv import FastMinv, GridSamplerMine, _lib as L, interp2x_boundary3d
+    out = []
+
+    def add(name, nbytes, fn):
+        sec, how = _graph_time(fn)
+        out.append(dict(kernel=name, us=round(sec * 1e6, 2), alg_bytes=int(nbytes),
+                        achieved_gbs=round(nbytes / sec / 1e9, 1), frac=round(nbytes / sec / HBM_PEAK, 4), timing=how))
+
+    sk = loop.deformer.defs[1]
+    vol = sk.ws                                                          # [1,24,D,H,W] channels-last
+    Cc = vol.shape[1]
+    verts = loop.garment_vs[0].detach()
+    nps = ((verts - sk.bbox_center.to(device)) / sk.bbox_extend.to(device) * 2.).view(1, 1, 1, -1, 3).contiguous()
+    for rep, tag in ((1, "1 frame"), (3, "3 frames")):
+        g = nps.repeat(1, 1, 1, rep, 1).contiguous()
+        P = g.shape[3]
+        go = torch.randn(1, Cc, 1, 1, P, device=device)
+        gg = torch.randn(1, 1, 1, P, 3, device=device)
+        add(f"grid sampler forward, P={P} MC vertices ({tag})", P * (12 + 4 * Cc),
+            lambda g=g: GridSamplerMine.forward(vol, g, 0, 1))
+        add(f"grid sampler backward (grad_grid), P={P}", P * (12 + 4 * Cc + 12),
+            lambda g=g, go=go: GridSamplerMine.backward(vol, g, go, 0, 1, need_grad_input=False))
+        add(f"grid sampler double backward, P={P}", P * (12 + 12 + 4 * Cc + 12 + 4 * Cc),
+            lambda g=g, go=go, gg=gg: GridSamplerMine.dbackward(None, gg, vol, g, go, 0, 1, need_grad_input=False))
+    lib = L.lib()
+    st = lambda: L.stream_ptr(device)
+    for shape, volume in (((257, 257, 257), None), (tuple(int(v) for v in loop.engine.resolutions[-1]), None)):
+        nx, ny, nz = shape
+        ax = [torch.linspace(-1, 1, n, device=device) for n in shape]
+        X, Y, Z = torch.meshgrid(*ax, indexing="ij")
+        v3 = (torch.sqrt(X * X + (0.8 * Y) ** 2 + Z * Z) - 0.6 + 0.03 * torch.sin(9 * X) * torch.cos(7 * Z)).contiguous()
+        ws = torch.empty(int(lib.recmv_mc_workspace_bytes(nx, ny, nz)), dtype=torch.uint8, device=device)
+        cnt = (C.c_int32 * 3)(0, 0, 0)
+        L.check(lib.recmv_mc_count(L.ptr(v3), nx, ny, nz, 0.0, L.ptr(ws), ws.numel(), C.cast(cnt, C.c_void_p), st()), "mc")
+        V, F = int(cnt[0]), int(cnt[1])
+        vb = torch.empty(V, 3, device=device)
+        fb = torch.empty(F, 3, dtype=torch.int64, device=device)
+        cdev = torch.empty(3, dtype=torch.int32, device=device)
+        add(f"marching cubes {nx}x{ny}x{nz} (V={V}, F={F}; inside + classify + scan + emit, no host round trip)",
+            4 * nx * ny * nz + 12 * V + 24 * F,
+            lambda v3=v3, ws=ws, vb=vb, fb=fb, cdev=cdev, nx=nx, ny=ny, nz=nz, V=V, F=F: L.check(lib.recmv_mc_run(
+                L.ptr(v3), nx, ny, nz, 0.0, 2. / nx, 2. / ny, 2. / nz, -1.0, -1.0, -1.0, L.ptr(ws), ws.numel(), L.ptr(vb), V,
+                L.ptr(fb), F, L.ptr(cdev), st()), "mc_run"))
+    x = torch.randn(1, 1, 129, 129, 129, device=device)
+    add("interp2x_boundary3d forward 129^3 -> 257^3", 4 * 129 ** 3 + 5 * 257 ** 3, lambda: interp2x_boundary3d.forward(x, 0.0))
+    ms = torch.randn(1 << 20, 3, 3, device=device)
+    add("3x3 inverse forward, 2^20 matrices", 73 * (1 << 20), lambda: FastMinv.Fast3x3Minv(ms))
+    return out
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` in this loop, from the committed rocprofv3 PMC passes
+    (profiles/r02_pmc_loop.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of `bench.py`, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_loop.py produced it)."""
+    f = REPO / "profiles" / "r02_pmc_loop.json"
+    if not f.exists():
+        return None
+    try:
+        table = json.loads(f.read_text())
+    except ValueError:
+        return None
+    # bench names the variant by <T, FAST, AMUL>; the kernel's 4th template argument is the matrix mode (BF3)
+    want = kernel_name.split(" ")[0].rstrip(">")
+    mode = ", true>" if "bf16x6" in kernel_name else ", false>"
+    for k, v in table.get("kernels", {}).items():
+        if k.startswith(want) and (k.endswith(mode) or "<" not in k):
+            return v
+    return None
 
 
 def main():
@@ -213,11 +369,13 @@ def main():
                     help="skip the short extra measurement in the other matrix mode (reported as `alt_mode`)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the MFMA kernel launches with HIP events (no roofline object)")
+    ap.add_argument("--no-hbm-kernels", action="store_true", help="skip the hbm_kernels block")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--state", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--conf", default=str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
     args = ap.parse_args()
     if args.cpu_baseline_child:
-        _cpu_baseline_child(args.conf)
+        _cpu_baseline_child(args.conf, args.state)
         return
 
     from recmv import dist as rdist
@@ -235,8 +393,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     conf = ConfigFactory.parse_file(args.conf)
-    loop = HotLoop(conf, device, n_frames=64, H=512, W=512, stage=args.stage, world_size=world, rank=rank,
-                   curves=args.curves)
+    loop = HotLoop(conf, device, stage=args.stage, world_size=world, rank=rank, curves=args.curves, **HOTLOOP_KW)
     rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters())
                           + (list(loop.inter_free_curve.parameters()) if loop.curves else []))
     allreduce = rdist.GradAllReduce(world) if world > 1 else None
@@ -257,6 +414,10 @@ def main():
         it += 1
         torch.cuda.synchronize()
         log("warm-up step %d done" % it)
+    # one re-mesh inside the timed region whatever K is (see the module docstring)
+    period = loop.remesh_intersect
+    if args.steps < period:
+        loop.forward_time = period - args.steps // 2
     prof = KernelEvents() if not args.no_kernel_events else None
     if prof:
         prof.begin()
@@ -264,11 +425,17 @@ def main():
         loop.phase_ms = {}          # RECMV_TIMING=1: report the timed steps only
     rays = 0
     converged = 0
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    remesh_steps = []
     rdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
+        if loop.forward_time % loop.remesh_intersect == 0:
+            remesh_steps.append(k)
         _, r = loop.step(it, allreduce)
+        marks[k + 1].record()
         rays += int(r)
         converged += sum(loop.info.get('rays_converged', []))     # host ints the loop's own gate read back
         it += 1
@@ -333,8 +500,8 @@ def main():
             "rays_per_sec": round(rays / elapsed, 1),
             "config": {
                 "workload": "configs[1]: PeopleSnapshot female-3-casual-like, 512x512, frames_per_step=%d per GPU, "
-                            "2 garments, sample_pix_num=%d, stage=%s pyramid %s, remesh every %d iters (inside the "
-                            "timed region when steps>=%d); surface points from the HIP first-hit mesh rasteriser + "
+                            "2 garments, sample_pix_num=%d, stage=%s pyramid %s, remesh every %d iters (at least one "
+                            "inside the timed region: period %d); surface points from the HIP first-hit mesh rasteriser + "
                             "FindSurfacePs, mask loss on the HIP point-splat silhouettes; feature-curve branch %s "
                             "(recmv/loop.py docstring)" % (loop.batch_size, loop.sample_pix, args.stage,
                                                           tuple(int(v) for v in loop.engine.resolutions[-1]),
@@ -352,10 +519,12 @@ def main():
             dom = max(gs, key=lambda k: gs[k]["seconds"])
             g = gs[dom]
             ach = g["flops"] / g["seconds"]
+            tr = pmc_traffic(dom + (" bf16x6" if args.gemm_mode == "bf16x6" else ""))
             line["roofline"] = {"kernel": "recmv::" + dom + " (MFMA layer: GEMM + bias + activation epilogue; matrix mode " +
                                           args.gemm_mode + ")",
                                 "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": MFMA_F32_PEAK / 1e12,
-                                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), "traffic": None,
+                                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), "traffic": tr.get("traffic_bytes_per_launch") if tr else None,
+                                "traffic_detail": tr,
                                 "launches": g["launches"], "avg_launch_us": round(g["avg_us"], 2),
                                 "avg_launch_gflop": round(g["avg_flops"] / 1e9, 3),
                                 "share_of_step": round(g["seconds"] / elapsed, 3),
@@ -363,6 +532,20 @@ def main():
                                                        "achieved": round(v["flops"] / v["seconds"] / 1e12, 3)}
                                                    for k, v in gs.items() if k != dom},
                                 "untimed_small_launches": prof.small}
+        step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
+        plain = [m for k, m in enumerate(step_ms) if k not in remesh_steps]
+        with_r = [step_ms[k] for k in remesh_steps]
+        if plain:
+            plain_ms = sum(plain) / len(plain)
+            extra = (sum(with_r) / len(with_r) - plain_ms) if with_r else None
+            line["remesh"] = {
+                "period_iters": period, "remesh_steps_in_timed_region": len(with_r), "plain_step_ms": round(plain_ms, 3),
+                "remesh_extra_ms": None if extra is None else round(extra, 3),
+                "ms_per_step_at_reference_cadence": None if extra is None else round(plain_ms + extra / period, 3),
+                "iters_per_sec_at_reference_cadence": None if extra is None else round(
+                    world * 1e3 / (plain_ms + extra / period), 4),
+                "note": "GPU time between HIP events recorded at the step boundaries (rank 0); `value` has %d re-mesh(es) "
+                        "in %d steps, the reference's cadence is 1 in %d" % (len(with_r), args.steps, period)}
         if alt:
             line["alt_mode"] = alt
         log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
@@ -371,8 +554,15 @@ def main():
         if not args.no_mc:
             line.update(mc_extract_timing(device))
             log("MC extraction timing done")
+        if not args.no_hbm_kernels:
+            line["hbm_kernels"] = hbm_kernel_block(loop, device)
+            log("HBM kernel block done")
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.conf)
+            import tempfile
+            with tempfile.TemporaryDirectory() as tmp:
+                state = os.path.join(tmp, "state.pt")
+                export_state(loop, state, loop.frame_batch(it), it)
+                line["cpu_baseline"] = cpu_baseline(args.conf, state)
             log("CPU baseline done")
         print(json.dumps(line), flush=True)
     rdist.barrier()

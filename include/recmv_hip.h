@@ -297,7 +297,8 @@ int recmv_rasterize_meshes(const float* face_verts, const int64_t* mesh_first_fa
  * dists (squared NDC distance of the point to the pixel centre; a point is listed when it is < radius^2 and z >= 0),
  * the K nearest in depth, sorted by (depth, index), packed to the front.
  *   recmv_rasterize_points_backward : grad_points [total_points,3] = d/dpoints of (grad_dists . dists + grad_zbuf . zbuf)
- *                                     (grad_zbuf may be NULL); accumulates with float atomics.
+ *                                     (grad_zbuf may be NULL).  One thread per point sums its pixels in row-major order:
+ *                                     deterministic (upstream accumulates with float atomics).
  *   recmv_alpha_composite_forward   : images [N,C,H,W]; images[n,c,y,x] = sum_k a_k prod_{l<k}(1 - a_l) features[c,idx_k]
  *                                     with alphas [N,H,W,K] and features [C,total_points].  radius2 == 0: `alphas`
  *                                     are the opacities.  radius2 != 0: `alphas` holds the rasteriser's dists and
@@ -311,8 +312,10 @@ int recmv_rasterize_points(const float* points, const int64_t* cloud_first_point
                            int64_t N, int64_t total_points, int64_t max_points_per_cloud, int64_t H, int64_t W,
                            float radius, int points_per_pixel, int32_t* idx, float* zbuf, float* dists,
                            void* workspace, int64_t workspace_bytes, void* stream);
-int recmv_rasterize_points_backward(const float* points, const int32_t* idx, const float* grad_dists,
-                                    const float* grad_zbuf, int64_t N, int64_t total_points, int64_t H, int64_t W,
+int recmv_rasterize_points_backward(const float* points, const int64_t* cloud_first_point,
+                                    const int64_t* cloud_num_points, const int32_t* idx, const float* grad_dists,
+                                    const float* grad_zbuf, int64_t N, int64_t total_points,
+                                    int64_t max_points_per_cloud, int64_t H, int64_t W, float radius,
                                     int points_per_pixel, float* grad_points, void* stream);
 int recmv_alpha_composite_forward(const int32_t* idx, const float* alphas, const float* features, int64_t N,
                                   int64_t H, int64_t W, int points_per_pixel, int64_t C, int64_t total_points,

@@ -16,8 +16,8 @@
 //   resolve  one thread per pixel: K rounds of "smallest key greater than the last one" -> sorted by (depth, index),
 //            recomputes the squared distance, pads with -1
 // List storage order depends on scheduling, the OUTPUT does not (it is sorted with a total order).
-// The compositor and both backward passes are one thread per pixel; gradients w.r.t. points are float atomics
-// (as upstream), everything else is atomics-free.
+// The compositor and its backward are one thread per pixel; the rasteriser's backward is one thread per point (a fixed
+// summation order per point: deterministic, unlike upstream's float atomics); grad_features keeps float atomics.
 #include "common.h"
 
 namespace recmv {
@@ -179,27 +179,50 @@ points_resolve_heavy_kernel(const float* __restrict__ pts, const int* __restrict
   }
 }
 
+// One thread per POINT (not per pixel): it walks the pixel centres of its disc in row-major order and looks itself up in
+// each pixel's K-list.  Every point sums its own contributions in a fixed order — no atomics, the gradient is a pure
+// function of the inputs (the per-pixel formulation adds them with float atomics in scheduling order, upstream included).
 __global__ void __launch_bounds__(256)
-points_backward_kernel(const float* __restrict__ pts, const int* __restrict__ idx, const float* __restrict__ g_dists,
-                       const float* __restrict__ g_zbuf, int64_t npix, int H, int W, int K,
-                       float* __restrict__ g_pts) {
+points_backward_kernel(const float* __restrict__ pts, const int64_t* __restrict__ first,
+                       const int64_t* __restrict__ count, const int* __restrict__ idx,
+                       const float* __restrict__ g_dists, const float* __restrict__ g_zbuf, int H, int W, int K,
+                       float radius, float* __restrict__ g_pts) {
+  const int n = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npix) return;
-  const int64_t pix = i % ((int64_t)H * W);
-  const float xf = pix_to_ndc((int)(pix % W), W), yf = pix_to_ndc((int)(pix / W), H);
-  for (int k = 0; k < K; ++k) {
-    const int p = idx[i * K + k];
-    if (p < 0) break;  // lists are packed: the first -1 ends them
-    const float gd = g_dists ? g_dists[i * K + k] : 0.f;
-    const float gx = 2.f * gd * (pts[3 * (int64_t)p] - xf);
-    const float gy = 2.f * gd * (pts[3 * (int64_t)p + 1] - yf);
-    if (gx != 0.f) atomicAdd(g_pts + 3 * (int64_t)p, gx);
-    if (gy != 0.f) atomicAdd(g_pts + 3 * (int64_t)p + 1, gy);
-    if (g_zbuf) {
-      const float gz = g_zbuf[i * K + k];
-      if (gz != 0.f) atomicAdd(g_pts + 3 * (int64_t)p + 2, gz);
+  if (i >= count[n]) return;
+  const int64_t p = first[n] + i;
+  const float px = pts[3 * p], py = pts[3 * p + 1], pz = pts[3 * p + 2];
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (pz >= 0.f) {
+    const float r2 = radius * radius;
+    int c0, c1, r0, r1;
+    disc_range(px, radius, W, c0, c1);
+    disc_range(py, radius, H, r0, r1);
+    const int64_t base = (int64_t)n * H * W;
+    for (int row = r0; row <= r1; ++row) {
+      const float yf = pix_to_ndc(row, H);
+      const float dy = yf - py;
+      for (int col = c0; col <= c1; ++col) {
+        const float xf = pix_to_ndc(col, W);
+        const float dx = xf - px;
+        if (!(dx * dx + dy * dy < r2)) continue;
+        const int64_t e = (base + (int64_t)row * W + col) * K;
+        for (int k = 0; k < K; ++k) {
+          const int q = idx[e + k];
+          if (q < 0) break;                     // lists are packed: the first -1 ends them
+          if (q != (int)p) continue;
+          const float gd = g_dists ? g_dists[e + k] : 0.f;
+          gx = gx + 2.f * gd * (px - xf);
+          gy = gy + 2.f * gd * (py - yf);
+          if (g_zbuf) gz = gz + g_zbuf[e + k];
+          break;
+        }
+      }
     }
   }
+  g_pts[3 * p] = gx;
+  g_pts[3 * p + 1] = gy;
+  g_pts[3 * p + 2] = gz;
 }
 
 // images[n,c,y,x] = sum_k a_k prod_{l<k} (1 - a_l) features[c, idx_k];  a = alphas, or 1 - alphas / radius2 when
@@ -340,18 +363,23 @@ extern "C" int recmv_rasterize_points(const float* points, const int64_t* cloud_
   return check_launch("rasterize_points");
 }
 
-extern "C" int recmv_rasterize_points_backward(const float* points, const int32_t* idx, const float* grad_dists,
-                                               const float* grad_zbuf, int64_t N, int64_t total_points, int64_t H,
-                                               int64_t W, int points_per_pixel, float* grad_points, void* stream) {
-  RECMV_REQUIRE(N >= 0 && H > 0 && W > 0 && total_points >= 0 && points_per_pixel > 0,
+extern "C" int recmv_rasterize_points_backward(const float* points, const int64_t* cloud_first_point,
+                                               const int64_t* cloud_num_points, const int32_t* idx,
+                                               const float* grad_dists, const float* grad_zbuf, int64_t N,
+                                               int64_t total_points, int64_t max_points_per_cloud, int64_t H,
+                                               int64_t W, float radius, int points_per_pixel, float* grad_points,
+                                               void* stream) {
+  RECMV_REQUIRE(N >= 0 && H > 0 && W > 0 && total_points >= 0 && points_per_pixel > 0 && max_points_per_cloud >= 0,
                 "rasterize_points_backward: bad sizes");
   hipStream_t s = (hipStream_t)stream;
+  // points outside every cloud's range get a zero gradient
   RECMV_HIP_TRY(hipMemsetAsync(grad_points, 0, (size_t)(total_points * 3 * sizeof(float)), s));
-  const int64_t npix = N * H * W;
-  if (npix == 0 || total_points == 0) return RECMV_OK;
-  points_backward_kernel<<<(unsigned)ceil_div(npix, 256), 256, 0, s>>>(points, idx, grad_dists, grad_zbuf, npix,
-                                                                        (int)H, (int)W, points_per_pixel,
-                                                                        grad_points);
+  if (N == 0 || total_points == 0 || max_points_per_cloud == 0) return RECMV_OK;
+  RECMV_REQUIRE(points && cloud_first_point && cloud_num_points && idx && grad_points,
+                "rasterize_points_backward: NULL pointer");
+  points_backward_kernel<<<dim3((unsigned)ceil_div(max_points_per_cloud, 256), (unsigned)N), 256, 0, s>>>(
+      points, cloud_first_point, cloud_num_points, idx, grad_dists, grad_zbuf, (int)H, (int)W, points_per_pixel, radius,
+      grad_points);
   return check_launch("rasterize_points_backward");
 }
 

@@ -116,7 +116,7 @@ def _declare(lib):
         "recmv_rasterize_meshes_workspace_bytes": (i64, [i64, i64, i64, i64]),
         "recmv_rasterize_points_workspace_bytes": (i64, [i64, i64, i64, i64, f32]),
         "recmv_rasterize_points": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, f32, i32, vp, vp, vp, vp, i64, vp]),
-        "recmv_rasterize_points_backward": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, i32, vp, vp]),
+        "recmv_rasterize_points_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, i32, vp, vp]),
         "recmv_alpha_composite_forward": (C.c_int, [vp, vp, vp, i64, i64, i64, i32, i64, i64, f32, vp, vp]),
         "recmv_alpha_composite_backward": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i32, i64, i64, f32, vp, vp, vp]),
         "recmv_rasterize_meshes": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, f32, i32, i32, vp, vp, vp, vp, vp,

@@ -117,21 +117,23 @@ class _RasterizePoints(torch.autograd.Function):
                                                P if max_points is None else int(max_points), H, W, float(radius),
                                                int(K), L.ptr(idx), L.ptr(zbuf), L.ptr(dists), L.ptr(ws), ws.numel(),
                                                L.stream_ptr(dev)), "rasterize_points")
-        ctx.save_for_backward(points, idx)
+        ctx.save_for_backward(points, idx, cloud_first, cloud_num)
+        ctx.radius, ctx.max_points = float(radius), (P if max_points is None else int(max_points))
         ctx.mark_non_differentiable(idx)
         return idx, zbuf, dists
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, _g_idx, g_zbuf, g_dists):
-        points, idx = ctx.saved_tensors
+        points, idx, cloud_first, cloud_num = ctx.saved_tensors
         N, H, W, K = idx.shape
         g_points = torch.empty_like(points)
         with torch.cuda.device(points.device):
             L.check(L.lib().recmv_rasterize_points_backward(
-                L.ptr(points), L.ptr(idx), L.ptr(g_dists.contiguous()) if g_dists is not None else None,
-                L.ptr(g_zbuf.contiguous()) if g_zbuf is not None else None, N, points.shape[0], H, W, K,
-                L.ptr(g_points), L.stream_ptr(points.device)), "rasterize_points_backward")
+                L.ptr(points), L.ptr(cloud_first), L.ptr(cloud_num), L.ptr(idx),
+                L.ptr(g_dists.contiguous()) if g_dists is not None else None,
+                L.ptr(g_zbuf.contiguous()) if g_zbuf is not None else None, N, points.shape[0], ctx.max_points, H, W,
+                ctx.radius, K, L.ptr(g_points), L.stream_ptr(points.device)), "rasterize_points_backward")
         return g_points, None, None, None, None, None, None, None
 
 

@@ -1,0 +1,68 @@
+"""HBM traffic per launch of the loop's MFMA kernels, from rocprofv3 PMC passes over bench.py itself.
+
+    # on the GPU box, one pass per counter (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
+    cd /tmp && export TMPDIR=/tmp
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o run -- python $REPO/bench.py --steps 3 --warmup 1 \
+          --settle-iters 40 --no-cpu-baseline --no-mc --no-alt-mode --no-hbm-kernels --no-kernel-events
+    done
+    python tools/pmc_loop.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > profiles/r02_pmc_loop.json
+
+Per kernel name (template arguments kept, parameter list dropped): launches seen, mean FETCH_SIZE / WRITE_SIZE per
+launch in bytes (rocprofv3 reports KiB-like units; FETCH_SIZE doubled: on gfx950 a wide coalesced streaming read is
+tallied at half its size; WRITE_SIZE is uncalibrated and taken as reported) and their sum = `traffic`.  The means are
+over ALL launches of the kernel in the run (settle + timed steps): the loop's launch mix, not one shape.
+"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("void ", "").replace("recmv::(anonymous namespace)::", "")
+    depth, out = 0, []
+    for ch in name:                      # cut the parameter list: the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out).strip()
+
+
+def collect(root):
+    acc = defaultdict(list)
+    for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if "recmv::" in row.get("Kernel_Name", ""):
+                    acc[(short(row["Kernel_Name"]), row["Counter_Name"])].append(float(row["Counter_Value"]))
+    return acc
+
+
+def main():
+    acc = {}
+    for root in sys.argv[1:]:
+        acc.update(collect(root))
+    kernels = {}
+    for (name, ctr), vals in acc.items():
+        k = kernels.setdefault(name, {"launches": len(vals)})
+        mean = sum(vals) / len(vals) * 1024.0
+        if ctr == "FETCH_SIZE":
+            k["fetch_bytes_per_launch"] = round(2.0 * mean)
+        elif ctr == "WRITE_SIZE":
+            k["write_bytes_per_launch"] = round(mean)
+    for k in kernels.values():
+        if "fetch_bytes_per_launch" in k and "write_bytes_per_launch" in k:
+            k["traffic_bytes_per_launch"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+    top = dict(sorted(kernels.items(), key=lambda kv: -kv[1].get("traffic_bytes_per_launch", 0) * kv[1]["launches"])[:40])
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py (tools/pmc_loop.py); FETCH_SIZE x2 "
+                         "(gfx950 wide-read correction), WRITE_SIZE as reported", "kernels": top}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -142,6 +142,32 @@ int recmv_mc_run(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float iso
                  int32_t* counts_device, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * E'. Seg3dLossless bookkeeping on the device (csrc/seg3d.hip) — the per-level steps of
+ *   MCAcc/seg3d_lossless.py:_forward (:233-428) between the upsampler (C above) and the MLP queries: which voxels of
+ *   the level to query, their world points, the write-back with sign-conflict detection, and the growth of the
+ *   conflicts' 3^3 neighbourhoods.  Volumes are [D,H,W], x fastest, linear voxel index i = (z*H + y)*W + x (int32);
+ *   the set of evaluated voxels is a bit volume (uint32 words, bit i&31 of word i>>5; ceil(D*H*W/32)+1 words).
+ *   Every counter is a DEVICE int32 that the call zeroes first; lists are never written past `capacity`.
+ *   recmv_seg3d_select : list = voxels with dilate3x3x3(is_boundary) != 0 that are not evaluated, where "evaluated" =
+ *                        bit of the parent level (sizes (D+1)/2 ...) at even coordinates; `done` receives
+ *                        evaluated | listed for the whole level (replaces: box filter, coords_accum erase, transposed
+ *                        nonzero, unique(dim=1) of :296-330).  List order is unspecified.
+ *   recmv_seg3d_points : points[t] = ((x*sx, y*sy, z*sz) / res + (1/res)/2) * extent + bmin  (batch_eval, :99-101)
+ *   recmv_seg3d_apply  : flags[t] = (occupancy[i] - balance) * (values[t] - balance) < 0, then occupancy[i] = values[t]
+ *   recmv_seg3d_expand : list_out = not-yet-evaluated voxels of the 3^3 blocks (clamped to the grid) around the flagged
+ *                        voxels, each exactly once; their bits are set in `done` (:348-372 without unique(dim=0))
+ * ---------------------------------------------------------------------------------------------- */
+int recmv_seg3d_select(const uint8_t* is_boundary, const uint32_t* done_prev, int64_t D, int64_t H, int64_t W,
+                       uint32_t* done, int32_t* list, int64_t capacity, int32_t* count_device, void* stream);
+int recmv_seg3d_points(const int32_t* list, int64_t n, int64_t H, int64_t W, const int32_t* stride_xyz,
+                       const float* res_xyz, const float* extent_xyz, const float* bmin_xyz, float* points,
+                       void* stream);
+int recmv_seg3d_apply(const int32_t* list, const float* values, int64_t n, float balance, float* occupancy,
+                      uint8_t* conflict_flags, int32_t* conflict_count_device, void* stream);
+int recmv_seg3d_expand(const int32_t* list, const uint8_t* conflict_flags, int64_t n, int64_t D, int64_t H, int64_t W,
+                       uint32_t* done, int32_t* list_out, int64_t capacity, int32_t* count_device, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * A/B/D. Dense f32 contractions of the three MLPs (SDF model/network.py:98-111, deformer
  * model/Deformer.py:194-199, colour model/RenderNet.py:83-94) — torch.nn.Linear/cuBLAS sgemm in the
  * reference.  f32 MFMA (v_mfma_f32_32x32x2_f32), exact-f32 accumulate.

@@ -1,17 +1,23 @@
-"""Coarse-to-fine sparse SDF-grid evaluation (MCAcc/seg3d_lossless.py:13-428 of the reference).
+"""Coarse-to-fine sparse SDF-grid evaluation — `Seg3dLossless` of MCAcc/seg3d_lossless.py:13-428 of the reference.
 
-Same class name, constructor signature and mutable public attributes (`query_func`, `balance_value`,
-`b_min`, `b_max`, `resolutions`, `spacing_*`, `b{x,y,z}` — mutated from outside by discretizeSDF,
-OptimGarmentNetwork.py:585-586, and set_hierarchical_config, utils/utils.py:335-347) and the same
-algorithm as `_forward` (:233-428): dense query at the coarsest level; per finer level 2x-1 trilinear
-upsample, boundary = sign disagreement dilated by a 3^3 box, query only unevaluated boundary voxels,
-scatter, then re-query 27-neighbourhoods of sign conflicts until none remain.
+Same class name, constructor signature and mutable public attributes (`query_func`, `balance_value`, `b_min`, `b_max`,
+`resolutions`, `spacing_*`, `b{x,y,z}` — mutated from outside by discretizeSDF, OptimGarmentNetwork.py:585-586, and
+set_hierarchical_config, utils/utils.py:335-347) and the same result as `_forward` (:233-428): dense query at the
+coarsest level; per finer level a 2x-1 trilinear upsample, the voxels within one step of a sign disagreement that have
+not been evaluated yet are queried and written back, and wherever a queried value contradicts the sign of the
+interpolated one the not-yet-evaluated voxels of its 3^3 neighbourhood are queried too, until no contradiction is left.
 
-Differences in HOW: the upsample + boundary mask is the HIP kernel (interp2x_boundary3d) whenever the
-volume lives on the GPU (`use_cuda_impl=True`, the default the recmv pipeline passes; the reference's
-F.interpolate route is kept behind `use_cuda_impl=False`) and the box-filter dilation is a max-pool (exact
-for 0/1 input).
+How it is organised here (not the reference's lists): the SET of evaluated voxels is a volume of the current level.
+  * device route (`use_cuda_impl=True` and a CUDA volume — what the loop uses): one bit per voxel and four kernels per
+    level (csrc/seg3d.hip: select / points / apply / expand) around the HIP upsampler; the host reads one counter per
+    query, nothing else crosses the bus;
+  * volume route (any device, `use_cuda_impl=False`; the CPU port and the tests' cross-check): the same steps as whole-
+    volume torch operations on a boolean volume (dilation = 3^3 max-pool, neighbourhood growth = max-pool of the
+    conflict volume).
+Both query exactly the voxels the reference queries, so the grids are identical up to the network's own arithmetic.
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -24,152 +30,181 @@ class Seg3dLossless(nn.Module):
                  visualize=False, debug=False, use_cuda_impl=False, faster=False, use_shadow=False, **kwargs):
         super().__init__()
         self.query_func = query_func
-        b_min = b_min if torch.is_tensor(b_min) else torch.tensor(b_min)
-        b_max = b_max if torch.is_tensor(b_max) else torch.tensor(b_max)
-        self.register_buffer('b_min', b_min.float().view(1, 1, 3))
-        self.register_buffer('b_max', b_max.float().view(1, 1, 3))
-        if type(resolutions[0]) is int:
-            resolutions = torch.tensor([(res, res, res) for res in resolutions])
-        else:
-            resolutions = torch.tensor(resolutions)
-        self.register_buffer('resolutions', resolutions)
-        tmp = ((self.b_max.view(3) - self.b_min.view(3)) / self.resolutions[-1].to(self.b_max.device).view(3).float())
-        self.spacing_x = tmp[0].item()
-        self.spacing_y = tmp[1].item()
-        self.spacing_z = tmp[2].item()
+        as_row = lambda v: (v if torch.is_tensor(v) else torch.tensor(v)).float().view(1, 1, 3)
+        self.register_buffer('b_min', as_row(b_min))
+        self.register_buffer('b_max', as_row(b_max))
+        res = torch.tensor([(r, r, r) for r in resolutions] if type(resolutions[0]) is int else resolutions)
+        self.register_buffer('resolutions', res)                                   # rows (W, H, D), coarse to fine
+        spacing = (self.b_max.view(3) - self.b_min.view(3)) / self.resolutions[-1].view(3).float()
+        self.spacing_x, self.spacing_y, self.spacing_z = (spacing[i].item() for i in range(3))
+        # marching-cubes origin: centre of the first voxel (seg3d_lossless.py:38-44)
         self.bx = self.b_min.view(-1)[0].item() + self.spacing_x / 2.
         self.by = self.b_min.view(-1)[1].item() + self.spacing_y / 2.
         self.bz = self.b_min.view(-1)[2].item() + self.spacing_z / 2.
-        self.batchsize = self.b_min.size(0)
-        assert self.batchsize == 1
+        self.batchsize, self.channels = 1, channels
         self.balance_value = balance_value
-        self.channels = channels
-        assert self.channels == 1
-        self.align_corners = align_corners
-        assert (align_corners == False)
-        self.visualize = visualize
-        assert visualize == False
-        self.debug = debug
-        self.use_cuda_impl = use_cuda_impl
-        self.faster = faster
-        assert faster == False, "the reference always runs faster=False (model/network.py:304)"
-        self.use_shadow = use_shadow
-        assert use_shadow == False
-        for resolution in resolutions:
-            assert resolution[0] % 2 == 1 and resolution[1] % 2 == 1, \
-                f"resolution {resolution} need to be odd becuase of align_corner."
-        init_coords = create_grid3D(0, resolutions[-1] - 1, steps=resolutions[0], device="cpu")
-        self.register_buffer('init_coords', init_coords.unsqueeze(0).repeat(self.batchsize, 1, 1))
-        calculated = torch.zeros((self.resolutions[-1][2], self.resolutions[-1][1], self.resolutions[-1][0]),
-                                 dtype=torch.bool)
-        self.register_buffer('calculated', calculated)
-        gird8_offsets = torch.stack(torch.meshgrid([torch.tensor([-1, 0, 1]), torch.tensor([-1, 0, 1]),
-                                                    torch.tensor([-1, 0, 1])], indexing="ij")).int().view(3, -1).t()
-        self.register_buffer('gird8_offsets', gird8_offsets)
+        self.align_corners, self.visualize, self.debug = align_corners, visualize, debug
+        self.use_cuda_impl, self.faster, self.use_shadow = use_cuda_impl, faster, use_shadow
+        # the configurations the reference itself never leaves (model/network.py:293-305)
+        assert channels == 1 and not align_corners and not visualize and not faster and not use_shadow, \
+            "Seg3dLossless: only channels=1, align_corners=False, visualize=faster=use_shadow=False are supported"
+        for r in self.resolutions:
+            assert r[0] % 2 == 1 and r[1] % 2 == 1 and r[2] % 2 == 1, f"resolution {r} must be odd (2n-1 nesting)"
+        for a, b in zip(self.resolutions[:-1], self.resolutions[1:]):
+            assert torch.equal(2 * a - 1, b), "every level must be 2n-1 of the previous one"
+        self.register_buffer('init_coords', create_grid3D(0, self.resolutions[-1] - 1, steps=self.resolutions[0],
+                                                          device="cpu").unsqueeze(0))
+        # attributes of the reference's module that outside code may look at (never read on this path)
+        self.register_buffer('calculated', torch.zeros(tuple(int(v) for v in self.resolutions[-1].flip(0)),
+                                                       dtype=torch.bool))
         self.smooth_conv3x3 = SmoothConv3D(in_channels=1, out_channels=1, kernel_size=3)
-        if self.use_cuda_impl:
-            from .interp2x_boundary3d import Interp2xBoundary3d
-            self.upsampler = Interp2xBoundary3d(self.balance_value)
+        # checkpoint key of the reference's module (`engine.gird8_offsets`, sic): the 27 offsets of a 3^3 block
+        self.register_buffer('gird8_offsets', torch.stack(torch.meshgrid([torch.arange(-1, 2)] * 3, indexing="ij"))
+                             .int().view(3, -1).t())
 
-    # ------------------------------------------------------------------------------------------
+    # ------------------------------------------------------------------------------------------ queries
     def batch_eval(self, coords, **kwargs):
-        """coords: integer voxel coordinates of the FINAL resolution -> world points -> query_func
+        """Integer voxel coordinates of the FINAL resolution [1,N,3] -> world points -> query_func -> [1,C,N]
         (seg3d_lossless.py:89-108)."""
-        coords = coords.detach()
         step = 1.0 / self.resolutions[-1].float()
-        coords2D = coords.float() / self.resolutions[-1] + step / 2
-        coords2D = coords2D * (self.b_max - self.b_min) + self.b_min
-        occupancys = self.query_func(**kwargs, points=coords2D)
-        if type(occupancys) is list:
-            occupancys = torch.stack(occupancys)
-        assert len(occupancys.size()) == 3, "query_func should return a occupancy with shape of [bz, C, N]"
-        return occupancys
+        pts = coords.detach().float() / self.resolutions[-1] + step / 2
+        pts = pts * (self.b_max - self.b_min) + self.b_min
+        return self._query(pts, **kwargs)
+
+    def _query(self, pts, **kwargs):
+        out = self.query_func(**kwargs, points=pts)
+        if type(out) is list:
+            out = torch.stack(out)
+        assert out.dim() == 3, "query_func should return a occupancy with shape of [bz, C, N]"
+        return out
 
     def forward(self, **kwargs):
         return self._forward(**kwargs)
 
-    def _upsample(self, occupancys, D, H, W):
-        if self.use_cuda_impl and occupancys.is_cuda:
-            self.upsampler.balance_value = self.balance_value
-            return self.upsampler(occupancys.contiguous())
-        with torch.no_grad():
-            valid = F.interpolate((occupancys > self.balance_value).float(), size=(D, H, W), mode="trilinear",
-                                  align_corners=True)
-        occupancys = F.interpolate(occupancys.float(), size=(D, H, W), mode="trilinear", align_corners=True)
-        return occupancys, (valid > 0.0) & (valid < 1.0)
-
     def _forward(self, **kwargs):
-        calculated = self.calculated.clone()
-        occupancys = None
-        # The reference carries the already-evaluated voxels as a coordinate list (`coords_accum`) that it doubles per
-        # level and de-duplicates with `unique(dim=1)` — a lexicographic sort of up to 10^5-10^6 rows, twice per level.
-        # The same SET is kept here as a boolean volume of the current level (`done`): doubling = writing it to the
-        # even lattice of the next level, union = a scatter of True.  Same voxels are queried, no sort.
-        done = None
-        for resolution in self.resolutions:
-            W, H, D = [int(v) for v in resolution]
-            stride = (self.resolutions[-1] - 1) // (resolution - 1)
-            if torch.equal(resolution, self.resolutions[0]):
-                coords = self.init_coords.clone()
-                occupancys = self.batch_eval(coords, **kwargs).view(self.batchsize, self.channels, D, H, W)
-                with torch.no_grad():
-                    done = torch.ones((D, H, W), dtype=torch.bool, device=occupancys.device)   # every level-0 voxel
-                    calculated[coords[0, :, 2], coords[0, :, 1], coords[0, :, 0]] = True
-                continue
+        W0, H0, D0 = (int(v) for v in self.resolutions[0])
+        occ = self.batch_eval(self.init_coords.clone(), **kwargs).view(1, 1, D0, H0, W0)
+        if self.use_cuda_impl and occ.is_cuda:
+            return self._forward_device(occ, **kwargs)
+        return self._forward_volume(occ, **kwargs)
 
+    # ------------------------------------------------------------------------------------------ volume route
+    def _forward_volume(self, occ, **kwargs):
+        bv = self.balance_value
+        final = self.resolutions[-1]
+        done = torch.ones(occ.shape[2:], dtype=torch.bool, device=occ.device)          # level 0: every voxel evaluated
+        for res in self.resolutions[1:]:
+            W, H, D = (int(v) for v in res)
+            stride = ((final - 1) // (res - 1)).to(occ.device)
             with torch.no_grad():
-                done_prev = done
-                done = torch.zeros((D, H, W), dtype=torch.bool, device=occupancys.device)
-                done[::2, ::2, ::2] = done_prev                                        # coords_accum * 2 (:271)
-            occupancys, is_boundary = self._upsample(occupancys, D, H, W)
+                sign = F.interpolate((occ > bv).float(), size=(D, H, W), mode="trilinear", align_corners=True)
+                parent, done = done, torch.zeros((D, H, W), dtype=torch.bool, device=occ.device)
+                done[::2, ::2, ::2] = parent
+            occ = F.interpolate(occ.float(), size=(D, H, W), mode="trilinear", align_corners=True)
             with torch.no_grad():
-                # 3^3 box filter > 0  ==  3^3 max-pool of the 0/1 mask (seg3d_lossless.py:296)
-                is_boundary = (F.max_pool3d(is_boundary.float(), 3, 1, 1) > 0)[0, 0]
-                is_boundary &= ~done                                                    # minus already computed (:299-301)
-                point_coords = is_boundary.permute(2, 1, 0).nonzero(as_tuple=False).unsqueeze(0)
-                point_indices = (point_coords[:, :, 2] * H * W + point_coords[:, :, 1] * W + point_coords[:, :, 0])
-                R, C, D, H, W = occupancys.shape
-                occupancys_interp = torch.gather(occupancys.reshape(R, C, D * H * W), 2, point_indices.unsqueeze(1))
-                coords = point_coords * stride
-            if coords.size(1) == 0:
-                continue
-            occupancys_topk = self.batch_eval(coords, **kwargs)
-            R, C, D, H, W = occupancys.shape
-            occupancys = (occupancys.reshape(R, C, D * H * W)
-                          .scatter_(2, point_indices.unsqueeze(1).expand(-1, C, -1), occupancys_topk)
-                          .view(R, C, D, H, W))
-            with torch.no_grad():
-                conflicts = ((occupancys_interp - self.balance_value) * (occupancys_topk - self.balance_value) < 0)[0, 0]
-                done.view(-1)[point_indices[0]] = True                                  # union with the new voxels
-                calculated[coords[0, :, 2], coords[0, :, 1], coords[0, :, 0]] = True
-
-            while conflicts.sum() > 0:
+                disagree = ((sign > 0.0) & (sign < 1.0)).float()
+                todo = (F.max_pool3d(disagree, 3, 1, 1)[0, 0] > 0) & ~done               # box filter > 0 == dilation
+            flat = occ.view(-1)
+            while True:
                 with torch.no_grad():
-                    conflicts_coords = coords[0, conflicts, :]
-                    conflicts_boundary = (conflicts_coords.int() + self.gird8_offsets.unsqueeze(1) * stride.int()
-                                          ).reshape(-1, 3).long().unique(dim=0)
-                    conflicts_boundary[:, 0] = conflicts_boundary[:, 0].clamp(0, calculated.size(2) - 1)
-                    conflicts_boundary[:, 1] = conflicts_boundary[:, 1].clamp(0, calculated.size(1) - 1)
-                    conflicts_boundary[:, 2] = conflicts_boundary[:, 2].clamp(0, calculated.size(0) - 1)
-                    coords = conflicts_boundary[calculated[conflicts_boundary[:, 2], conflicts_boundary[:, 1],
-                                                           conflicts_boundary[:, 0]] == False]
-                    coords = coords.unsqueeze(0)
-                    point_coords = coords // stride
-                    point_indices = (point_coords[:, :, 2] * H * W + point_coords[:, :, 1] * W + point_coords[:, :, 0])
-                    R, C, D, H, W = occupancys.shape
-                    occupancys_interp = torch.gather(occupancys.reshape(R, C, D * H * W), 2,
-                                                     point_indices.unsqueeze(1))
-                    coords = point_coords * stride
-                if coords.size(1) == 0:
+                    idx = todo.view(-1).nonzero(as_tuple=True)[0]
+                if idx.numel() == 0:
                     break
-                occupancys_topk = self.batch_eval(coords, **kwargs)
                 with torch.no_grad():
-                    conflicts = ((occupancys_interp - self.balance_value) *
-                                 (occupancys_topk - self.balance_value) < 0)[0, 0]
-                occupancys = (occupancys.reshape(R, C, D * H * W)
-                              .scatter_(2, point_indices.unsqueeze(1).expand(-1, C, -1), occupancys_topk)
-                              .view(R, C, D, H, W))
+                    xyz = torch.stack([idx % W, (idx // W) % H, idx // (W * H)], dim=-1) * stride
+                    guess = flat[idx]
+                values = self.batch_eval(xyz.unsqueeze(0), **kwargs).view(-1)
+                flat[idx] = values
                 with torch.no_grad():
-                    done.view(-1)[point_indices[0]] = True
-                    calculated[coords[0, :, 2], coords[0, :, 1], coords[0, :, 0]] = True
-        return occupancys
+                    done.view(-1)[idx] = True
+                    wrong = torch.zeros_like(done)
+                    wrong.view(-1)[idx] = (guess - bv) * (values - bv) < 0
+                    # the 3^3 block around every contradiction (clamping at the faces == zero-padded max-pool)
+                    todo = (F.max_pool3d(wrong[None, None].float(), 3, 1, 1)[0, 0] > 0) & ~done
+        return occ
+
+    # ------------------------------------------------------------------------------------------ device route
+    def forward_multi(self, query_funcs, **kwargs):
+        """The pyramids of SEVERAL fields over the same box and resolutions, level by level in lockstep (the re-mesh
+        extracts the body and every garment, OptimGarmentNetwork.py:593-617): one counter read-back per step serves all
+        fields, and the small launches of the coarse levels of one field overlap the others'.  Returns one volume per
+        query function; each equals what `forward()` gives with that function."""
+        W0, H0, D0 = (int(v) for v in self.resolutions[0])
+        keep = self.query_func
+        try:
+            occs = []
+            for q in query_funcs:
+                self.query_func = q
+                occs.append(self.batch_eval(self.init_coords.clone(), **kwargs).view(1, 1, D0, H0, W0))
+            if self.use_cuda_impl and occs[0].is_cuda:
+                return self._forward_device(occs, query_funcs, **kwargs)
+            out = []
+            for q, occ in zip(query_funcs, occs):
+                self.query_func = q
+                out.append(self._forward_volume(occ, **kwargs))
+            return out
+        finally:
+            self.query_func = keep
+
+    def _forward_device(self, occs, query_funcs=None, **kwargs):
+        from .. import _lib as L
+        from .. import interp2x_boundary3d
+        single = not isinstance(occs, (list, tuple))
+        if single:
+            occs, query_funcs = [occs], [self.query_func]
+        K = len(occs)
+        lib, dev = L.lib(), occs[0].device
+        bv = float(self.balance_value)
+        final = [int(v) for v in self.resolutions[-1]]
+        res_f = (C.c_float * 3)(*[float(v) for v in final])
+        extent = (C.c_float * 3)(*(self.b_max - self.b_min).view(-1).tolist())
+        origin = (C.c_float * 3)(*self.b_min.view(-1).tolist())
+        counters = torch.zeros((K, 2), dtype=torch.int32, device=dev)          # per field: [list length, conflicts]
+        host = torch.zeros((K, 2), dtype=torch.int32).pin_memory()
+        words = lambda n: (n + 31) // 32 + 1
+
+        def list_lengths():
+            host.copy_(counters, non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+            return [int(host[k, 0]) for k in range(K)]
+
+        D, H, W = occs[0].shape[2:]
+        done = [torch.full((words(D * H * W),), -1, dtype=torch.int32, device=dev) for _ in range(K)]   # level 0: all
+        keep = self.query_func
+        try:
+            with torch.cuda.device(dev):
+                st = lambda: L.stream_ptr(dev)
+                for res in self.resolutions[1:]:
+                    W, H, D = (int(v) for v in res)
+                    n_vox = D * H * W
+                    stride = (C.c_int32 * 3)(*[(f - 1) // (r - 1) for f, r in zip(final, (W, H, D))])
+                    todo = [None] * K
+                    for k in range(K):
+                        occs[k], boundary = interp2x_boundary3d.forward(occs[k].contiguous(), bv)
+                        parent, done[k] = done[k], torch.empty(words(n_vox), dtype=torch.int32, device=dev)
+                        todo[k] = torch.empty(n_vox, dtype=torch.int32, device=dev)
+                        L.check(lib.recmv_seg3d_select(L.ptr(boundary), L.ptr(parent), D, H, W, L.ptr(done[k]),
+                                                       L.ptr(todo[k]), n_vox, L.ptr(counters[k]), st()), "seg3d_select")
+                    n = list_lengths()
+                    while any(n):
+                        for k in range(K):
+                            if n[k] == 0:
+                                continue
+                            pts = torch.empty((1, n[k], 3), dtype=torch.float32, device=dev)
+                            L.check(lib.recmv_seg3d_points(L.ptr(todo[k]), n[k], H, W, stride, res_f, extent, origin,
+                                                           L.ptr(pts), st()), "seg3d_points")
+                            self.query_func = query_funcs[k]
+                            values = self._query(pts, **kwargs).reshape(-1).contiguous().float()
+                            flags = torch.empty(n[k], dtype=torch.uint8, device=dev)
+                            grown = torch.empty(min(27 * n[k], n_vox), dtype=torch.int32, device=dev)
+                            L.check(lib.recmv_seg3d_apply(L.ptr(todo[k]), L.ptr(values), n[k], bv, L.ptr(occs[k]),
+                                                          L.ptr(flags), L.ptr(counters[k, 1:]), st()), "seg3d_apply")
+                            # grown unconditionally (no contradiction -> empty list): one read-back answers both questions
+                            L.check(lib.recmv_seg3d_expand(L.ptr(todo[k]), L.ptr(flags), n[k], D, H, W, L.ptr(done[k]),
+                                                           L.ptr(grown), grown.numel(), L.ptr(counters[k]), st()),
+                                    "seg3d_expand")
+                            todo[k] = grown
+                        n = list_lengths()              # a field that had nothing to query left a 0 in its counter
+        finally:
+            self.query_func = keep
+        return occs[0] if single else occs

@@ -76,6 +76,10 @@ def _declare(lib):
         "recmv_mc_count": (C.c_int, [vp, i64, i64, i64, f32, vp, i64, vp, vp]),
         "recmv_mc_emit": (C.c_int, [vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, f32, vp, i64, i64, vp, i64, vp, i64,
                                     vp]),
+        "recmv_seg3d_select": (C.c_int, [vp, vp, i64, i64, i64, vp, vp, i64, vp, vp]),
+        "recmv_seg3d_points": (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]),
+        "recmv_seg3d_apply": (C.c_int, [vp, vp, i64, f32, vp, vp, vp, vp]),
+        "recmv_seg3d_expand": (C.c_int, [vp, vp, i64, i64, i64, i64, vp, vp, i64, vp, vp]),
         "recmv_mc_run": (C.c_int, [vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, f32, vp, i64, vp, i64, vp, i64, vp,
                                    vp]),
         "recmv_gemm_nt": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, f32, f32, vp]),

@@ -161,6 +161,21 @@ class SyntheticFrames:
         sl = frame_ids % self.n_img
         return self.img[sl], self.normal[sl]
 
+    def get_batch(self, frame_ids, garment_names=('upper', 'bottom')):
+        """The `datas` dict of one mini-batch as the reference's DataLoader collates it (dataset/dataset.py:617-680;
+        read by OptimGarmentNetwork.forward :1888-1904): img / normal [N,H,W,3], mask and one segmentation per garment
+        [N,H,W], fl_pts [N, n_curves*M, 2] and fl_masks [N, n_curves] when feature lines exist."""
+        img, normal = self.images(frame_ids)
+        out = {'img': img, 'normal': normal, 'frame_ids': frame_ids}
+        masks = [self.garment_masks(g, frame_ids) for g in range(len(self._masks))]
+        for name, m in zip(garment_names, masks):
+            out[name] = m > 0
+        out['mask'] = torch.stack(masks, 0).amax(0)
+        if hasattr(self, 'gt_fl_pts'):
+            slot = frame_ids % self.n_img
+            out['fl_pts'], out['fl_masks'] = self.gt_fl_pts[slot], self.fl_masks[slot]
+        return out
+
     def set_garment_silhouettes(self, radii, seed=0):
         """Synthetic ground-truth segmentation: garment g of image slot k is a slightly elliptical disc — the outline
         of a sphere of radius radii[g] seen by this camera, jittered by a few pixels per slot — so that the IoU term of
@@ -201,7 +216,8 @@ class HotLoop:
     """The per-frame optimisation inner loop (see module docstring)."""
 
     def __init__(self, conf, device, n_frames=64, H=512, W=512, stage='coarse', seed=0, resolutions=None,
-                 skin_grid=(65, 225, 129), bbox=None, world_size=1, rank=0, curves=False):
+                 skin_grid=(65, 225, 129), bbox=None, world_size=1, rank=0, curves=False, large_pose=False,
+                 dataset=None):
         self.conf_all = conf
         self.conf = conf.get_config('loss_' + stage)
         self.device = device
@@ -243,10 +259,18 @@ class HotLoop:
         self.deformer = CompositeDeformer([getTranslatorNet(device, conf.get_config('mlp_deformer')),
                                            skinner.to(device)])
         self.netRender = getRenderNet(device, conf.get_config('render_net'))
-        self.dataset = SyntheticFrames(n_frames, self.garment_size, H, W, device, seed=seed + 2,
-                                       condlen=conf.get_int('mlp_deformer.condlen'),
-                                       rendlen=conf.get_int('render_net.condlen'))
-        self.dataset.set_garment_silhouettes([_zero_level_radius(n, device) for n in self.garment_nets], seed=seed + 3)
+        if dataset is None:
+            dataset = SyntheticFrames(n_frames, self.garment_size, H, W, device, seed=seed + 2,
+                                      condlen=conf.get_int('mlp_deformer.condlen'),
+                                      rendlen=conf.get_int('render_net.condlen'))
+            dataset.set_garment_silhouettes([_zero_level_radius(n, device) for n in self.garment_nets], seed=seed + 3)
+        self.dataset = dataset                     # getOptNet hands over the caller's dataset (model/network.py:352)
+        self._datas = None                         # the mini-batch dict of forward(datas, ...), when a caller passes one
+        # large-pose fitting (OptimGarmentNetwork_Large_Pose.py:122-137): the surfaces are frozen, only the deformation,
+        # the per-frame tensors, the colour net and the camera move
+        self.large_pose = bool(large_pose)
+        if self.large_pose:
+            self.freeze_sdf()
         res = resolutions if resolutions is not None else RESOLUTIONS[stage]
         self.engine = Seg3dLossless(query_func=None, b_min=list(bmin), b_max=list(bmax), resolutions=res,
                                     align_corners=False, balance_value=0.0, use_cuda_impl=True, faster=False).to(device)
@@ -267,10 +291,7 @@ class HotLoop:
         self.curves = bool(curves)
         if self.curves:
             self._init_curves(seed + 4)
-        params = [p for p in self.netRender.parameters()] + [p for p in self.deformer.parameters()] + \
-                 [p for p in self.garment_nets.parameters()]
-        self.optimizer = torch.optim.Adam(self.dataset.learnable_weights() + params,
-                                          lr=conf.get_float('train.learning_rate'))
+        self.optimizer = self.rebuild_optimizer()
         cams = self._cameras()
         self.angThred = cams.angThreshold(0.5)                                   # OptimNetwork.py:65
 
@@ -300,6 +321,32 @@ class HotLoop:
             self.remesh_intersect = self.next_train_conf.get_int('point_render.remesh_intersect')
             self.sdfShrinkRadius = 0.0
             self.next_conf = self.next_train_conf = None
+
+    def freeze_sdf(self):
+        """OptimGarmentNetwork_LargePose.freeze_sdf (:130-137): when fitting large poses the surfaces are not optimised."""
+        for net in list(self.garment_nets) + [self.sdf]:
+            for para in net.parameters():
+                para.requires_grad = False
+
+    # -- ground truth of the mini-batch: the `datas` dict of forward(datas, ...) when given, else the synthetic frames
+    def _gt_images(self, frame_ids):
+        d = self._datas
+        if d is not None:
+            return d['img'].to(self.device), (d['normal'].to(self.device) if 'normal' in d else None)
+        return self.dataset.images(frame_ids)
+
+    def _gt_garment_mask(self, g_i, frame_ids):
+        d = self._datas
+        if d is not None:
+            return d[self.garment_names[g_i]].to(self.device).float()                 # datas['upper'] / ['bottom'] :1896
+        return self.dataset.garment_masks(g_i, frame_ids)
+
+    def _gt_feature_lines(self, frame_ids):
+        d = self._datas
+        if d is not None:
+            return d['fl_pts'].to(self.device), d['fl_masks'].to(self.device)            # :1891-1892
+        slot = frame_ids % self.dataset.n_img
+        return self.dataset.gt_fl_pts[slot], self.dataset.fl_masks[slot]
 
     def _modules(self):
         mods = {'sdf': self.sdf, 'garment_nets': self.garment_nets, 'deformer': self.deformer,
@@ -376,20 +423,21 @@ class HotLoop:
         """OptimGarmentNetwork.py:581-618."""
         engine = engine or self.engine
 
-        def run(net):
+        def query_of(net):
             def query(points):
                 with torch.no_grad():
                     # only the SDF value is read here: skip the 256 render-feature rows of the last layer
                     return net.forward(points.reshape(-1, 3), ratio, features=False).reshape(1, 1, -1)
-            engine.balance_value = balance_value
-            engine.query_func = query
-            sdfs = engine.forward()
-            return MCGpu.mc_gpu(sdfs[0, 0].permute(2, 1, 0).contiguous(), engine.spacing_x, engine.spacing_y,
-                                engine.spacing_z, engine.bx, engine.by, engine.bz, balance_value)
+            return query
 
+        nets = [self.sdf] + list(self.garment_nets)
+        engine.balance_value = balance_value
+        # the body's and the garments' pyramids run level by level in lockstep (Seg3dLossless.forward_multi)
+        volumes = engine.forward_multi([query_of(net) for net in nets])
         pts, faces = [], []
-        for net in [self.sdf] + list(self.garment_nets):
-            v, f = run(net)
+        for sdfs in volumes:
+            v, f = MCGpu.mc_gpu(sdfs[0, 0].permute(2, 1, 0).contiguous(), engine.spacing_x, engine.spacing_y,
+                                engine.spacing_z, engine.bx, engine.by, engine.bz, balance_value)
             pts.append(v)
             faces.append(f)
         return pts, faces
@@ -560,11 +608,10 @@ class HotLoop:
         self._shared_def_vs = self._deform_garments(N, frame_ids, ratio)
         curves_now = self.inter_free_curve()                                             # [L,S,3]
         fl_vs_dict = {n: curves_now[i] for i, n in enumerate(self.fl_names)}
-        slot = frame_ids % self.dataset.n_img
-        gt_all = self.dataset.gt_fl_pts[slot]                                            # [N, L*M, 2]
+        gt_all, fl_mask_all = self._gt_feature_lines(frame_ids)                          # [N, L*M, 2], [N, L]
         M = gt_all.shape[1] // len(self.fl_names)
         gt_dict = {n: gt_all[:, i * M:(i + 1) * M] for i, n in enumerate(self.fl_names)}
-        mask_dict = {n: self.dataset.fl_masks[slot][:, i:i + 1] for i, n in enumerate(self.fl_names)}
+        mask_dict = {n: fl_mask_all[:, i:i + 1] for i, n in enumerate(self.fl_names)}
         project_loss, sdf_loss = 0., 0.
         self.info['fl_loss'] = {}
         for g_i, name in enumerate(self.garment_names):
@@ -588,7 +635,10 @@ class HotLoop:
             self.info['fl_loss']['pc_{}_loss_sdf'.format(name)] = s_loss.detach()
             sdf_loss = sdf_loss + s_loss * (conf.get_float('fl_weight.sdf_weight') if 'fl_weight' in conf else 60.)
         self.fl_optimizer.zero_grad()
-        loss = 10. * sdf_loss + 1. * project_loss                                         # :1865
+        if self.large_pose:
+            loss = 0. * sdf_loss + 0. * project_loss           # OptimGarmentNetwork_Large_Pose.py:219: zero-weighted
+        else:
+            loss = 10. * sdf_loss + 1. * project_loss                                     # :1865
         loss.backward()
         if getattr(self, '_allreduce', None) is not None:
             self._allreduce(list(self.inter_free_curve.parameters()))     # curve gradients are shared across ranks (§8e)
@@ -630,7 +680,7 @@ class HotLoop:
         rpx = int(np.round(self.pc_radius / 2. * float(min(H, W)) / 1.2))                  # :940-941
         garment_loss = 0.
         for g_i, name in enumerate(self.garment_names):
-            gt = self.dataset.garment_masks(g_i, frame_ids)
+            gt = self._gt_garment_mask(g_i, frame_ids)
             if rpx > 0:                                                                   # :947
                 gt = F.max_pool2d(gt, kernel_size=2 * rpx + 1, stride=1, padding=rpx)
             garment_loss = garment_loss + self.compute_garment_pc_loss(
@@ -720,7 +770,7 @@ class HotLoop:
         with ctx, torch.no_grad():
             found = self.find_surface_ps(def_vs, tmp_vs, cameras)
             for g_i, (batch_inds, row_inds, col_inds, init_pts, _faces) in enumerate(found):
-                gt = self.dataset.garment_masks(g_i, frame_ids)                         # :1013-1018
+                gt = self._gt_garment_mask(g_i, frame_ids)                              # :1013-1018
                 keep = (gt[batch_inds, row_inds, col_inds] > 0.).nonzero(as_tuple=True)[0]
                 batch_inds, row_inds, col_inds, init_pts = (t[keep] for t in (batch_inds, row_inds, col_inds,
                                                                               init_pts))
@@ -758,7 +808,7 @@ class HotLoop:
     # ------------------------------------------------------------------------------------------ render loss
     def surface_render_loss(self, N, cameras, frame_ids, ratio, checks, init_ps_list, samples):
         conf = self.conf
-        gtCs, gtNs = self.dataset.images(frame_ids)
+        gtCs, gtNs = self._gt_images(frame_ids)
         self.TmpPs = [None] * self.garment_size
         self.rays = [None] * self.garment_size
         self.batch_inds = [None] * self.garment_size
@@ -820,7 +870,7 @@ class HotLoop:
                     color_loss = utils.scatter_mean(color_loss, b, N).mean()
                     self.info['{}_color_loss'.format(name)] = color_loss.detach()
                     total_loss = total_loss + conf.get_float('color_weight') * color_loss
-                if 'normal_weight' in conf and conf.get_float('normal_weight') > 0.:        # :1191-1217
+                if 'normal_weight' in conf and conf.get_float('normal_weight') > 0. and gtNs is not None:  # :1191-1217
                     if 'weighted_normal' in conf and conf.get_bool('weighted_normal'):
                         cnx, _ = utils.compute_deformed_normals(net, self.deformer, p, defconds, b, ratio, 'test',
                                                                 offset_type=name)
@@ -860,7 +910,9 @@ class HotLoop:
         return dct_loss * self.conf.get_float('dct_weight')
 
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, frame_ids, ratio):
+    def forward(self, frame_ids, ratio, global_optimizer=None):
+        """OptimGarmentNetwork.forward (:1885-1969) on the frames `frame_ids`; `global_optimizer` is the caller's Adam
+        whose gradients are cleared after the curve branch (:1934; train.py passes it as a keyword, :324)."""
         N = frame_ids.numel()
         self.info = {}
         self._def_cache, self._frag_cache = None, {}      # per-iteration caches (shared deformation / fragments)
@@ -872,7 +924,7 @@ class HotLoop:
         if self.curves:
             with self._phase('curves'):
                 self.project_2d_loss(N, frame_ids, ratio, cameras)                           # :1932
-        self.optimizer.zero_grad()                                                         # :1934
+        (global_optimizer if global_optimizer is not None else self.optimizer).zero_grad()  # :1934
         with self._phase('mask_loss'):
             def_vs, pc_sdf_loss = self.mask_loss(N, frame_ids, ratio, cameras)
         total_loss = total_loss + pc_sdf_loss
@@ -932,9 +984,10 @@ class HotLoop:
             # non-leaf targets (per-frame codes gathered by frame id, rays, camera centre) get one backward call.
             targets, grads = [], []
             params = [q for q in net.parameters() if q.requires_grad]
-            pg = torch.autograd.grad(net(p, ratio), params, -rhs_1[:, :, 0])
-            targets += params
-            grads += list(pg)
+            if params:                     # frozen in the large-pose stage (OptimGarmentNetwork_Large_Pose.py:440-452)
+                pg = torch.autograd.grad(net(p, ratio), params, -rhs_1[:, :, 0])
+                targets += params
+                grads += list(pg)
             params = [q for q in self.deformer.parameters() if q.requires_grad]
             d = self.deformer(p, defconds, self.batch_inds[g_i], ratio=ratio, offset_type=name)
             temp = -(rhs_1[:, :, -3:].transpose(1, 2) * v_cross).sum(1)                      # rhs[1:4] @ (-[v]_x)
@@ -981,8 +1034,8 @@ class HotLoop:
 
     def rebuild_optimizer(self, lr=None):
         """New Adam over the dataset's learnable tensors and the networks (train.py:213, :229-231 after a resume)."""
-        params = [p for p in self.netRender.parameters()] + [p for p in self.deformer.parameters()] + \
-                 [p for p in self.garment_nets.parameters()]
+        params = [p for m in (self.netRender, self.deformer, self.garment_nets) for p in m.parameters()
+                  if p.requires_grad]                                  # train.py:213: `if p.requires_grad`
         lr = self.conf_all.get_float('train.learning_rate') if lr is None else lr
         self.optimizer = torch.optim.Adam(self.dataset.learnable_weights() + params, lr=lr)
         return self.optimizer
@@ -993,7 +1046,7 @@ class HotLoop:
         frame_ids = self.frame_batch(it) if frame_ids is None else frame_ids
         ratio = {'sdfRatio': 1., 'deformerRatio': self.opt_times / 2500. + 0.5, 'renderRatio': 1.}
         self._allreduce = allreduce
-        loss = self.forward(frame_ids, ratio)
+        loss = HotLoop.forward(self, frame_ids, ratio)      # (the facade subclass overrides forward(datas, ...))
         with self._phase('backward'):
             loss.backward()
         with self._phase('propagate'):
@@ -1004,6 +1057,29 @@ class HotLoop:
             self.optimizer.step()
         self.opt_times += 1.
         return loss.detach(), self.info['rays_total']
+
+
+class FrameLoader:
+    """Stands in for the reference's `DataLoader(dataset, batch_size, sampler=RandomSampler(dataset, 1, shuffle))`
+    (dataset/dataset.py:1135-1183) in `for data_index, (frame_ids, outs) in enumerate(dataloader)` (train.py:317): per
+    epoch a seeded permutation of the frames in mini-batches of the current stage's batch size (the short last batch
+    kept), dealt round-robin over the frame-sharded ranks; `outs` is the mini-batch dict (`dataset.get_batch`)."""
+
+    def __init__(self, loop, epoch=0):
+        self.loop, self.epoch = loop, epoch
+        self.dataset = loop.dataset
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+        return self
+
+    def __len__(self):
+        return self.loop.iters_per_epoch()
+
+    def __iter__(self):
+        for pos in range(len(self)):
+            frame_ids = self.loop.frame_batch_at(self.epoch, pos)
+            yield frame_ids, self.dataset.get_batch(frame_ids, self.loop.garment_names)
 
 
 def fan_mesh(curve_pts):

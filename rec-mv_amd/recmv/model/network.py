@@ -232,3 +232,29 @@ def getTmpSdf(device, multires, bias=0.6, feature_vector_size=256):
                           dims=[512, 512, 512, 512, 512, 512, 512, 512], geometric_init=True, bias=bias,
                           skip_in=[4], weight_norm=True, multires=multires)
     return net.to(device)
+
+
+def getOptNet(dataset, save_folder, N, bmins, bmaxs, resolutions, device, conf, use_initial_sdf=True,
+              use_initial_skinner=True, visualizer=None, opt_large=False, **hotloop_kwargs):
+    """model/network.py:182-361 of the reference: build the optimisation object train.py drives — body SDF + one SDF per
+    garment (:188-199), offset MLP + skinner (:223-283), cameras, the Seg3dLossless engine (:293-305), the silhouette /
+    point renderers, the colour net (:323) — and return `(optNet, sdf_initialized)`.
+
+    `dataset` is the caller's dataset object (per-frame learnable tensors + camera: `get_grad_parameters`,
+    `get_camera_parameters`, `learnable_weights`, `get_batchframe_data`, `poses`, `trans`, `conds`, `camera_params`,
+    `frame_num`); `None` builds the synthetic frames.  `bmins` / `bmaxs` the canonical box, `resolutions` the pyramid of
+    the current stage (rows (W,H,D)), `N` the batch size (kept for signature compatibility: the stage config sets it).
+    `sdf_initialized` is -1: the networks start from the geometric initialisation (the reference returns the number of
+    IGR pre-fit epochs still to run, :203-221 — a start-up step outside this package's scope).
+    `opt_large=True` returns the large-pose variant (OptimGarmentNetwork_LargePose, :337-340)."""
+    from ..engineer.networks import OptimGarmentNetwork, OptimGarmentNetwork_LargePose
+    cls = OptimGarmentNetwork_LargePose if opt_large else OptimGarmentNetwork
+    bbox = None if bmins is None else (tuple(float(v) for v in bmins), tuple(float(v) for v in bmaxs))
+    kw = dict(resolutions=[tuple(int(v) for v in r) for r in resolutions] if resolutions is not None else None, bbox=bbox,
+              dataset=dataset)
+    if dataset is not None:
+        kw.update(n_frames=int(getattr(dataset, 'frame_num', len(dataset))), H=int(dataset.H), W=int(dataset.W))
+    kw.update(hotloop_kwargs)
+    optNet = cls(conf, device, **kw)
+    optNet.visualizer = visualizer
+    return optNet, -1

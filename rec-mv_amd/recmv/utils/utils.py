@@ -16,7 +16,7 @@ from torch.autograd import Function
 
 from ..FastMinv import Fast3x3Minv, Fast3x3Minv_backward
 
-__all__ = ["save_model", "load_model", "FastDiff3x3MinvFunction", "quat2mat", "annealing_weights", "GMRobustError", "sample_points",
+__all__ = ["save_model", "load_model", "set_hierarchical_config", "FastDiff3x3MinvFunction", "quat2mat", "annealing_weights", "GMRobustError", "sample_points",
            "compute_Jacobian", "batch_compute_Jacobian", "compute_deformed_normals", "compute_cardinal_rays",
            "compute_netRender_color", "scatter_mean"]
 
@@ -160,6 +160,15 @@ def scatter_mean(src, index, dim_size):
     out = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, src)
     cnt = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, torch.ones_like(src))
     return out / cnt.clamp(min=1)
+
+
+def set_hierarchical_config(conf, name, optNet, dataloader, resolutions):
+    """utils/utils.py:330-348 of the reference: switch `optNet` to stage `name` ('coarse' | 'medium' | 'fine') — new
+    batch size and Seg3dLossless pyramid at once, loss weights / point radius / re-mesh period parked until the next
+    re-mesh (`next_conf`, `next_train_conf`) — and return `(optNet, dataloader)`.  The frame loader reads the batch size
+    from `optNet`, so the same loader comes back (the reference rebuilds its DataLoader for the new batch size)."""
+    optNet.set_stage(name, [tuple(int(v) for v in r) for r in resolutions] if resolutions is not None else None)
+    return optNet, dataloader
 
 
 def save_model(name, epoch, optNet, dataset):

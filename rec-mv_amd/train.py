@@ -1,11 +1,20 @@
 """train.py — the reference's training driver (train.py:21-356) on the MI355X hot loop.
 
 Same command line (`--gpu-ids --conf --data --model-rm-prefix --sdf-model --save-folder --project_name --exp_name
---data_type --a_pose --curve_sampling --resume`), same HOCON schema, same schedule: coarse -> medium -> fine stages
-switched at `train.<stage>.start_epoch` (Seg3dLossless pyramid, batch size, re-mesh period, loss weights), Adam +
-MultiStepLR, `coarse.pth` / `medium.pth` at the stage switches and `latest.pth` every epoch in the reference's
-checkpoint layout (recmv.utils.save_model / load_model), resume with the scheduler fast-forwarded and `opt_times`
-recomputed (train.py:232-260).
+--data_type --a_pose --curve_sampling --resume`), same HOCON schema, same entry points and the same loop body:
+
+    optNet, sdf_initialized = getOptNet(dataset, save_folder, batch_size, bmins, bmaxs, resolutions['coarse'], device, config)
+    optNet, dataloader = utils.set_hierarchical_config(config, 'coarse', optNet, dataloader, resolutions['coarse'])
+    ...
+    loss = optNet(outs, sample_pix_num, ratio, frame_ids, debug_root, global_optimizer=optimizer)
+    loss.backward()
+    optNet.propagateTmpPsGrad(frame_ids, ratio)
+    optimizer.step()
+
+coarse -> medium -> fine stages switched at `train.<stage>.start_epoch`, Adam + MultiStepLR, `coarse.pth` / `medium.pth`
+at the stage switches and `latest.pth` every epoch in the reference's checkpoint layout (recmv.utils.save_model /
+load_model), resume with the scheduler fast-forwarded and `opt_times` recomputed (train.py:232-260).
+`train_large_pose.py` is the same driver on the large-pose variant (SDF nets frozen, resume from `a-pose.pth`).
 
 What differs: the dataset loaders, the SDF / feature-curve initialisers and wandb are outside this tier,
 so the frames are synthetic (`recmv.loop.SyntheticFrames`; `--frames` sets their number) and `--data` is only the
@@ -16,7 +25,6 @@ ranks and the shared gradients all-reduced with RCCL (recmv.dist); `--gpu-ids` p
 from __future__ import annotations
 
 import argparse
-import math
 import os
 import os.path as osp
 import sys
@@ -25,7 +33,7 @@ import time
 sys.path.insert(0, osp.dirname(osp.abspath(__file__)))
 
 
-def build_parser():
+def build_parser(large_pose=False):
     parser = argparse.ArgumentParser(description='neu video body rec')
     parser.add_argument('--gpu-ids', nargs='+', type=int, metavar='IDs', default=[0], help='gpu ids')
     parser.add_argument('--conf', default=None, metavar='M', help='config file')
@@ -36,9 +44,10 @@ def build_parser():
     parser.add_argument('--project_name', type=str, default='recmv', help='exp name show by wandb (unused: no wandb)')
     parser.add_argument('--exp_name', type=str, default='run', help='exp name show by wandb (unused: no wandb)')
     parser.add_argument('--data_type', type=str, default='synthetic', help='the type of dataset')
-    parser.add_argument('--a_pose', action='store_true', help='the type of dataset')
     parser.add_argument('--curve_sampling', type=int, default=1, help='the type of dataset')
-    parser.add_argument('--resume', default=None, metavar='M', help='pretrained scene model')
+    if not large_pose:                           # train_large_pose.py:20-37 has neither flag: it resumes from a-pose.pth
+        parser.add_argument('--a_pose', action='store_true', help='the type of dataset')
+        parser.add_argument('--resume', default=None, metavar='M', help='pretrained scene model')
     # extensions
     parser.add_argument('--no-curves', action='store_true',
                         help='skip the feature-curve branch (project_2d_loss) the reference runs every iteration')
@@ -72,12 +81,13 @@ def resumed_opt_times(config, n_frames, start_epoch, world_size=1):
     return float(coarse_time + medium_time + fine_time)
 
 
-def main(argv=None):
-    args = build_parser().parse_args(argv)
+def main(argv=None, large_pose=False):
+    args = build_parser(large_pose).parse_args(argv)
     import torch
     from recmv import dist as rdist, utils
     from recmv.hocon import ConfigFactory
-    from recmv.loop import HotLoop
+    from recmv.loop import RESOLUTIONS, FrameLoader
+    from recmv.model.network import getOptNet
 
     torch.set_num_threads(min(8, os.cpu_count() or 1))     # host side only launches kernels (see bench.py)
     config = ConfigFactory.parse_file(args.conf)
@@ -89,67 +99,94 @@ def main(argv=None):
         print('please set save-folder...')
         assert (False)
     save_root = osp.join(args.data or '.', args.save_folder)
+    debug_root = osp.join(save_root, 'debug')
     if rank == 0:
-        os.makedirs(osp.join(save_root, 'debug'), exist_ok=True)
+        os.makedirs(debug_root, exist_ok=True)
+    resolutions = RESOLUTIONS                                          # train.py:42-79
+    batch_size = config.get_int('train.coarse.point_render.batch_size')
+    sample_pix_num = config.get_int('train.sample_pix_num')
 
-    loop = HotLoop(config, device, n_frames=args.frames, H=512, W=512, stage='coarse', world_size=world, rank=rank,
-                   curves=not args.no_curves)
-    rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters())
-                          + (list(loop.inter_free_curve.parameters()) if loop.curves else []))
+    # train.py:170-171 (bmins / bmaxs None: the synthetic pipeline sizes the canonical box from its initial surfaces)
+    optNet, sdf_initialized = getOptNet(None, args.save_folder, batch_size, None, None, resolutions['coarse'], device,
+                                        config, opt_large=large_pose, n_frames=args.frames, H=512, W=512,
+                                        world_size=world, rank=rank, curves=not args.no_curves)
+    dataset = optNet.dataset
+    dataloader = FrameLoader(optNet)
+    optNet, dataloader = utils.set_hierarchical_config(config, 'coarse', optNet, dataloader, resolutions['coarse'])
+    rdist.broadcast_state([p for p in optNet.shared_parameters()] + list(optNet.sdf.parameters())
+                          + (list(optNet.inter_free_curve.parameters()) if optNet.curves else []))
     allreduce = rdist.GradAllReduce(world) if world > 1 else None
-    dataset = loop.dataset
+    optNet._allreduce = allreduce                 # the explicit-vertex and curve gradients are shared inside forward
+    optNet.train()
+    optNet.opt_times = 0.
     start_epoch = 0
-    optimizer = loop.optimizer
     milestones = config.get_list('train.scheduler.milestones')
     gamma = config.get_float('train.scheduler.factor')
+    optimizer = optNet.rebuild_optimizer()                                               # train.py:213
     scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma=gamma)
+    ratio = {'sdfRatio': None, 'deformerRatio': None, 'renderRatio': None}
     stage = 'coarse'
 
-    if args.resume is not None and osp.isfile(args.resume):
-        print('load model: ' + args.resume)
-        loop, dataset, start_epoch = utils.load_model(args.resume, loop, dataset, device, args.sdf_model,
-                                                      args.model_rm_prefix)
+    resume = osp.join(args.data or '.', args.save_folder, 'a-pose.pth') if large_pose else args.resume   # train_large_pose.py:39
+    if resume is not None and osp.isfile(resume):
+        print('load model: ' + resume)
+        optNet, dataset, start_epoch = utils.load_model(resume, optNet, dataset, device, args.sdf_model,
+                                                        args.model_rm_prefix)
+        if large_pose:
+            start_epoch = 60                                                             # train_large_pose.py:210
         stage = stage_of_epoch(config, start_epoch)
         if stage != 'coarse':
-            loop.set_stage(stage)
-            loop.isfine = stage == 'fine'
+            optNet, dataloader = utils.set_hierarchical_config(config, stage, optNet, dataloader, resolutions[stage])
+            optNet.isfine = stage == 'fine'
             print('enable %s hierarchical' % stage)
-        optimizer = loop.rebuild_optimizer()
+        optimizer = optNet.rebuild_optimizer()
         scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma=gamma)
         for __ in range(start_epoch + 1):
             scheduler.step()
-        loop.opt_times += resumed_opt_times(config, len(dataset), start_epoch, world)
+        optNet.opt_times += resumed_opt_times(config, len(dataset), start_epoch, world)
         start_epoch += 1
 
-    nepochs = config.get_int('train.nepoch')
+    nepochs = config.get_int('train.nepoch') + (1 if large_pose else 0)                  # train_large_pose.py:289
     done = 0
     for epoch in range(start_epoch, nepochs):
         new_stage = stage_of_epoch(config, epoch)
         if new_stage != stage:
             if rank == 0:
-                utils.save_model(osp.join(save_root, stage + ".pth"), epoch, loop, dataset)   # coarse.pth / medium.pth
-            loop.set_stage(new_stage)
-            loop.isfine = new_stage == 'fine'                  # train.py:312
+                utils.save_model(osp.join(save_root, stage + ".pth"), epoch, optNet, dataset)   # coarse.pth / medium.pth
+            optNet, dataloader = utils.set_hierarchical_config(config, new_stage, optNet, dataloader,
+                                                               resolutions[new_stage])
+            optNet.isfine = new_stage == 'fine'                  # train.py:312
             stage = new_stage
             torch.cuda.empty_cache()
             print('enable %s hierarchical' % stage)
-        for data_index in range(loop.iters_per_epoch()):
+        for data_index, (frame_ids, outs) in enumerate(dataloader.set_epoch(epoch)):
             t0 = time.perf_counter()
-            frame_ids = loop.frame_batch_at(epoch, data_index)
-            loss, rays = loop.step(int(loop.opt_times), allreduce, frame_ids=frame_ids)
+            frame_ids = frame_ids.long().to(device)
+            optimizer.zero_grad()
+            ratio['sdfRatio'] = 1.
+            ratio['deformerRatio'] = optNet.opt_times / 2500. + 0.5
+            ratio['renderRatio'] = 1.
+            loss = optNet(outs, sample_pix_num, ratio, frame_ids, debug_root, global_optimizer=optimizer)
+            loss.backward()
+            optNet.propagateTmpPsGrad(frame_ids, ratio)
+            if allreduce is not None:
+                allreduce(optNet.shared_parameters())            # frame-sharded ranks: mean of the shared gradients
+            optimizer.step()
             if rank == 0:
                 lr = optimizer.param_groups[0]['lr']
-                info = loop.info
-                msg = '(%d/%d) loss = %.5f lr = %.2e rays = %d' % (epoch, data_index, float(loss), lr, int(rays))
-                for name in loop.garment_names:
+                info = optNet.info
+                msg = '(%d/%d) loss = %.5f lr = %.2e rays = %d' % (epoch, data_index, float(loss), lr,
+                                                                   int(info.get('rays_total', 0)))
+                for name in optNet.garment_names:
                     msg += ' | %s: eik %.4f pc_sdf %.5f' % (name, float(info.get(name + '_grad_loss', 0.)),
                                                            float(info.get('pc_%s_loss_sdf' % name, 0.)))
                 print(msg + ' (%.0f ms)' % ((time.perf_counter() - t0) * 1e3), flush=True)
+            optNet.opt_times += 1.
             done += 1
             if 0 <= args.max_iters <= done:
                 break
         if rank == 0:
-            utils.save_model(osp.join(save_root, "latest.pth"), epoch, loop, dataset)
+            utils.save_model(osp.join(save_root, "latest.pth"), epoch, optNet, dataset)
         scheduler.step()
         if 0 <= args.max_iters <= done:
             break

@@ -71,11 +71,12 @@ def build_nets(device):
 
 
 # ------------------------------------------------------------------------------------------------ propagateTmpPsGrad
-def run_propagate(device, rtol=2e-3, atol_rel=2e-4):
-    """OptimGarmentNetwork.propagateTmpPsGrad (:2159-2313)."""
-    g = load("propagate")
+def run_propagate(device, rtol=2e-3, atol_rel=2e-4, large_pose=False):
+    """OptimGarmentNetwork.propagateTmpPsGrad (:2159-2313); large_pose: the OptimGarmentNetwork_LargePose variant
+    (OptimGarmentNetwork_Large_Pose.py:326-475) with its frozen SDF nets."""
+    g = load("propagate_large" if large_pose else "propagate")
     n = build_nets(device)
-    out, n_total, n_ok = pc.run(g, n["sdf"], n["tr"], n["comp"], device)
+    out, n_total, n_ok = pc.run(g, n["sdf"], n["tr"], n["comp"], device, large_pose=large_pose)
     assert (n_total, n_ok) == (int(g["inv_total"]), int(g["inv_ok"]))
     pc.compare(out, g, rtol=rtol, atol_rel=atol_rel)
 
@@ -93,7 +94,7 @@ def run_render_loss(device, rtol_loss=2e-4, rtol_info=5e-4, rtol_grad=5e-3, atol
     fake = types.SimpleNamespace(conf=loss_conf(), device=device, garment_size=1, garment_names=['upper'],
                                  garment_nets=[sdf], deformer=comp, netRender=rn, info={})
     fake.garment_vs = [g["in_verts"].clone().requires_grad_(True)]
-    fake.dataset = types.SimpleNamespace(images=lambda fids: (g["in_gtC"], g["in_gtN"]))
+    fake._gt_images = lambda fids: (g["in_gtC"], g["in_gtN"])
     fake.get_grad_parameters = lambda fids, dev: ([None, leaves["conds"]], leaves["poses"], leaves["trans"],
                                                   leaves["rendcond"])
     fake._ray_valid = [g["in_check"].sum()]
@@ -156,7 +157,7 @@ def run_sample_rays(device):
     found = [(g[f"in{i}_b"], g[f"in{i}_r"], g[f"in{i}_c"], g[f"in{i}_p"], None) for i in range(2)]
     fake = types.SimpleNamespace(conf={}, sample_pix=1024, garment_size=2, device=device, info={},
                                  _surface_inputs=(None, None), find_surface_ps=lambda d, t, c: found,
-                                 dataset=types.SimpleNamespace(garment_masks=lambda g_i, fids: g["masks"][g_i]))
+                                 _gt_garment_mask=lambda g_i, fids: g["masks"][g_i])
     if torch.device(device).type == "cuda":
         fake._surface_stream = None
         fake._surface_ready = torch.cuda.Event()

@@ -5,6 +5,10 @@ tensors, ray bookkeeping).  Two substitutions, both outside the arithmetic under
 (the CUDA extension cannot be built here) and `RectifiedPerspectiveCameras` is recmv's stand-alone restatement (the
 reference class derives from pytorch3d's CamerasBase, absent here; its ray / centre formulas are pinned separately).
 
+`propagate_large.npz`: the same state through `OptimGarmentNetwork_LargePose.propagateTmpPsGrad`
+(engineer/networks/OptimGarmentNetwork_Large_Pose.py:326-475) after its `freeze_sdf` (:130-137): the SDF nets are
+frozen and receive nothing, the deformer / per-frame / camera gradients are injected as before.
+
     python tests/golden/make_golden_propagate.py
 """
 import sys
@@ -40,12 +44,15 @@ def inputs(sdf, comp, ratio):
                 R=torch.diag(torch.tensor([-1., -1., 1.])).view(1, 3, 3), T=torch.tensor([[0.1, -0.2, 3.0]]))
 
 
-def main():
+def main(large_pose=False):
     N = ref_loader.ref_module("model.network")
     Dref = ref_loader.ref_module("model.Deformer")
     OGN = ref_loader.ref_module("engineer.networks.OptimGarmentNetwork")
     from recmv.model import RectifiedPerspectiveCameras as OurCameras
     OGN.RectifiedPerspectiveCameras = OurCameras
+    if large_pose:
+        OGNL = ref_loader.ref_module("engineer.networks.OptimGarmentNetwork_Large_Pose")
+        OGNL.RectifiedPerspectiveCameras = OurCameras
     sdf = cs.build_sdf(N.getTmpSdf)
     tr = cs.build_translator(Dref.MLPTranslator)
     sk = cs.build_skinner(Dref.LBSkinner, Dref.batch_rodrigues)
@@ -74,17 +81,25 @@ def main():
     for m in (sdf, comp):
         for q in m.parameters():
             q.grad = None
-    OGN.OptimGarmentNetwork.propagateTmpPsGrad(fake, torch.arange(3), ratio)
+    if large_pose:
+        fake.garment_nets = torch.nn.ModuleList([sdf])
+        OGNL.OptimGarmentNetwork_LargePose.freeze_sdf(fake)                  # the reference's own freezing (:130-137)
+        assert not any(q.requires_grad for q in sdf.parameters())
+        OGNL.OptimGarmentNetwork_LargePose.propagateTmpPsGrad(fake, torch.arange(3), ratio)
+        assert all(q.grad is None for q in sdf.parameters()), "frozen SDF nets receive no gradient"
+    else:
+        OGN.OptimGarmentNetwork.propagateTmpPsGrad(fake, torch.arange(3), ratio)
     sp, tp = dict(sdf.named_parameters()), dict(tr.named_parameters())
-    out = {"g_sdf_" + k.replace(".", "_"): sp[k].grad for k in SDF_KEYS}
+    out = {} if large_pose else {"g_sdf_" + k.replace(".", "_"): sp[k].grad for k in SDF_KEYS}
     out.update({"g_tr_" + k.replace(".", "_"): tp[k].grad for k in TR_KEYS})
     out.update({"g_" + k: v.grad for k, v in leaves.items()})
     n_inv = fake.info["upper_invInfo"]
     print("propagate: invertible %d / %d" % (n_inv[1], n_inv[0]))
-    save("propagate", p=x["p"], grad_l_p=x["grad_l_p"], col=x["col"], row=x["row"], binds=x["binds"], focal=x["focal"],
+    save("propagate_large" if large_pose else "propagate", p=x["p"], grad_l_p=x["grad_l_p"], col=x["col"], row=x["row"], binds=x["binds"], focal=x["focal"],
          pp=x["pp"], R=x["R"], T=x["T"], conds=conds.detach(), poses=poses.detach(), trans=trans.detach(), inv_total=n_inv[0], inv_ok=n_inv[1],
          **out)
 
 
 if __name__ == "__main__":
     main()
+    main(large_pose=True)

@@ -8,7 +8,7 @@ SDF_KEYS = ["lin0.weight_v", "lin4.weight_g", "lin8.bias", "lin3.bias"]
 TR_KEYS = ["lin0.weight", "lin2.bias", "lin4.weight"]
 
 
-def run(g, sdf, tr, comp, device):
+def run(g, sdf, tr, comp, device, large_pose=False):
     from recmv.loop import HotLoop
     from recmv.model import RectifiedPerspectiveCameras
     dev = torch.device(device)
@@ -31,10 +31,15 @@ def run(g, sdf, tr, comp, device):
     for m in (sdf, comp):
         for q in m.parameters():
             q.grad = None
+    if large_pose:                             # OptimGarmentNetwork_LargePose.freeze_sdf (:130-137)
+        fake.sdf = sdf
+        HotLoop.freeze_sdf(fake)
     ratio = {"sdfRatio": 0.8, "deformerRatio": 0.7, "renderRatio": 1.0}
     HotLoop.propagateTmpPsGrad(fake, torch.arange(3, device=dev), ratio)
     sp, tp = dict(sdf.named_parameters()), dict(tr.named_parameters())
-    out = {"g_sdf_" + k.replace(".", "_"): sp[k].grad for k in SDF_KEYS}
+    if large_pose:
+        assert all(q.grad is None for q in sdf.parameters()), "frozen SDF nets receive no gradient"
+    out = {} if large_pose else {"g_sdf_" + k.replace(".", "_"): sp[k].grad for k in SDF_KEYS}
     out.update({"g_tr_" + k.replace(".", "_"): tp[k].grad for k in TR_KEYS})
     out.update({"g_" + k: v.grad for k, v in leaves.items()})
     n_total, n_ok = fake.info["upper_invInfo"]

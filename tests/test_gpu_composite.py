@@ -21,6 +21,10 @@ def test_propagate_tmp_ps_grad_on_gpu_matches_the_reference_method():
     cc.run_propagate(DEV)
 
 
+def test_large_pose_propagate_on_gpu_matches_the_reference_method():
+    cc.run_propagate(DEV, large_pose=True)
+
+
 def test_compute_garment_pc_loss_on_gpu_matches_the_reference_method():
     cc.run_pc_loss(DEV)
 

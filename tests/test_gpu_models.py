@@ -233,6 +233,58 @@ def test_seg3d_lossless_and_mc(nets):
         close(verts, g["verts"], rtol=0, atol=2e-4)
 
 
+def test_seg3d_device_route_queries_the_same_voxels_and_lockstep_equals_separate_runs(nets):
+    """Device route (bit volume + select / points / apply / expand kernels, csrc/seg3d.hip) vs the volume route (torch
+    ops on a boolean volume): identical voxel sets per query — incl. the conflict rounds, provoked here by a field with
+    thin features that trilinear interpolation gets wrong — and identical world points; `forward_multi` (several fields
+    level by level in lockstep) returns bit for bit what separate `forward()` calls return."""
+    from recmv.MCAcc import Seg3dLossless
+    sdf = nets["sdf"]
+
+    def field(kind):
+        def q(points):
+            p = points.reshape(-1, 3)
+            with torch.no_grad():
+                if kind == "net":
+                    return sdf.forward(p, 1.0).reshape(1, 1, -1)
+                # two close shells: thin negative layers between coarse lattice points -> interpolation has the wrong sign
+                r = p.norm(dim=1)
+                return (torch.minimum((r - 0.55).abs(), (r - 0.62).abs()) - 0.012).reshape(1, 1, -1)
+        return q
+
+    res = [(9, 11, 7), (17, 21, 13), (33, 41, 25), (65, 81, 49)]
+    logs = {}
+    vols = {}
+    for route in (True, False):
+        for kind in ("net", "shells"):
+            seen = []
+            f = field(kind)
+
+            def q(points, f=f, seen=seen):
+                seen.append(points.reshape(-1, 3).clone())
+                return f(points)
+
+            eng = Seg3dLossless(query_func=q, b_min=[-1.0, -1.1, -0.9], b_max=[1.0, 1.1, 0.9], resolutions=res,
+                                align_corners=False, balance_value=0.0, use_cuda_impl=route, faster=False).to(DEV)
+            vols[(route, kind)] = eng.forward()
+            logs[(route, kind)] = seen
+    for kind in ("net", "shells"):
+        a, b = logs[(True, kind)], logs[(False, kind)]
+        assert [t.shape[0] for t in a] == [t.shape[0] for t in b], (kind, [t.shape[0] for t in a], [t.shape[0] for t in b])
+        for ta, tb in zip(a, b):                 # same points, the device list is unordered: compare as sorted rows
+            key = lambda t: torch.argsort(t[:, 0].double() * 1e8 + t[:, 1].double() * 1e4 + t[:, 2].double())
+            ka, kb = ta[key(ta)], tb[key(tb)]
+            assert torch.equal(ka, kb), kind
+        close(vols[(True, kind)], vols[(False, kind)], rtol=0, atol=1e-6)     # interpolated-only voxels: last bit
+        assert torch.equal(vols[(True, kind)] < 0, vols[(False, kind)] < 0)
+    assert len(logs[(True, "shells")]) > len(res), "the shell field must go through at least one conflict round"
+    eng = Seg3dLossless(query_func=None, b_min=[-1.0, -1.1, -0.9], b_max=[1.0, 1.1, 0.9], resolutions=res,
+                        align_corners=False, balance_value=0.0, use_cuda_impl=True, faster=False).to(DEV)
+    both = eng.forward_multi([field("net"), field("shells"), field("net")])
+    assert torch.equal(both[0], vols[(True, "net")]) and torch.equal(both[1], vols[(True, "shells")])
+    assert torch.equal(both[2], both[0]) and eng.query_func is None
+
+
 # ------------------------------------------------------------------------------------------ jet passes
 def _grads(loss, params):
     gs = torch.autograd.grad(loss, params, allow_unused=True)

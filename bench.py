@@ -471,13 +471,29 @@ def main():
         alt = dict(gemm_mode=other, steps=n_alt, value=round(n_alt * world / alt_elapsed, 4), unit="iters/s",
                    ms_per_step=round(alt_elapsed / n_alt * 1e3, 3),
                    note="same loop, other matrix mode, short run after the timed region (no re-mesh inside)")
+    per_rank_ms, allreduce_us = None, None
     if world > 1:
+        mine = elapsed
         t = torch.tensor([elapsed, float(rays)], device=device, dtype=torch.float64)
         tmax = t.clone()
         tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
         tsum = t.clone()
         tdist.all_reduce(tsum, op=tdist.ReduceOp.SUM)
         elapsed, rays = float(tmax[0]), int(tsum[1])
+        slots = torch.zeros(world, device=device, dtype=torch.float64)
+        slots[rank] = mine
+        tdist.all_reduce(slots, op=tdist.ReduceOp.SUM)
+        per_rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in slots]
+        # the step's collective alone: the flattened all-reduce of the shared gradients (~25 MB), 10 repetitions
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        allreduce(loop.shared_parameters())
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            allreduce(loop.shared_parameters())
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_us = round(e0.elapsed_time(e1) * 1e2, 1)
 
     if rank == 0:
         iters = args.steps * world
@@ -508,6 +524,9 @@ def main():
                                                           loop.remesh_intersect, loop.remesh_intersect,
                                                           "ON (project_2d_loss + curve_aware_loss)" if args.curves else "OFF (--no-curves)"),
                 "parallelism": "frame-sharded dp%d, 1 RCCL all-reduce of shared grads / step" % world,
+                "per_rank_ms_per_step": per_rank_ms,
+                "shared_grad_allreduce_us": allreduce_us,
+                "shared_grad_bytes": int(sum(p.numel() for p in loop.shared_parameters()) * 4),
                 "mc_vertices": [int(v.shape[0]) for v in loop.garment_vs],
                 "rays_per_iter": int(loop.info.get('rays_total', 0)),
                 "rays_converged_per_iter": round(converged / max(args.steps, 1), 1),

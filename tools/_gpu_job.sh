@@ -1,9 +1,7 @@
 set -x
-timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -6 > gpurun_out/r2_gputests.log
-timeout 200 python tools/seg3d_timing.py > gpurun_out/r2_seg3d.log 2>&1
-rm -rf /tmp/run1; mkdir -p /tmp/run1
-timeout 300 python rec-mv_amd/train.py --conf configs/synthetic/people_snapshot_like.conf --data /tmp/run1 --save-folder out --frames 12 --max-iters 5 > gpurun_out/r2_train_smoke.log 2>&1
-ls -la /tmp/run1/out >> gpurun_out/r2_train_smoke.log
-cp /tmp/run1/out/latest.pth /tmp/run1/out/a-pose.pth
-timeout 300 python rec-mv_amd/train_large_pose.py --conf configs/synthetic/people_snapshot_like.conf --data /tmp/run1 --save-folder out --frames 12 --max-iters 4 --project_name p --exp_name e --data_type large_pose > gpurun_out/r2_train_large_smoke.log 2>&1
-timeout 600 python bench.py --steps 20 --warmup 1 --no-cpu-baseline > gpurun_out/r2_bench2.json 2> gpurun_out/r2_bench2.err
+timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -4 > gpurun_out/r2_gputests.log
+RECMV_TIMING=1 timeout 600 python bench.py --steps 30 --warmup 1 --no-cpu-baseline --no-mc --no-alt-mode --no-hbm-kernels --settle-iters 120 > gpurun_out/r2_phases.json 2> gpurun_out/r2_phases.err
+cd /tmp && export TMPDIR=/tmp
+timeout 800 rocprofv3 --kernel-trace --stats -d /tmp/prof -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 1 --no-cpu-baseline --no-mc --no-alt-mode --no-hbm-kernels --settle-iters 60 > /tmp/prof_bench.json 2> /tmp/prof_bench.err
+cd $GRAFT_REPO_ROOT
+python tools/prof_summary.py /tmp/prof 70 > gpurun_out/r2_kernel_trace.txt 2>&1

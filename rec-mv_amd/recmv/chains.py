@@ -238,7 +238,8 @@ class MlpJet(torch.autograd.Function):
                 nb = cfg['cond_blocks']
                 gcond = gc.reshape(nb, P // nb, gc.shape[1]).sum(1)
             else:
-                gcond = torch.zeros(ctx.cond_shape, dtype=torch.float32, device=dev).index_add_(0, cidx, gc)
+                from .ops import rows_sum_by_index
+                gcond = rows_sum_by_index(gc, cidx, ctx.cond_shape[0])       # fixed order, no float atomics
         ctx.ws = None
         return (None, gx, gcond) + tuple(gWs) + tuple(gbs)
 

@@ -475,16 +475,27 @@ class HotLoop:
 
     def _garment_fragments(self, g_i, def_v, cameras):
         """First-hit fragments of garment g_i's deformed meshes, rasterised once per iteration (the z-buffer of the
-        curve branch :1399 and the surface points of find_surface_ps :767 are the same image)."""
+        curve branch :1399 and the surface points of find_surface_ps :767 are the same image).  The two users run on
+        different streams: the cache keeps the event recorded behind the rasterisation, a reader on another stream waits
+        for it."""
         cache = getattr(self, '_frag_cache', None)
         if cache is None:
             cache = self._frag_cache = {}
+        cuda = torch.device(self.device).type == 'cuda'
         if g_i not in cache:
             rast = raster.MeshRasterizer(cameras, (self.dataset.H, self.dataset.W), blur_radius=0.,
                                          perspective_correct=True, cull_backfaces=False)           # :2336-2347
             with torch.no_grad():
-                cache[g_i] = rast(def_v.detach(), self.garment_fs[g_i])
-        return cache[g_i]
+                frags = rast(def_v.detach(), self.garment_fs[g_i])
+            ev = None
+            if cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+            cache[g_i] = (frags, ev, torch.cuda.current_stream(self.device) if cuda else None)
+        frags, ev, producer = cache[g_i]
+        if ev is not None and torch.cuda.current_stream(self.device) != producer:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        return frags
 
     # ------------------------------------------------------------------------------------------ feature curves
     FL_GARMENT = {'upper': 'short_sleeve_upper', 'bottom': 'long_pants'}      # female-3-casual, utils/constant.py:116
@@ -686,12 +697,8 @@ class HotLoop:
             garment_loss = garment_loss + self.compute_garment_pc_loss(
                 def_vs[g_i], [d_cond_list[g_i + 1], [poses, trans]], garment_masks_list[g_i], gt, name,
                 self.garment_vs[g_i])
-        # find_surface_ps reads the deformed meshes and the PRE-step vertices (:918 runs before the SGD step): take
-        # the snapshot here, rasterise later on a side stream while the backward below keeps the device busy
-        self._surface_inputs = ([d.detach() for d in def_vs], [v.detach().clone() for v in self.garment_vs])
-        self._surface_ready = torch.cuda.Event() if torch.device(self.device).type == 'cuda' else None
-        if self._surface_ready is not None:
-            self._surface_ready.record()
+        # (the snapshot find_surface_ps reads — deformed meshes and PRE-step vertices — was taken in forward(), right after
+        # the deformation: the ray pipeline runs on side streams while the backward below keeps the device busy)
         self.garment_optimizer.zero_grad()
         garment_loss.backward()                    # grads also reach deformer / codes / poses and stay for Adam (:959)
         if getattr(self, '_allreduce', None) is not None:
@@ -794,13 +801,38 @@ class HotLoop:
         self.info['surface_pixels'] = [int(f[0].shape[0]) for f in found]
         return out
 
+    def _prepare_rays_early(self, frame_ids, cameras, ratio):
+        """What the ray pipeline (find_surface_ps -> sample_train_ray -> root finder) needs from the main stream, produced
+        NOW, before the curve branch and the mask loss are queued: the per-frame tensors of the batch, the camera centre,
+        the root finder's shared state (weight-normed weights + transposes, posed skeleton, chain descriptors).  With
+        these and the deformed vertices the pipeline runs on side streams underneath the mask loss's large GEMMs instead
+        of behind them; the root finder's result is the same (it reads the nets, it does not change them)."""
+        if torch.device(self.device).type != 'cuda' or os.environ.get('RECMV_SERIAL_RAYS') == '1':
+            self._early = None              # RECMV_SERIAL_RAYS=1: the root finder forks from the main stream's tail (A/B timing)
+            return
+        with torch.no_grad():
+            d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
+            early = dict(d_cond=[c.detach() for c in d_cond_list[1:]], poses=poses.detach(), trans=trans.detach(),
+                         cam_pos=cameras.cam_pos().detach().clone())
+            utils.prepare_root_finder(list(self.garment_nets), self.deformer, [early['poses'], early['trans']], ratio)
+        early['ready'] = torch.cuda.Event()
+        early['ready'].record()
+        self._early = early
+
     def opt_garment_surface_ps(self, frame_ids, cameras, ratio, samples):
-        d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
-        defconds_list = [d_cond_list[1:], [poses, trans]]
+        early = getattr(self, '_early', None)
+        if early is not None:
+            defconds_list = [early['d_cond'], [early['poses'], early['trans']]]
+            cam_pos, after = early['cam_pos'], [early['ready'], self._surface_stream]
+        else:
+            d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
+            defconds_list = [d_cond_list[1:], [poses, trans]]
+            cam_pos, after = cameras.cam_pos().detach(), None
         pts, checks = utils.OptimizeGarmentSurfacePs(
-            cameras.cam_pos().detach(), [s[4].detach() for s in samples], [s[3] for s in samples],
+            cam_pos, [s[4].detach() for s in samples], [s[3] for s in samples],
             [s[0] for s in samples], self.garment_nets, ratio, self.deformer, defconds_list,
-            garment_names=self.garment_names, dthreshold=5.e-5, athreshold=self.angThred, w1=3.05, w2=1., times=20)
+            garment_names=self.garment_names, dthreshold=5.e-5, athreshold=self.angThred, w1=3.05, w2=1., times=20,
+            after=after)
         self.info['rays_total'] = sum(c.numel() for c in checks)
         self._ray_valid = [c.sum() for c in checks]
         return pts, checks
@@ -889,8 +921,9 @@ class HotLoop:
                     gtn = (grad_d_p.transpose(-2, -1) * gtn.unsqueeze(-2)).sum(-1)
                     normal_loss = (gtn - nx).norm(2, dim=1) * weights
                     w = valid_mask.to(normal_loss.dtype)
-                    num = torch.zeros(N, device=dev).index_add(0, b, normal_loss * w)
-                    den = torch.zeros(N, device=dev).index_add(0, b, w)
+                    from .ops import rows_sum_by_index                   # per-frame sums in a fixed order
+                    num = rows_sum_by_index((normal_loss * w).view(-1, 1), b, N).view(-1)
+                    den = rows_sum_by_index(w.view(-1, 1), b, N).view(-1)
                     normal_loss = (num / den.clamp(min=1)).mean()
                     self.info['{}_normal_loss'.format(name)] = normal_loss.detach()
                     total_loss = total_loss + conf.get_float('normal_weight') * normal_loss
@@ -917,10 +950,21 @@ class HotLoop:
         self.info = {}
         self._def_cache, self._frag_cache = None, {}      # per-iteration caches (shared deformation / fragments)
         cameras = self._cameras()
+        # a second camera object for the ray phases (its own autograd graph: the mask loss's backward frees the first
+        # one's, :1036), built NOW so that the side streams of the ray pipeline never wait for the main stream's queue
+        cameras_rays = self._cameras()
         if self.body_vs is None or self.forward_time % self.remesh_intersect == 0:
             with self._phase('remesh'):
                 self.marching_cube_update(ratio)
         total_loss = 0.
+        with self._phase('deform'):
+            def_vs = self._deform_garments(N, frame_ids, ratio)
+            # find_surface_ps reads the deformed meshes and the PRE-step vertices (:918 runs before the SGD step)
+            self._surface_inputs = ([d.detach() for d in def_vs], [v.detach().clone() for v in self.garment_vs])
+            self._surface_ready = torch.cuda.Event() if torch.device(self.device).type == 'cuda' else None
+            if self._surface_ready is not None:
+                self._surface_ready.record()
+            self._prepare_rays_early(frame_ids, cameras_rays, ratio)
         if self.curves:
             with self._phase('curves'):
                 self.project_2d_loss(N, frame_ids, ratio, cameras)                           # :1932
@@ -929,7 +973,7 @@ class HotLoop:
             def_vs, pc_sdf_loss = self.mask_loss(N, frame_ids, ratio, cameras)
         total_loss = total_loss + pc_sdf_loss
         d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
-        cameras = self._cameras()                                                          # rebuilt graph (:1036)
+        cameras = cameras_rays                                                             # rebuilt graph (:1036)
         with self._phase('sample_rays'):
             samples = self.sample_train_ray(N, frame_ids, cameras)
         with self._phase('root_find'):

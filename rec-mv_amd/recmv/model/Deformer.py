@@ -176,7 +176,7 @@ class MLPTranslator(nn.Module):
             else:
                 ps = self.embed_fn(ps, annealing_weights(self.multires, ratio))
         if batch_inds is not None:
-            x = torch.cat([ps, conds.index_select(0, batch_inds)], dim=1)
+            x = torch.cat([ps, ops.gather_rows(conds, batch_inds)], dim=1)       # deterministic backward
         else:
             x = torch.cat([ps, conds.view(-1, 1, self.feature_vector_size).expand(
                 -1, ps.shape[1], self.feature_vector_size)], dim=-1).view(-1, ps.shape[-1] + self.feature_vector_size)
@@ -452,7 +452,7 @@ class LBSkinner(nn.Module):
         Tall = ops.MatmulNT.apply(ps_ws, Ball).view(-1, batch_size, 16)
         T = Tall.gather(1, binds.view(-1, 1, 1).expand(-1, 1, 16)).view(-1, 4, 4)
         v = (T[:, :3, :3] * flat.unsqueeze(-2)).sum(-1) + T[:, :3, 3]
-        return v + trans.index_select(0, binds)
+        return v + ops.gather_rows(trans, binds)
 
     # -- graph-free passes on ray points: fused kernels (csrc/lbs_fused.hip) ----------------------------
     def _lbs_grid(self):

@@ -206,6 +206,45 @@ class MatmulTN(torch.autograd.Function):
         return gA, gB
 
 
+def rows_sum_by_index(g, index, n):
+    """out[k] = sum of the rows of `g` [P,C] whose `index` [P] is k, k < n — as a one-hot product on the split-K MFMA
+    kernel: a FIXED summation order.  torch's `index_add_` / the backward of `index_select` add with float atomics in
+    scheduling order; with a handful of frames and thousands of rays per frame that makes the per-frame gradients (and,
+    through the optimiser, every later iteration) differ from run to run.  Differentiable (MatmulTN) when a graph is
+    being built."""
+    onehot = (index.view(-1, 1) == torch.arange(n, device=g.device).view(1, -1)).to(g.dtype)
+    g2 = g.reshape(g.shape[0], -1)
+    if g2.shape[0] == 0:
+        return torch.zeros((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+    if not g.is_cuda:
+        out = torch.zeros(n, g2.shape[1], dtype=g.dtype, device=g.device).index_add(0, index, g2)   # sequential on the host
+    elif torch.is_grad_enabled() and g.requires_grad:
+        out = MatmulTN.apply(onehot, g2.contiguous())
+    else:
+        out = gemm_tn(onehot, g2.detach().contiguous())
+    return out.view((n,) + tuple(g.shape[1:]))
+
+
+class GatherRows(torch.autograd.Function):
+    """rows[index] of a small per-frame table (per-frame codes, translations) with a deterministic backward
+    (rows_sum_by_index) — the `cond[batch_inds]` of model/Deformer.py:190."""
+
+    @staticmethod
+    def forward(ctx, table, index):
+        ctx.save_for_backward(index)
+        ctx.n = table.shape[0]
+        return table.index_select(0, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        return rows_sum_by_index(g, index, ctx.n), None
+
+
+def gather_rows(table, index):
+    return GatherRows.apply(table, index)
+
+
 def _dact_from_output(y, act, act_param):
     """act'(z) expressed through y = act(z) with differentiable torch ops."""
     if act == ACT_NONE:

@@ -14,7 +14,7 @@ import os
 import numpy as np
 import torch
 
-__all__ = ["FindSurfacePs", "OptimizeGarmentSurfacePs"]
+__all__ = ["FindSurfacePs", "OptimizeGarmentSurfacePs", "prepare_root_finder"]
 
 
 def FindSurfacePs(TmpVs, TmpFaces, frags):
@@ -127,22 +127,40 @@ class _RootState:
 
 
 @torch.no_grad()
+def prepare_root_finder(tmpSdf_nets, deformer, smpl_conds, ratio):
+    """Everything the garments' root finders share (weight-normed weights and their transposes, posed skeleton, chain
+    descriptors), produced on the CURRENT stream.  A caller that wants the root finder to start before the rest of its
+    queue has drained calls this early, records an event, and passes it as `after` to OptimizeGarmentSurfacePs."""
+    with torch.no_grad():
+        for net in tmpSdf_nets:
+            net.chain(net._pe_weights(ratio), need_t=True)
+        deformer.prepare_explicit([None, smpl_conds], ratio=ratio)
+
+
 def _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, tmpSdf_nets, ratio, deformer,
-                           defconds_list, smpl_conds, garment_names, dthreshold, athreshold, w1, w2, times):
+                           defconds_list, smpl_conds, garment_names, dthreshold, athreshold, w1, w2, times, after=None):
     """All garments at once, one HIP stream per garment: a garment's step is a train of ~60 small kernels on a few
     thousand rays that cannot fill 256 CUs; the garments are independent, so their trains overlap."""
     dev = initTmpPs_list[0].device
     main = torch.cuda.current_stream(dev)
     streams = _streams(dev, len(initTmpPs_list))
     # everything the garments share (weight-normed weights and their transposes, posed skeleton, chain descriptors) is
-    # produced on the main stream BEFORE the side streams fork from it
-    for net in tmpSdf_nets[:len(initTmpPs_list)]:
-        net.chain(net._pe_weights(ratio), need_t=True)
-    deformer.prepare_explicit([None, smpl_conds], ratio=ratio)
+    # produced BEFORE the side streams fork: on the main stream right here, or — `after` given — earlier by the caller
+    # (prepare_root_finder), in which case the side streams wait for the caller's events / streams only and start while
+    # the main stream still works through whatever was queued after them
+    if after is None:
+        prepare_root_finder(tmpSdf_nets[:len(initTmpPs_list)], deformer, smpl_conds, ratio)
     states = []
     for g, (initTmpPs, batch_inds, defconds, rays, name) in enumerate(
             zip(initTmpPs_list, batch_inds_list, defconds_list, rays_list, garment_names)):
-        streams[g].wait_stream(main)
+        if after is None:
+            streams[g].wait_stream(main)
+        else:
+            for dep in after:
+                if isinstance(dep, torch.cuda.Stream):
+                    streams[g].wait_stream(dep)
+                else:
+                    streams[g].wait_event(dep)
         states.append(_RootState(cam_pos, rays, initTmpPs, batch_inds, tmpSdf_nets[g], ratio, deformer, defconds,
                                  smpl_conds, name, dthreshold, athreshold, w1, w2, times, streams[g]))
     live = True
@@ -168,13 +186,13 @@ def _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, 
 
 def OptimizeGarmentSurfacePs(cam_pos, rays_list, initTmpPs_list, batch_inds_list, tmpSdf_nets, ratio, deformer,
                              defconds_list, garment_names, dthreshold=5.e-5, athreshold=0.02, w1=3.05, w2=1.,
-                             times=5):
+                             times=5, after=None):
     smpl_conds = defconds_list[1]
     if (len(initTmpPs_list) > 0 and all(t.is_cuda for t in initTmpPs_list) and hasattr(deformer, 'ray_energy_and_vjp')
             and all(hasattr(n, 'chain') for n in tmpSdf_nets)):
         outs, oks = _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, tmpSdf_nets, ratio,
                                            deformer, defconds_list[0], smpl_conds, garment_names, dthreshold,
-                                           athreshold, w1, w2, times)
+                                           athreshold, w1, w2, times, after=after)
         return [o.detach() for o in outs], oks
     optimized_init_tmp_ps_list = []
     optimized_check_list = []

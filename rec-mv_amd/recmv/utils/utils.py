@@ -155,10 +155,11 @@ def compute_netRender_color(net, ps, ds, ns, vs, features, framefeatures, ratio)
 
 
 def scatter_mean(src, index, dim_size):
-    """torch_scatter.scatter(src, index, reduce='mean', dim_size=...) for 1-D src (third-party in the
-    reference: OptimGarmentNetwork.py:1188,1215).  Empty bins give 0, like torch_scatter."""
-    out = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, src)
-    cnt = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, torch.ones_like(src))
+    """torch_scatter.scatter(src, index, reduce='mean', dim_size=...) for 1-D src (OptimGarmentNetwork.py:1188, :1215),
+    summed in a fixed order (ops.rows_sum_by_index) instead of with float atomics."""
+    from ..ops import rows_sum_by_index
+    out = rows_sum_by_index(src.view(-1, 1), index, dim_size).view(-1)
+    cnt = rows_sum_by_index(torch.ones_like(src).detach().view(-1, 1), index, dim_size).view(-1)
     return out / cnt.clamp(min=1)
 
 

@@ -220,7 +220,7 @@ def run_fl_visibility(device):
     comp = build_nets(device)["comp"]
     smpl_conds = [g["poses"], g["trans"]]
     fake = types.SimpleNamespace(deformer=comp, garment_fs=[g["gf"]], tmpBodyVs=g["bv"], tmpBodyFs=g["bf"],
-                                 dataset=types.SimpleNamespace(H=H, W=W), _frag_cache={})
+                                 dataset=types.SimpleNamespace(H=H, W=W), _frag_cache={}, device=device)
     fake._garment_fragments = types.MethodType(HotLoop._garment_fragments, fake)
     with torch.no_grad():
         fake._shared_def_vs = [comp(g["gv"][None].expand(N, -1, 3), [g["conds"], smpl_conds], ratio=RATIO,

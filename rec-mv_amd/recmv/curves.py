@@ -98,7 +98,7 @@ def fl_proj_loss(fl_pts_list, gt_fl_pts_list, fl_masks, proj_fl_weights=None):
     """engineer/core/fl_optimizer.py:72-110.  Per feature line: chamfer between the VISIBLE projected samples of each
     frame and that frame's 2-D ground-truth curve, averaged over the frames that see the line and over the visible
     samples, then over the lines."""
-    loss = torch.tensor(0.).to(fl_pts_list[0])
+    loss = fl_pts_list[0].new_zeros(())          # (no host tensor: a pageable H2D copy would block the host on this stream)
     if proj_fl_weights is None:
         proj_fl_weights = [1. for _ in range(len(fl_pts_list))]
     for fl_pts, gt_fl_pts, fl_mask, w in zip(fl_pts_list, gt_fl_pts_list, fl_masks, proj_fl_weights):

@@ -650,7 +650,12 @@ class HotLoop:
             loss = 0. * sdf_loss + 0. * project_loss           # OptimGarmentNetwork_Large_Pose.py:219: zero-weighted
         else:
             loss = 10. * sdf_loss + 1. * project_loss                                     # :1865
-        loss.backward()
+        # The reference calls loss.backward() here (:1866) and throws the gradients it leaves on the shared networks away
+        # with the optimiser's zero_grad that follows (:1934): only the curve parameters' gradients are used.  They are
+        # computed directly, so the branch touches no shared `.grad` and can run beside the mask loss on its own stream.
+        curve_params = list(self.inter_free_curve.parameters())
+        for q, gq in zip(curve_params, torch.autograd.grad(loss, curve_params, allow_unused=True)):
+            q.grad = gq if gq is not None else torch.zeros_like(q)
         if getattr(self, '_allreduce', None) is not None:
             self._allreduce(list(self.inter_free_curve.parameters()))     # curve gradients are shared across ranks (§8e)
         self.fl_optimizer.step()
@@ -677,8 +682,8 @@ class HotLoop:
             loss = loss + closs * cw
         return loss
 
-    def mask_loss(self, N, frame_ids, ratio, cameras):
-        """OptimGarmentNetwork.py:841-981: deform the explicit garment meshes, splat the merged point cloud into one
+    def mask_loss(self, N, frame_ids, ratio, cameras, defer_sdf_terms=False):
+        """OptimGarmentNetwork.py:841-981 (`defer_sdf_terms`: stop after the SGD step; the caller adds pc_sdf_terms()): deform the explicit garment meshes, splat the merged point cloud into one
         alpha-composited silhouette per garment (pcRender, :937), IoU loss against the dilated ground-truth masks +
         LBS-consistency term (compute_garment_pc_loss, :621-667), SGD step on the explicit vertices, |SDF| loss."""
         d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
@@ -704,14 +709,24 @@ class HotLoop:
         if getattr(self, '_allreduce', None) is not None:
             self._allreduce(self.garment_vs)       # explicit MC vertices: identical numbering on every rank (§8e-2)
         self.garment_optimizer.step()
+        if torch.device(self.device).type == 'cuda':
+            self._sgd_done = torch.cuda.Event()      # the render loss samples around the POST-step vertices (:1108)
+            self._sgd_done.record()
+        if defer_sdf_terms:
+            return [d.detach() for d in def_vs], None
+        return [d.detach() for d in def_vs], self.pc_sdf_terms(ratio)
+
+    def pc_sdf_terms(self, ratio):
+        """The |SDF| terms at the end of mask_loss (:963-972): the moved explicit vertices and the curve-aware disc pull
+        their garment's zero level towards them."""
+        conf = self.conf
         pc_sdf_loss = 0.
         for g_i, name in enumerate(self.garment_names):                                   # :966-970
             mnfld_pred = self.garment_nets[g_i](self.garment_vs[g_i], ratio, features=False).view(-1)
             sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
             self.info['pc_{}_loss_sdf'.format(name)] = sdf_loss.detach()
             pc_sdf_loss = pc_sdf_loss + sdf_loss * conf.get_float('pc_weight.weight')
-        pc_sdf_loss = pc_sdf_loss + self.curve_aware_loss(ratio)                          # :972
-        return [d.detach() for d in def_vs], pc_sdf_loss
+        return pc_sdf_loss + self.curve_aware_loss(ratio)                                # :972
 
     CURVE_AWARE = {'female_outfit1': 'bottom_curve', 'female_outfit3': 'bottom_curve',
                    'anran_dance': 'bottom_curve'}                                          # utils/constant.py:228-232
@@ -807,8 +822,8 @@ class HotLoop:
         the root finder's shared state (weight-normed weights + transposes, posed skeleton, chain descriptors).  With
         these and the deformed vertices the pipeline runs on side streams underneath the mask loss's large GEMMs instead
         of behind them; the root finder's result is the same (it reads the nets, it does not change them)."""
-        if torch.device(self.device).type != 'cuda' or os.environ.get('RECMV_SERIAL_RAYS') == '1':
-            self._early = None              # RECMV_SERIAL_RAYS=1: the root finder forks from the main stream's tail (A/B timing)
+        if torch.device(self.device).type != 'cuda' or self.world_size != 1 or os.environ.get('RECMV_SERIAL') == '1':
+            self._early = None              # RECMV_SERIAL=1: the reference's order on one stream (A/B timing, determinism)
             return
         with torch.no_grad():
             d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
@@ -910,7 +925,8 @@ class HotLoop:
                     else:
                         weights = torch.ones(nx.shape[0], device=dev)
                     gtn = gtNs[b, self.row_inds[g_i], self.col_inds[g_i], :]
-                    flip = torch.tensor([[-1., 0., 0.], [0., 1., 0.], [0., 0., -1.]], device=dev)
+                    flip = torch.diag(torch.ones(3, device=dev) * torch.arange(-1., 2., device=dev).abs().mul(-2.).add(1.))
+                    # = diag(-1, 1, -1), formed on the device (a host list would be a blocking H2D copy on this stream)
                     M = (cameras.R[0].unsqueeze(-1) * flip.unsqueeze(0)).sum(1)             # R @ flip
                     gtn = (M.unsqueeze(0) * gtn.unsqueeze(-2)).sum(-1)
                     gtnorms = gtn.norm(dim=1, keepdim=True)
@@ -965,24 +981,71 @@ class HotLoop:
             if self._surface_ready is not None:
                 self._surface_ready.record()
             self._prepare_rays_early(frame_ids, cameras_rays, ratio)
-        if self.curves:
-            with self._phase('curves'):
-                self.project_2d_loss(N, frame_ids, ratio, cameras)                           # :1932
-        (global_optimizer if global_optimizer is not None else self.optimizer).zero_grad()  # :1934
-        with self._phase('mask_loss'):
-            def_vs, pc_sdf_loss = self.mask_loss(N, frame_ids, ratio, cameras)
-        total_loss = total_loss + pc_sdf_loss
-        d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
-        cameras = cameras_rays                                                             # rebuilt graph (:1036)
-        with self._phase('sample_rays'):
-            samples = self.sample_train_ray(N, frame_ids, cameras)
-        with self._phase('root_find'):
-            init_ps_list, checks = self.opt_garment_surface_ps(frame_ids, cameras, ratio, samples)
-        with self._phase('render_loss_fwd'):
-            total_loss = total_loss + self.surface_render_loss(N, cameras, frame_ids, ratio, checks, init_ps_list,
-                                                               samples)
-        with self._phase('dct'):
-            total_loss = total_loss + self.dct_poses_loss(poses, trans, frame_ids, N)
+        opt = global_optimizer if global_optimizer is not None else self.optimizer
+        cuda = torch.device(self.device).type == 'cuda'
+        if not (cuda and self.world_size == 1 and os.environ.get('RECMV_SERIAL') != '1'):
+            # ---- the reference's order, one phase after the other
+            if self.curves:
+                with self._phase('curves'):
+                    self.project_2d_loss(N, frame_ids, ratio, cameras)                       # :1932
+            opt.zero_grad()                                                                # :1934
+            with self._phase('mask_loss'):
+                def_vs, pc_sdf_loss = self.mask_loss(N, frame_ids, ratio, cameras)
+            total_loss = total_loss + pc_sdf_loss
+            d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
+            cameras = cameras_rays                                                         # rebuilt graph (:1036)
+            with self._phase('sample_rays'):
+                samples = self.sample_train_ray(N, frame_ids, cameras)
+            with self._phase('root_find'):
+                init_ps_list, checks = self.opt_garment_surface_ps(frame_ids, cameras, ratio, samples)
+            with self._phase('render_loss_fwd'):
+                total_loss = total_loss + self.surface_render_loss(N, cameras, frame_ids, ratio, checks, init_ps_list,
+                                                                   samples)
+            with self._phase('dct'):
+                total_loss = total_loss + self.dct_poses_loss(poses, trans, frame_ids, N)
+        else:
+            # ---- the same terms as a dependency graph over three streams.  What depends on what:
+            #   mask loss (explicit vertices: splat, IoU, backward through the deformer, SGD step)  <- deformation
+            #   ray pipeline (surface points, ray sampling, root finder)                             <- deformation
+            #   curve branch (its gradients reach the curve parameters only, see project_2d_loss)   <- deformation
+            #   |SDF| terms: vertices after the SGD step, curve-aware disc after the curve step
+            #   render loss: root finder + vertices after the SGD step
+            # The mask loss's large GEMMs go to the main stream first; the two chains of small launches run beside them
+            # on side streams; the final backward runs every node on the stream of its forward.  Same arithmetic, same
+            # random draws in the same host order: bit-identical to the serial order (tools/determinism_probe.py).
+            main = torch.cuda.current_stream(self.device)
+            if getattr(self, '_surface_stream', None) is None:
+                self._surface_stream = torch.cuda.Stream(device=self.device)
+            if getattr(self, '_curve_stream', None) is None:
+                self._curve_stream = torch.cuda.Stream(device=self.device)
+            s_ray, s_curve = self._surface_stream, self._curve_stream
+            opt.zero_grad()              # (:1934) nothing of the curve branch lands on the shared gradients any more
+            with self._phase('mask_loss'):
+                self.mask_loss(N, frame_ids, ratio, cameras, defer_sdf_terms=True)
+            with torch.cuda.stream(s_ray):
+                with self._phase('sample_rays'):
+                    samples = self.sample_train_ray(N, frame_ids, cameras_rays)            # waits for the deformation only
+                with self._phase('root_find'):
+                    init_ps_list, checks = self.opt_garment_surface_ps(frame_ids, cameras_rays, ratio, samples)
+            curve_done = None
+            if self.curves:
+                with torch.cuda.stream(s_curve), self._phase('curves'):
+                    s_curve.wait_event(self._surface_ready)
+                    self.project_2d_loss(N, frame_ids, ratio, cameras)                       # :1932
+                    curve_done = torch.cuda.Event()
+                    curve_done.record()
+            with self._phase('pc_sdf'):
+                if curve_done is not None:
+                    main.wait_event(curve_done)          # curve_aware_loss reads the curves after their AdamW step
+                total_loss = total_loss + self.pc_sdf_terms(ratio)
+            with torch.cuda.stream(s_ray), self._phase('render_loss_fwd'):
+                s_ray.wait_event(self._sgd_done)
+                render_loss = self.surface_render_loss(N, cameras_rays, frame_ids, ratio, checks, init_ps_list, samples)
+            main.wait_stream(s_ray)
+            total_loss = total_loss + render_loss
+            with self._phase('dct'):
+                d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
+                total_loss = total_loss + self.dct_poses_loss(poses, trans, frame_ids, N)
         self.forward_time += 1
         return total_loss
 

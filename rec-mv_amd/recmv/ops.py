@@ -29,13 +29,24 @@ def _ws_key(dev):
 
 
 def transposed(W):
-    """Contiguous W^T, cached on the tensor object for as long as its data is unchanged."""
+    """Contiguous W^T, cached on the tensor object for as long as its data is unchanged.  The cache is shared by every
+    stream that differentiates through W in an iteration (mask loss, curve branch, render loss): it keeps the event
+    recorded behind the transpose, and a hit from another stream waits for it."""
     hit = getattr(W, "_recmv_t", None)
     if hit is not None and hit[0] == W._version:
+        if hit[2] is not None:
+            cur = torch.cuda.current_stream(W.device)
+            if cur.cuda_stream != hit[3]:
+                cur.wait_event(hit[2])
         return hit[1]
     Wt = W.detach().t().contiguous()
+    ev = sid = None
+    if W.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record()
+        sid = torch.cuda.current_stream(W.device).cuda_stream
     try:
-        W._recmv_t = (W._version, Wt)
+        W._recmv_t = (W._version, Wt, ev, sid)
     except Exception:
         pass
     return Wt

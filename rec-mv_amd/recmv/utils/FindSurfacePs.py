@@ -67,9 +67,9 @@ class _RootState:
     input gradient), four for the deformer (offset MLP, fused skinning + ray energy, and their VJPs) and one fused
     stopping-test / update kernel.  All rays are carried through every step (rows of the kernels are independent, so
     the active rays get the same updates); finished rays are simply not updated.  The post-update check of step i is
-    the forward pass of step i+1, evaluated once.  The early exit reads the unfinished-ray count of the PREVIOUS step
-    (pinned host copy + event), so the host never waits on the step it has just enqueued; the one extra evaluation
-    this can cost changes nothing (no unfinished ray = no update)."""
+    the forward pass of step i+1, evaluated once.  The early exit polls the unfinished-ray count of an earlier step
+    (pinned host copy + event query) and never blocks the host; the extra evaluations this can cost change nothing
+    (no unfinished ray = no update)."""
 
     def __init__(self, cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds, smpl_conds, name,
                  dthreshold, athreshold, w1, w2, times, stream):
@@ -98,11 +98,11 @@ class _RootState:
         if self.finished:
             return False
         it = self.it
-        if it >= 2:                        # lagged early exit: the count of step it-2 has certainly been asked for
-            self.events[it - 2].synchronize()
-            if int(self.host[it - 2]) == 0:
-                self.finished = True
-                return False
+        if it >= 2 and self.events[it - 2].query() and int(self.host[it - 2]) == 0:
+            # early exit, never waited for: the count of step it-2 is looked at only if it has already arrived (the
+            # host keeps queueing — it has other streams to feed); a step queued past the end changes nothing
+            self.finished = True
+            return False
         if it > self.times:
             self.finished = True
             return False

@@ -13,13 +13,13 @@ from recmv.loop import HotLoop  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
-loop = HotLoop(conf, torch.device("cuda", 0), n_frames=64, H=512, W=512)
-for it in range(2):
+loop = HotLoop(conf, torch.device("cuda", 0), n_frames=64, H=512, W=512, curves=True)
+for it in range(3):
     loop.step(it)
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-for it in range(2, 2 + steps):
+for it in range(3, 3 + steps):
     loop.step(it)
 torch.cuda.synchronize()
 pr.disable()

@@ -387,6 +387,14 @@ int recmv_lbs_vjp_params_stage(const float* ps, const int64_t* frame, int64_t P,
 int recmv_rootfind_update(float* p, const float* f, const float* gf, const float* loss2, const float* angle,
                           const float* gd, uint8_t* unfinished, int32_t* counter, int64_t P, float dthreshold,
                           float athreshold, float w1, float w2, int do_update, void* stream);
+/* The same step with the step index on the device, so that all steps of an iteration are one and the same launch (a
+ * step captured in a hipGraph can be replayed).  counters / marks: int32 [times + 2], zero-initialised by the caller;
+ * state: int32 [1] = index of the step to run (0 at the start).  Runs the update with do_update = (step < times),
+ * counters[step] += unfinished rays; then marks[step] = counters[step] + 1 and state[0] = step + 1.  A host that polls an
+ * asynchronous copy of `marks` reads 0 for "not run yet" and 1 for "no unfinished ray" (utils/FindSurfacePs.py:311-313). */
+int recmv_rootfind_step(float* p, const float* f, const float* gf, const float* loss2, const float* angle,
+                        const float* gd, uint8_t* unfinished, int32_t* counters, int32_t* marks, int32_t* state,
+                        int64_t P, float dthreshold, float athreshold, float w1, float w2, int times, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of one fused layer y = act(x W^T + b) in one call (csrc/linear_bwd.hip) — autograd of nn.Linear +

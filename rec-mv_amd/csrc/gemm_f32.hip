@@ -20,6 +20,7 @@
 // FLOPs: 2*M*N*K.  With K=N=512 the arithmetic intensity is 128 FLOP/B >> 157e12/8e12, so every layer
 // is MFMA-bound, not HBM-bound.
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include "common.h"
 
@@ -330,6 +331,262 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
   // accumulators -> LDS: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   constexpr int LDC = TBN + 4;
   float* Cs = smem;                        // [TBM][LDC] <= the operand buffers
+#pragma unroll
+  for (int mi = 0; mi < T; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < T; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = wn * WT + ni * 32 + (lane & 31);
+        Cs[row * LDC + col] = acc[mi][ni][r];
+      }
+  __syncthreads();
+  switch (act) {
+    case RECMV_ACT_RELU:
+      nt_epilogue<T, RECMV_ACT_RELU>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      break;
+    case RECMV_ACT_SOFTPLUS:
+      nt_epilogue<T, RECMV_ACT_SOFTPLUS>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      break;
+    case RECMV_ACT_TANH:
+      nt_epilogue<T, RECMV_ACT_TANH>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      break;
+    default:
+      nt_epilogue<T, RECMV_ACT_NONE>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ NT, bf16x6 staged
+// The bf16x6 mode with the 3-way split done ONCE per operand element, on the global -> LDS staging path (8 elements
+// per thread and item: two 16-byte loads, 44 VALU, three 16-byte LDS stores), instead of once per wave that reads the
+// element as an MFMA fragment: the main loop is then 16-byte fragment reads + bf16 MFMAs, with the split's VALU issued
+// in the shadow of the MFMAs (about four per MFMA).
+// LDS image of an operand tile: three planes (h, m, l) of [rows][32 k] bf16, row = 64 bytes = four 16-byte chunks,
+// chunk c of row r stored at chunk position c ^ ((r >> 2) & 3): the four 16-lane groups of a ds_read_b128 fragment
+// read (rows {0-3,12-15,20-27}+.. at one chunk) and the 8-lane groups of the ds_write_b128 stores (two rows x four
+// chunks) each cover distinct 16-byte bank slots, without padding.  One LDS buffer (48 KB of operands for 128x128; two
+// workgroups per CU, each covering the other's barriers and epilogue).
+// Pipeline per K-tile kt (raw = f32 as loaded, pieces = packed bf16 planes, both in registers): the raw registers hold
+// tile kt+1 (requested during the previous iteration); it is split while the first 16 columns of tile kt are multiplied
+// (each MFMA followed by its share of the split's VALU), tile kt+2 is requested as soon as the raw registers are free,
+// the second 16 columns are multiplied, then barrier, pieces -> LDS, barrier.
+// Measured alternatives that were slower (profiles/r02_gemm_staged_split.txt): two raw A sets with the A request a whole
+// K-tile ahead (-6 %), accumulators taking turns between consecutive MFMAs (-5 %): the loop is bound by the SIMD's issue
+// slots (about 6 non-MFMA instructions per MFMA across the two co-resident waves), not by latency.
+__device__ __forceinline__ int b3_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int T, bool AMUL>
+__global__ __launch_bounds__(kBlk, 2) void gemm_nt_b3_kernel(const float* __restrict__ A, int64_t lda,
+                                                             const float* __restrict__ B, int64_t ldb,
+                                                             const float* __restrict__ bias, float* __restrict__ C,
+                                                             int64_t ldc, int M, int N, int K, int act,
+                                                             float act_param, float out_scale, int nbm, int nbn,
+                                                             bool c_vec, AMul am) {
+  constexpr int TBM = 64 * T, TBN = 64 * T, WT = 32 * T;
+  constexpr int NI = TBM * 4 / kBlk;            // (row, 8-k chunk) items per thread and operand: 2 or 1
+  constexpr int PLANE = TBM * 64;               // bytes of one plane of one operand tile
+  constexpr int NSET = 1;                       // raw A register sets
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* As = reinterpret_cast<char*>(smem);     // [3][TBM][64 B]
+  char* Bs = As + 3 * PLANE;                    // [3][TBN][64 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t logical = xcd_remap(blockIdx.x, (int64_t)nbm * nbn);
+  const int tile_m = (int)(logical / nbn), tile_n = (int)(logical % nbn);
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+
+  f32x16 acc[T][T];
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 ra[NSET][NI][2], rb[NI][2], ry[AMUL ? NI : 1][2];
+  u32x4 sa[NI][3], sb[NI][3];
+  const float* pa[NI];
+  const float* pb[NI];
+  const float* py[NI];
+  int soff[NI];
+#pragma unroll
+  for (int r = 0; r < NI; ++r) {
+    const int item = tid + kBlk * r;
+    const int row = item >> 2, ch = item & 3;
+    int gm = m0 + row, gn = n0 + row;
+    gm = gm < M ? gm : M - 1;                   // clamped rows are computed and never stored
+    gn = gn < N ? gn : N - 1;
+    pa[r] = A + (int64_t)gm * lda + ch * 8;
+    pb[r] = B + (int64_t)gn * ldb + ch * 8;
+    if (AMUL) py[r] = am.Y + (int64_t)gm * am.ldy + ch * 8;
+    soff[r] = b3_off(row, ch);
+  }
+  const int kch = (tid & 3) * 8;
+  const int nk = (K + BK - 1) / BK;
+  // Offsets of a thread's two float4 of K-tile t, and whether they are inside K (K % 4 == 0: a float4 is entirely
+  // inside or outside; an outside one reads the row's last float4 and is zeroed).  Whole tiles take the plain path.
+#define RECMV_KEEP4(v, c) v = make_float4((c) ? v.x : 0.f, (c) ? v.y : 0.f, (c) ? v.z : 0.f, (c) ? v.w : 0.f)
+  auto load_a = [&](auto set_c, auto whole_c, int t) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_c)::value;
+    const int k0 = t * BK, k = k0 + kch;
+    const bool in0 = decltype(whole_c)::value || k < K, in1 = decltype(whole_c)::value || k + 4 < K;
+    const int o0 = in0 ? k0 : K - 4 - kch, o1 = in1 ? k0 + 4 : K - 4 - kch;
+#pragma unroll
+    for (int r = 0; r < NI; ++r) {
+      ra[S][r][0] = *reinterpret_cast<const float4*>(pa[r] + o0);
+      ra[S][r][1] = *reinterpret_cast<const float4*>(pa[r] + o1);
+      if (AMUL) {
+        ry[r][0] = *reinterpret_cast<const float4*>(py[r] + o0);
+        ry[r][1] = *reinterpret_cast<const float4*>(py[r] + o1);
+      }
+      if (!decltype(whole_c)::value) {
+        RECMV_KEEP4(ra[S][r][0], in0);
+        RECMV_KEEP4(ra[S][r][1], in1);
+      }
+    }
+  };
+  auto load_b = [&](auto whole_c, int t) __attribute__((always_inline)) {
+    const int k0 = t * BK, k = k0 + kch;
+    const bool in0 = decltype(whole_c)::value || k < K, in1 = decltype(whole_c)::value || k + 4 < K;
+    const int o0 = in0 ? k0 : K - 4 - kch, o1 = in1 ? k0 + 4 : K - 4 - kch;
+#pragma unroll
+    for (int r = 0; r < NI; ++r) {
+      rb[r][0] = *reinterpret_cast<const float4*>(pb[r] + o0);
+      rb[r][1] = *reinterpret_cast<const float4*>(pb[r] + o1);
+      if (!decltype(whole_c)::value) {
+        RECMV_KEEP4(rb[r][0], in0);
+        RECMV_KEEP4(rb[r][1], in1);
+      }
+    }
+  };
+#undef RECMV_KEEP4
+  auto split_a = [&](auto set_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_c)::value;
+#pragma unroll
+    for (int r = 0; r < NI; ++r) {
+      if (AMUL) {
+        ra[S][r][0] = amul4(ra[S][r][0], ry[r][0], am);
+        ra[S][r][1] = amul4(ra[S][r][1], ry[r][1], am);
+      }
+      const Pieces a = split8(ra[S][r][0], ra[S][r][1]);
+      sa[r][0] = __builtin_bit_cast(u32x4, a.h);
+      sa[r][1] = __builtin_bit_cast(u32x4, a.m);
+      sa[r][2] = __builtin_bit_cast(u32x4, a.l);
+    }
+  };
+  // keeps everything computed from `v` behind this point of the instruction stream (the split is pure arithmetic: without
+  // it the compiler may start it ahead of the scheduling barrier, right behind the loads it waits for)
+  auto pin4 = [&](float4& v) __attribute__((always_inline)) {
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+  };
+  auto split_b = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < NI; ++r) {
+      pin4(rb[r][0]);
+      pin4(rb[r][1]);
+      const Pieces b = split8(rb[r][0], rb[r][1]);
+      sb[r][0] = __builtin_bit_cast(u32x4, b.h);
+      sb[r][1] = __builtin_bit_cast(u32x4, b.m);
+      sb[r][2] = __builtin_bit_cast(u32x4, b.l);
+    }
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < NI; ++r)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        *reinterpret_cast<u32x4*>(As + p * PLANE + soff[r]) = sa[r][p];
+        *reinterpret_cast<u32x4*>(Bs + p * PLANE + soff[r]) = sb[r][p];
+      }
+  };
+  const int arow = wm * WT + (lane & 31), brow = wn * WT + (lane & 31), kh = lane >> 5;
+  const int aswz = (arow >> 2) & 3, bswz = (brow >> 2) & 3;   // (+32 rows leaves the swizzle unchanged)
+  bf16x8 fa[T][3], fb[T][3];
+  auto reads = [&](int ks) __attribute__((always_inline)) {
+    const char* ap = As + arow * 64 + (((ks * 2 + kh) ^ aswz) << 4);
+    const char* bp = Bs + brow * 64 + (((ks * 2 + kh) ^ bswz) << 4);
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fa[i][p] = *reinterpret_cast<const bf16x8*>(ap + p * PLANE + i * 32 * 64);
+        fb[i][p] = *reinterpret_cast<const bf16x8*>(bp + p * PLANE + i * 32 * 64);
+      }
+  };
+  auto mfmas = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < T; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < T; ++ni) {     // piece products hl, lh, mm, hm, mh, hh: small terms first
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][0], fb[ni][2], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][2], fb[ni][0], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][1], fb[ni][1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][0], fb[ni][1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][1], fb[ni][0], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][0], fb[ni][0], acc[mi][ni], 0, 0, 0);
+      }
+  };
+  // the scheduling pattern of half a K-tile: its fragment reads, then every MFMA followed by VALU of the split
+  auto pattern = [&](auto valu_c) __attribute__((always_inline)) {
+    constexpr int valu_per_mfma = decltype(valu_c)::value;
+    __builtin_amdgcn_sched_group_barrier(0x100, 6 * T, 0);
+#pragma unroll
+    for (int i = 0; i < 6 * T * T; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, valu_per_mfma, 0);
+    }
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  using S0 = std::integral_constant<int, 0>;
+
+  {
+    auto ktile = [&](auto whole_c, int kt) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      reads(0);
+      split_a(S0{});
+      split_b();
+      if (decltype(whole_c)::value || kt + 2 < nk) {
+        load_a(S0{}, whole_c, kt + 2);
+        load_b(whole_c, kt + 2);
+      }
+      mfmas();
+      if (decltype(whole_c)::value) {
+        pattern(std::integral_constant<int, 8>{});
+        __builtin_amdgcn_sched_group_barrier(0x020, (AMUL ? 6 : 4) * NI, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      reads(1);
+      mfmas();
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      lstore();
+      __syncthreads();
+    };
+    load_a(S0{}, No{}, 0);
+    load_b(No{}, 0);
+    split_a(S0{});
+    split_b();
+    lstore();
+    if (nk > 1) {
+      load_a(S0{}, No{}, 1);
+      load_b(No{}, 1);
+    }
+    __syncthreads();
+    int kt = 0;
+    const int nwhole = K / BK;
+    for (; kt + 2 < nwhole; ++kt) ktile(Yes{}, kt);
+    for (; kt + 1 < nk; ++kt) ktile(No{}, kt);
+  }
+  reads(0);
+  mfmas();
+  reads(1);
+  mfmas();
+  __syncthreads();
+
+  constexpr int LDC = TBN + 4;
+  float* Cs = smem;                        // [TBM][LDC]
 #pragma unroll
   for (int mi = 0; mi < T; ++mi)
 #pragma unroll
@@ -800,6 +1057,25 @@ static int launch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, c
   return check_launch("gemm_nt");
 }
 
+template <int T, bool AMUL>
+static int launch_nt_b3(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
+                        int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
+                        bool c_vec, const AMul& am, hipStream_t stream) {
+  constexpr int lds_ops = 6 * 64 * T * 64, lds_c = 64 * T * (64 * T + 4) * 4;
+  constexpr int lds = lds_ops > lds_c ? lds_ops : lds_c;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_b3_kernel<T, AMUL>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int nbm = (int)ceil_div(M, 64 * T), nbn = (int)ceil_div(N, 64 * T);
+  ScopedLaunchTimer timer((T - 1) + 2 + 4 * (AMUL ? 1 : 0), 2.0 * M * N * K, stream);
+  hipLaunchKernelGGL((gemm_nt_b3_kernel<T, AMUL>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds, stream, A, lda,
+                     B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, c_vec, am);
+  return check_launch("gemm_nt(b3)");
+}
+
 constexpr int kNarrowLds = 2 * (64 + 32) * LDK * 4;   // 27648 B
 
 template <bool FAST, bool AMUL, bool BF3>
@@ -829,7 +1105,12 @@ static int dispatch_nt(const float* A, int64_t lda, const float* B, int64_t ldb,
                                                     a_vec, b_vec, c_vec, am, s)                                    \
                     : launch_nt<TT, FF, AMUL, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param,        \
                                                      out_scale, a_vec, b_vec, c_vec, am, s))
-  if (big_blocks >= 2 * kNumCU) return fast ? RECMV_NT(2, true) : RECMV_NT(2, false);
+  if (big_blocks >= 2 * kNumCU) {
+    if (g_gemm_mode == 1 && fast) {
+      return launch_nt_b3<2, AMUL>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, c_vec, am, s);
+    }
+    return fast ? RECMV_NT(2, true) : RECMV_NT(2, false);
+  }
   // 64x64 tiles unless they would give the CUs fewer than ~2.5 workgroups each: then 64x32 tiles (twice as many)
   const int64_t mid_blocks = ceil_div(M, 64) * ceil_div(N, 64);
   if (mid_blocks < (5 * kNumCU) / 2) {

@@ -259,6 +259,53 @@ __global__ __launch_bounds__(kBlk) void rootfind_update_kernel(float* __restrict
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(counter, local);
 }
 
+// The same step with its index kept on the device, so that every step of an iteration is the SAME launch (a captured
+// step can be replayed): state[0] = index of the step being run; counters[step] receives the number of unfinished rays.
+__global__ __launch_bounds__(kBlk) void rootfind_step_kernel(float* __restrict__ p, const float* __restrict__ f,
+                                                             const float* __restrict__ gf,
+                                                             const float* __restrict__ loss2,
+                                                             const float* __restrict__ angle,
+                                                             const float* __restrict__ gd,
+                                                             uint8_t* __restrict__ unfinished,
+                                                             int32_t* __restrict__ counters,
+                                                             const int32_t* __restrict__ state, int64_t P, float dthr,
+                                                             float athr, float w1, float w2, int times) {
+  const int step = state[0];
+  const bool do_update = step < times;
+  int local = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlk + threadIdx.x; i < P; i += (int64_t)gridDim.x * kBlk) {
+    const float fi = f[i];
+    const bool done = fabsf(fi) < dthr && angle[i] < athr;
+    const bool un = unfinished[i] && !done;
+    unfinished[i] = un ? 1 : 0;
+    if (un) {
+      ++local;
+      if (do_update) {
+        const float loss = w1 * fabsf(fi) + w2 * loss2[i];
+        const float sg = fi > 0.f ? 1.f : (fi < 0.f ? -1.f : 0.f);
+        const float g0 = w1 * sg * gf[3 * i] + w2 * gd[3 * i];
+        const float g1 = w1 * sg * gf[3 * i + 1] + w2 * gd[3 * i + 1];
+        const float g2 = w1 * sg * gf[3 * i + 2] + w2 * gd[3 * i + 2];
+        const float t = -loss / (g0 * g0 + g1 * g1 + g2 * g2);
+        p[3 * i] += t * g0;
+        p[3 * i + 1] += t * g1;
+        p[3 * i + 2] += t * g2;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(counters + step, local);
+}
+
+// marks[step] = counters[step] + 1 (0 = "step not run yet" for a host that polls a copy of marks); state[0] = step + 1
+__global__ void rootfind_advance_kernel(const int32_t* __restrict__ counters, int32_t* __restrict__ marks,
+                                        int32_t* __restrict__ state) {
+  const int step = state[0];
+  marks[step] = counters[step] + 1;
+  state[0] = step + 1;
+}
+
 int check_geom(const recmv_lbs_grid* g) {
   RECMV_REQUIRE(g && g->volume, "lbs: NULL skinning grid");
   RECMV_REQUIRE(g->D > 0 && g->H > 0 && g->W > 0, "lbs: empty skinning grid");
@@ -328,6 +375,19 @@ extern "C" int recmv_lbs_vjp_params_stage(const float* ps, const int64_t* frame,
   hipLaunchKernelGGL(lbs_vjp_params_stage_kernel, dim3(stream_grid(P, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, ps,
                      frame, (int)B, grid->volume, to_geom(grid), P, g_d, W, Q, Gs);
   return check_launch("lbs_vjp_params_stage");
+}
+
+extern "C" int recmv_rootfind_step(float* p, const float* f, const float* gf, const float* loss2, const float* angle,
+                                   const float* gd, uint8_t* unfinished, int32_t* counters, int32_t* marks,
+                                   int32_t* state, int64_t P, float dthreshold, float athreshold, float w1, float w2,
+                                   int times, void* stream) {
+  RECMV_REQUIRE(P > 0 && times >= 0, "rootfind_step: bad sizes");
+  RECMV_REQUIRE(p && f && gf && loss2 && angle && gd && unfinished && counters && marks && state,
+                "rootfind_step: NULL pointer");
+  hipLaunchKernelGGL(rootfind_step_kernel, dim3(stream_grid(P, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, p, f, gf,
+                     loss2, angle, gd, unfinished, counters, state, P, dthreshold, athreshold, w1, w2, times);
+  hipLaunchKernelGGL(rootfind_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counters, marks, state);
+  return check_launch("rootfind_step");
 }
 
 extern "C" int recmv_rootfind_update(float* p, const float* f, const float* gf, const float* loss2,

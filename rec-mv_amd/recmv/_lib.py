@@ -117,6 +117,7 @@ def _declare(lib):
         "recmv_lbs_vjp_input": (C.c_int, [vp, vp, i64, vp, i64, C.POINTER(LbsGrid), vp, vp, vp]),
         "recmv_lbs_vjp_params_stage": (C.c_int, [vp, vp, i64, i64, C.POINTER(LbsGrid), vp, vp, vp, vp, vp]),
         "recmv_rootfind_update": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
+        "recmv_rootfind_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
         "recmv_rasterize_meshes_workspace_bytes": (i64, [i64, i64, i64, i64]),
         "recmv_rasterize_points_workspace_bytes": (i64, [i64, i64, i64, i64, f32]),
         "recmv_rasterize_points": (C.c_int, [vp, vp, vp, i64, i64, i64, i64, i64, f32, i32, vp, vp, vp, vp, i64, vp]),

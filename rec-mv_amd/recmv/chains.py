@@ -138,6 +138,15 @@ def rootfind_update(p, f, gf, loss2, angle, gd, unfinished, counter, dthreshold,
                                               L.stream_ptr(p.device)), "rootfind_update")
 
 
+def rootfind_step(p, f, gf, loss2, angle, gd, unfinished, counters, marks, state, dthreshold, athreshold, w1, w2, times):
+    """recmv_rootfind_step: the update with its step index on the device (every step is the same launch)."""
+    with torch.cuda.device(p.device):
+        L.check(L.lib().recmv_rootfind_step(L.ptr(p), L.ptr(f), L.ptr(gf), L.ptr(loss2), L.ptr(angle), L.ptr(gd),
+                                            L.ptr(unfinished), L.ptr(counters), L.ptr(marks), L.ptr(state), p.shape[0],
+                                            float(dthreshold), float(athreshold), float(w1), float(w2), int(times),
+                                            L.stream_ptr(p.device)), "rootfind_step")
+
+
 # --------------------------------------------------------------------------------------------------
 # MLP jet: value + input Jacobian forward, explicit first-order reverse (csrc/mlp_jet.hip)
 # --------------------------------------------------------------------------------------------------

@@ -94,6 +94,19 @@ def chamfer_distance_sum(x, y):
     return d.min(dim=1).values.sum() + d.min(dim=0).values.sum()
 
 
+def chamfer_visible_sum(x, vis, y):
+    """`chamfer_distance_sum(x[vis][None], y[None])` without forming x[vis] (boolean indexing is a `nonzero`: a host
+    round trip that stalls the stream's feeder).  x [n,D], vis [n] bool, y [m,D].  Hidden samples contribute no row
+    term and are kept out of the column minima; no visible sample or an empty side = zero, as upstream."""
+    if x.shape[0] == 0 or y.shape[0] == 0:
+        return x.sum() * 0.
+    d = ((x[:, None, :] - y[None, :, :]) ** 2).sum(-1)                      # [n,m]
+    rows = torch.where(vis, d.min(dim=1).values, d.new_zeros(()))
+    cols = torch.where(vis[:, None], d, d.new_full((), float('inf'))).min(dim=0).values
+    cols = torch.where(vis.any(), cols, cols.new_zeros(()))
+    return rows.sum() + cols.sum()
+
+
 def fl_proj_loss(fl_pts_list, gt_fl_pts_list, fl_masks, proj_fl_weights=None):
     """engineer/core/fl_optimizer.py:72-110.  Per feature line: chamfer between the VISIBLE projected samples of each
     frame and that frame's 2-D ground-truth curve, averaged over the frames that see the line and over the visible
@@ -107,8 +120,9 @@ def fl_proj_loss(fl_pts_list, gt_fl_pts_list, fl_masks, proj_fl_weights=None):
         valid_batch = (fl_mask[..., 0].sum(dim=-1) > 0).float().sum()
         batch_loss = 0.
         for screen_fl_pt, screen_fl_mask, gt_fl_pt in zip(screen_fl_pts, screen_fl_masks, gt_fl_pts):
-            screen_fl_pt = screen_fl_pt[screen_fl_mask == 1].view(1, -1, 2)
-            batch_loss = batch_loss + w * chamfer_distance_sum(screen_fl_pt, gt_fl_pt.view(1, -1, 2))
+            # the reference compacts `screen_fl_pt[screen_fl_mask == 1]` (:92); same sums, no compaction
+            batch_loss = batch_loss + w * chamfer_visible_sum(screen_fl_pt, screen_fl_mask[..., 0] == 1,
+                                                              gt_fl_pt.view(-1, 2))
         # the reference branches on `valid_batch != 0` / `masks.sum() != 0` through host reads; the same selection is
         # made on the device here
         batch_loss = torch.where(valid_batch != 0, batch_loss / valid_batch.clamp(min=1.), batch_loss)

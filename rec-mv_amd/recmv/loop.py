@@ -1025,8 +1025,8 @@ class HotLoop:
             with torch.cuda.stream(s_ray):
                 with self._phase('sample_rays'):
                     samples = self.sample_train_ray(N, frame_ids, cameras_rays)            # waits for the deformation only
-                with self._phase('root_find'):
-                    init_ps_list, checks = self.opt_garment_surface_ps(frame_ids, cameras_rays, ratio, samples)
+            with torch.cuda.stream(s_ray), self._phase('root_find'):
+                init_ps_list, checks = self.opt_garment_surface_ps(frame_ids, cameras_rays, ratio, samples)
             curve_done = None
             if self.curves:
                 with torch.cuda.stream(s_curve), self._phase('curves'):
@@ -1134,7 +1134,10 @@ class HotLoop:
         ids = perm[pos * per_it:(pos + 1) * per_it]
         if ids.numel() < self.world_size:
             ids = torch.cat([ids, perm[:self.world_size - ids.numel()]])
-        return ids[self.rank::self.world_size][:self.batch_size].to(self.device)
+        ids = ids[self.rank::self.world_size][:self.batch_size]
+        if torch.device(self.device).type == 'cuda':      # pinned + non_blocking: a pageable copy synchronises the stream (a drain per step)
+            return ids.pin_memory().to(self.device, non_blocking=True)
+        return ids.to(self.device)
 
     def frame_batch(self, it):
         return self.frame_batch_at(*divmod(it, self.iters_per_epoch()))

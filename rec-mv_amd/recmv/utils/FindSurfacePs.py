@@ -65,11 +65,19 @@ def _streams(device, n):
 class _RootState:
     """One garment's root-finding iteration on the graph-free passes: per step two C calls for the SDF net (value +
     input gradient), four for the deformer (offset MLP, fused skinning + ray energy, and their VJPs) and one fused
-    stopping-test / update kernel.  All rays are carried through every step (rows of the kernels are independent, so
-    the active rays get the same updates); finished rays are simply not updated.  The post-update check of step i is
-    the forward pass of step i+1, evaluated once.  The early exit polls the unfinished-ray count of an earlier step
-    (pinned host copy + event query) and never blocks the host; the extra evaluations this can cost change nothing
-    (no unfinished ray = no update)."""
+    stopping-test / update kernel — about 55 launches on a few thousand rays.  All rays are carried through every step
+    (rows of the kernels are independent, so the active rays get the same updates); finished rays are simply not
+    updated.  The post-update check of step i is the forward pass of step i+1, evaluated once.
+
+    Every step is the SAME sequence of launches on the same buffers (the step index lives on the device,
+    recmv_rootfind_step).  With `RECMV_ROOT_GRAPH=1` the first step runs eagerly, the second is captured into a hipGraph
+    and the remaining ones replay it; on ROCm 7.2 that is SLOWER than the plain launches (capture + instantiate per
+    iteration and a replay that costs about as much as the launches: 149.9 vs 131.4 ms per iteration), so it is off by
+    default; results are bit-identical either way.
+    The early exit polls a pinned copy of the per-step unfinished-ray marks and never blocks the host; the extra steps
+    this can cost change nothing (no unfinished ray = no update)."""
+
+    _pools = {}      # one graph memory pool per stream: the garments' graphs replay concurrently and must not share blocks
 
     def __init__(self, cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds, smpl_conds, name,
                  dthreshold, athreshold, w1, w2, times, stream):
@@ -79,6 +87,8 @@ class _RootState:
         self.times, self.it, self.finished = times, 0, False
         self.tmpSdf, self.deformer, self.ratio, self.name = tmpSdf, deformer, ratio, name
         self.conds = [defconds, smpl_conds]
+        self.graph = None
+        self.use_graph = os.environ.get('RECMV_ROOT_GRAPH', '0') == '1'
         with torch.cuda.stream(stream):
             self.p = initTmpPs.detach().clone().contiguous()
             P = self.p.shape[0]
@@ -86,41 +96,74 @@ class _RootState:
             self.rays = rays.detach().contiguous()
             self.frame = batch_inds.contiguous()
             self.unfinished = torch.ones(P, dtype=torch.uint8, device=dev)
-            self.counters = torch.zeros(times + 1, dtype=torch.int32, device=dev)
-        self.host = torch.zeros(times + 1, dtype=torch.int32).pin_memory()
-        self.events = []
+            # [counters | marks | state]: unfinished rays per step, the same + 1 once the step has run, the step index
+            self.ints = torch.zeros(2 * (times + 2) + 1, dtype=torch.int32, device=dev)
+        self.counters = self.ints[:times + 2]
+        self.marks = self.ints[times + 2:2 * (times + 2)]
+        self.state = self.ints[2 * (times + 2):]
+        self.host = torch.zeros(times + 2, dtype=torch.int32).pin_memory()
         self.sdf_chain = tmpSdf.chain(tmpSdf._pe_weights(ratio), need_t=True)
         assert tmpSdf.d_out == 1
+        if P == 0:
+            self.finished = True
+
+    def _enqueue(self):
+        """One step on the current stream — identical every time it is called."""
+        from .. import chains
+        dthr, athr, w1, w2 = self.args
+        p = self.p
+        f = self.sdf_chain.forward(p, n_out=1, keep=True)
+        gf = self.sdf_chain.vjp_input(p, None)
+        _, loss2, angle, gd = self.deformer.ray_energy_and_vjp(p, self.conds, self.frame, self.cam, self.rays,
+                                                               ratio=self.ratio, offset_type=self.name)
+        chains.rootfind_step(p, f, gf, loss2, angle, gd, self.unfinished, self.counters, self.marks, self.state, dthr,
+                             athr, w1, w2, self.times)
+        self.host.copy_(self.marks, non_blocking=True)
 
     def step(self):
         """Enqueue one iteration on this garment's stream; returns False once the iteration is over."""
-        from .. import chains
         if self.finished:
             return False
         it = self.it
-        if it >= 2 and self.events[it - 2].query() and int(self.host[it - 2]) == 0:
-            # early exit, never waited for: the count of step it-2 is looked at only if it has already arrived (the
-            # host keeps queueing — it has other streams to feed); a step queued past the end changes nothing
+        if it >= 1 and any(int(m) == 1 for m in self.host[:it]):
+            # early exit, never waited for: a step whose mark has already arrived and says "no unfinished ray"; the
+            # host keeps queueing otherwise (it has other streams to feed); a step queued past the end changes nothing
             self.finished = True
             return False
         if it > self.times:
             self.finished = True
             return False
-        dthr, athr, w1, w2 = self.args
         with torch.cuda.stream(self.stream):
-            p = self.p
-            f = self.sdf_chain.forward(p, n_out=1, keep=True)
-            gf = self.sdf_chain.vjp_input(p, None)
-            _, loss2, angle, gd = self.deformer.ray_energy_and_vjp(p, self.conds, self.frame, self.cam, self.rays,
-                                                                   ratio=self.ratio, offset_type=self.name)
-            chains.rootfind_update(p, f, gf, loss2, angle, gd, self.unfinished, self.counters[it:it + 1], dthr, athr,
-                                   w1, w2, it < self.times)
-            self.host[it:it + 1].copy_(self.counters[it:it + 1], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            self.events.append(ev)
+            if not self.use_graph or it == 0:
+                self._enqueue()                       # (the first step also warms every cache the sequence touches)
+            else:
+                if self.graph is None:
+                    keep = _RootState._pools.get(self.stream.cuda_stream)
+                    if keep is None:
+                        # the allocator drops a pool with its last graph: a one-node graph that is never replayed keeps
+                        # this stream's pool (and the blocks the per-iteration graphs reuse) alive
+                        pool = torch.cuda.graph_pool_handle()
+                        k = torch.cuda.CUDAGraph()
+                        k.capture_begin(pool=pool, capture_error_mode="thread_local")
+                        try:
+                            k_t = torch.zeros(1, device=self.p.device)
+                        finally:
+                            k.capture_end()
+                        keep = _RootState._pools[self.stream.cuda_stream] = (pool, k, k_t)
+                    pool = keep[0]
+                    g = torch.cuda.CUDAGraph()
+                    g.capture_begin(pool=pool, capture_error_mode="thread_local")
+                    try:
+                        self._enqueue()
+                    finally:
+                        g.capture_end()
+                    self.graph = g
+                self.graph.replay()
         self.it += 1
         return True
+
+    def steps_trace(self):
+        return [int(m) - 1 for m in self.host[:self.it]]
 
     def result(self):
         return self.p, self.unfinished == 0
@@ -178,7 +221,7 @@ def _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, 
         ok.record_stream(main)
         if os.environ.get('RECMV_ROOT_TRACE'):
             torch.cuda.synchronize()
-            print('rootfind unfinished per step:', st.host[:len(st.events)].tolist(), flush=True)
+            print('rootfind unfinished per step:', st.steps_trace(), flush=True)
         outs.append(p)
         oks.append(ok)
     return outs, oks

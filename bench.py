@@ -445,6 +445,7 @@ def main():
     rdist.barrier()
     elapsed = time.perf_counter() - t0
     gs = prof.end() if prof else {}
+    small_launches = prof.small if prof else None
     alt = None
     if not args.no_alt_mode:
         # the same loop in the OTHER matrix mode, a short extra run outside the timed region (not part of `value`)
@@ -471,6 +472,23 @@ def main():
         alt = dict(gemm_mode=other, steps=n_alt, value=round(n_alt * world / alt_elapsed, 4), unit="iters/s",
                    ms_per_step=round(alt_elapsed / n_alt * 1e3, 3),
                    note="same loop, other matrix mode, short run after the timed region (no re-mesh inside)")
+    gs_serial = None
+    if prof and not args.no_alt_mode:
+        # the MFMA kernels once more with the iteration in the reference's serial order (RECMV_SERIAL=1: one stream, no
+        # other kernel beside them): their duration as kernels, next to their duration inside the overlapped loop
+        os.environ["RECMV_SERIAL"] = "1"
+        try:
+            loop.step(it, allreduce)
+            it += 1
+            torch.cuda.synchronize()
+            prof.begin()
+            for _ in range(max(2, min(5, args.steps))):
+                loop.step(it, allreduce)
+                it += 1
+            torch.cuda.synchronize()
+            gs_serial = prof.end()
+        finally:
+            del os.environ["RECMV_SERIAL"]
     per_rank_ms, allreduce_us = None, None
     if world > 1:
         mine = elapsed
@@ -550,7 +568,16 @@ def main():
                                 "other_variants": {k: {"launches": v["launches"], "avg_launch_us": round(v["avg_us"], 2),
                                                        "achieved": round(v["flops"] / v["seconds"] / 1e12, 3)}
                                                    for k, v in gs.items() if k != dom},
-                                "untimed_small_launches": prof.small}
+                                "untimed_small_launches": small_launches}
+            if gs_serial and dom in gs_serial:
+                a = gs_serial[dom]
+                line["roofline"]["serial_order"] = {
+                    "achieved": round(a["flops"] / a["seconds"] / 1e12, 3),
+                    "frac": round(a["flops"] / a["seconds"] / MFMA_F32_PEAK, 4), "launches": a["launches"],
+                    "avg_launch_us": round(a["avg_us"], 2), "avg_launch_gflop": round(a["avg_flops"] / 1e9, 3),
+                    "note": "the same kernel in a short pass with the iteration in the reference's serial order on one "
+                            "stream (RECMV_SERIAL=1), i.e. alone on the device; in the timed region the ray pipeline and "
+                            "the curve branch run beside it on other streams and share the CUs with it"}
         step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
         plain = [m for k, m in enumerate(step_ms) if k not in remesh_steps]
         with_r = [step_ms[k] for k in remesh_steps]

@@ -107,6 +107,62 @@ __global__ __launch_bounds__(kBlk) void gs3d_fwd_kernel(int64_t nthreads, const 
   }
 }
 
+// Forward for a channels-last f32 volume, one WAVE per (64 consecutive points, group of 4 channels): the workgroup's C/4
+// waves share the points (and, through the CU's L1, their 8 corner records); each lane has its 8 sixteen-byte loads in
+// flight at once instead of walking the channel groups one dependent round after the other, and the chip holds C/4
+// times as many of them.  The arithmetic per output element is the one of gs3d_fwd_kernel (same fma chain over the
+// corners): bit-identical.  Output stores are one coalesced run per channel (points along lanes).
+__global__ __launch_bounds__(1024) void gs3d_fwd_cg_kernel(int64_t nthreads, const float* __restrict__ input,
+                                                           Desc5 in, const float* __restrict__ grid, Desc5 gr,
+                                                           float* __restrict__ output, Desc5 out) {
+  const int64_t D = in.size[2], H = in.size[3], W = in.size[4];
+  const int64_t oD = gr.size[1], oH = gr.size[2], oW = gr.size[3];
+  const int lane = threadIdx.x & 63, ch = (threadIdx.x >> 6) * 4;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < nthreads; base += (int64_t)gridDim.x * 64) {
+    const int64_t index = base + lane;
+    if (index >= nthreads) continue;
+    int64_t w, h, d, n;
+    if (oD * oH == 1 && nthreads < (1ll << 31)) {      // a list of points per batch item: 32-bit index arithmetic
+      const unsigned iw = (unsigned)index, uw = (unsigned)oW;
+      n = iw / uw;
+      w = iw - (unsigned)n * uw;
+      h = d = 0;
+    } else {
+      w = index % oW, h = (index / oW) % oH, d = (index / (oH * oW)) % oD, n = index / (oD * oH * oW);
+    }
+    const float* g = grid + n * gr.stride[0] + d * gr.stride[1] + h * gr.stride[2] + w * gr.stride[3];
+    const Cell<float> c = make_cell<float>(g[0], g[gr.stride[4]], g[2 * gr.stride[4]], W, H, D);
+    const float* inp = input + n * in.stride[0] + ch;
+    float4 val[8];
+    float wgt[8];
+    bool inb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      RECMV_CORNER_BITS(k);
+      wgt[k] = c.fx[bx] * c.fy[by] * c.fz[bz];
+      inb[k] = c.in_x[bx] && c.in_y[by] && c.in_z[bz];
+      const int64_t off = (int64_t)(c.z0 + bz) * in.stride[2] + (int64_t)(c.y0 + by) * in.stride[3] +
+                          (int64_t)(c.x0 + bx) * in.stride[4];
+      if (inb[k]) val[k] = *reinterpret_cast<const float4*>(inp + off);
+    }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (inb[k]) {
+        a0 = fma(val[k].x, wgt[k], a0);
+        a1 = fma(val[k].y, wgt[k], a1);
+        a2 = fma(val[k].z, wgt[k], a2);
+        a3 = fma(val[k].w, wgt[k], a3);
+      }
+    float* o = output + n * out.stride[0] + d * out.stride[2] + h * out.stride[3] + w * out.stride[4] +
+               ch * out.stride[1];
+    o[0] = a0;
+    o[out.stride[1]] = a1;
+    o[2 * out.stride[1]] = a2;
+    o[3 * out.stride[1]] = a3;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
@@ -326,7 +382,16 @@ extern "C" int recmv_grid_sample3d_forward(const void* input, const recmv_tensor
   hipStream_t s = (hipStream_t)stream;
   const int g = stream_grid(count, kBlk);
   if (dtype == RECMV_F32) {
-    if (vec4_ok(input, in, dtype))
+    // the wave-per-channel-group kernel wins while the launch is latency-bound (18 vs 24 us at 153 k surface-coherent
+    // points, 35 vs 111 us on random ones); past ~3e5 points the one-lane-per-point kernel amortises the per-point
+    // geometry better (30 vs 44 us at 461 k) — profiles/r02_kernel_only_v2_sampler_cg.txt
+    if (vec4_ok(input, in, dtype) && in.size[1] <= 64 && count >= 4096 && count <= 300000) {
+      const int waves = (int)(in.size[1] / 4);
+      const int64_t blocks = ceil_div(count, (int64_t)64);
+      const int64_t cap = (int64_t)kNumCU * (32 / waves > 0 ? 32 / waves : 1) * 2;
+      hipLaunchKernelGGL(gs3d_fwd_cg_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(64 * waves), 0, s, count,
+                         (const float*)input, in, (const float*)grid, gr, (float*)output, out);
+    } else if (vec4_ok(input, in, dtype))
       hipLaunchKernelGGL((gs3d_fwd_kernel<float, 4>), dim3(g), dim3(kBlk), 0, s, count,
                          (const float*)input, in, (const float*)grid, gr, (float*)output, out);
     else

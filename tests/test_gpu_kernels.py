@@ -493,9 +493,12 @@ def bf16x6_mode():
         L.lib().recmv_set_gemm_mode(prev)
 
 
-@pytest.mark.parametrize("M,N,K", [(5, 3, 39), (300, 473, 512), (4096, 512, 512), (129, 130, 167), (20000, 512, 512)])
+@pytest.mark.parametrize("M,N,K", [(5, 3, 39), (300, 473, 512), (4096, 512, 512), (129, 130, 167), (20000, 512, 512),
+                                   (70001, 512, 40), (33000, 257, 168), (16400, 473, 36)])
 def test_gemm_nt_bf16x6_same_bound_as_f32(bf16x6_mode, M, N, K):
-    """The six-product bf16 split meets the SAME error bound vs fp64 as the exact-f32 MFMA path."""
+    """The six-product bf16 split meets the SAME error bound vs fp64 as the exact-f32 MFMA path.  The last four shapes
+    take the staged-split 128x128 kernel (gemm_nt_b3_kernel): whole K-tiles, a K tail, a single short K-tile, ragged
+    M and N."""
     from recmv import ops
     g = torch.Generator().manual_seed(M + 3 * N)
     A = torch.randn(M, K, generator=g) * torch.logspace(-3, 2, M).view(-1, 1)      # rows over 5 decades
@@ -518,3 +521,62 @@ def test_gemm_tn_bf16x6_same_bound_as_f32(bf16x6_mode, K, M, N):
     bound = 4e-7 * (A.abs().double().t() @ B.abs().double()) + 1e-6
     assert ((out.cpu().double() - ref).abs() <= bound).all()
     assert torch.equal(out, ops.gemm_tn(gpu(A), gpu(B)))
+
+
+# ------------------------------------------------------------------------------------------ ray-path pieces of round 2
+def test_act_grad_2d_vector_and_scalar_paths_agree():
+    """recmv_act_grad_2d: the float4 path (aligned, widths % 4 == 0) and the element path give the same numbers, both
+    equal to g * act'(y) in torch (softplus beta=100: act'(z) = 1 - exp(-beta y))."""
+    import ctypes as C
+    from recmv import _lib as L
+    from recmv import ops
+    g0 = torch.Generator().manual_seed(5)
+    P, Cw = 3001, 512
+    gy = gpu(torch.randn(P, Cw, generator=g0))
+    y = gpu(torch.rand(P, Cw, generator=g0) * 0.05)
+    want = 0.5 * gy * (-torch.expm1(-100.0 * 1.25 * y))
+    outs = []
+    for ld in (Cw, Cw + 1):                     # ld 513: rows lose their 16-byte alignment -> element path
+        buf_g = torch.zeros(P, ld, device=gy.device)
+        buf_y = torch.zeros(P, ld, device=gy.device)
+        buf_o = torch.zeros(P, ld, device=gy.device)
+        buf_g[:, :Cw], buf_y[:, :Cw] = gy, y
+        L.check(L.lib().recmv_act_grad_2d(L.ptr(buf_g), ld, L.ptr(buf_y), ld, L.ptr(buf_o), ld, P, Cw, ops.ACT_SOFTPLUS,
+                                          100.0, 1.25, 0.5, L.stream_ptr(gy.device)), "act_grad_2d")
+        outs.append(buf_o[:, :Cw].clone())
+    assert torch.equal(outs[0], outs[1])
+    assert torch.allclose(outs[0], want, rtol=2e-6, atol=1e-7)
+    # one cotangent row for every point (row stride 0)
+    row = gpu(torch.randn(Cw, generator=g0))
+    out = torch.empty(P, Cw, device=gy.device)
+    L.check(L.lib().recmv_act_grad_2d(L.ptr(row), 0, L.ptr(y), Cw, L.ptr(out), Cw, P, Cw, ops.ACT_SOFTPLUS, 100.0, 1.0, 1.0,
+                                      L.stream_ptr(gy.device)), "act_grad_2d")
+    assert torch.allclose(out, row.view(1, -1) * (-torch.expm1(-100.0 * y)), rtol=2e-6, atol=1e-7)
+
+
+def test_rootfind_step_equals_rootfind_update():
+    """recmv_rootfind_step (step index on the device, marks for a polling host) performs exactly recmv_rootfind_update's
+    arithmetic: same points, flags and counts over several steps, the last one without an update (step == times)."""
+    from recmv import chains
+    g0 = torch.Generator().manual_seed(11)
+    P, times = 5000, 2
+    p0 = torch.randn(P, 3, generator=g0)
+    un0 = (torch.rand(P, generator=g0) < 0.9).to(torch.uint8)
+    steps = []
+    for _ in range(times + 1):
+        f = torch.randn(P, generator=g0) * 1e-4
+        steps.append((f, torch.randn(P, 3, generator=g0), torch.rand(P, generator=g0), torch.rand(P, generator=g0) * 0.05,
+                      torch.randn(P, 3, generator=g0)))
+    pa, ua = gpu(p0.clone()), gpu(un0.clone())
+    pb, ub = gpu(p0.clone()), gpu(un0.clone())
+    cnt_a = torch.zeros(times + 2, dtype=torch.int32, device=pa.device)
+    ints = torch.zeros(2 * (times + 2) + 1, dtype=torch.int32, device=pa.device)
+    counters, marks, state = ints[:times + 2], ints[times + 2:2 * (times + 2)], ints[2 * (times + 2):]
+    for it, (f, gf, l2, ang, gd) in enumerate(steps):
+        args = [gpu(t) for t in (f, gf, l2, ang, gd)]
+        chains.rootfind_update(pa, *args, ua, cnt_a[it:it + 1], 5e-5, 0.02, 3.05, 1.0, it < times)
+        chains.rootfind_step(pb, *args, ub, counters, marks, state, 5e-5, 0.02, 3.05, 1.0, times)
+        assert int(state[0]) == it + 1
+    assert torch.equal(pa, pb) and torch.equal(ua, ub)
+    assert torch.equal(cnt_a[:times + 1], counters[:times + 1])
+    assert torch.equal(marks[:times + 1], counters[:times + 1] + 1) and int(marks[times + 1]) == 0

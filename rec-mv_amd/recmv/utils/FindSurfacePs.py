@@ -102,6 +102,7 @@ class _RootState:
         self.marks = self.ints[times + 2:2 * (times + 2)]
         self.state = self.ints[2 * (times + 2):]
         self.host = torch.zeros(times + 2, dtype=torch.int32).pin_memory()
+        self.host_np = self.host.numpy()          # the same pinned words, read without creating tensors
         self.sdf_chain = tmpSdf.chain(tmpSdf._pe_weights(ratio), need_t=True)
         assert tmpSdf.d_out == 1
         if P == 0:
@@ -125,7 +126,7 @@ class _RootState:
         if self.finished:
             return False
         it = self.it
-        if it >= 1 and any(int(m) == 1 for m in self.host[:it]):
+        if it >= 1 and bool((self.host_np[:it] == 1).any()):
             # early exit, never waited for: a step whose mark has already arrived and says "no unfinished ray"; the
             # host keeps queueing otherwise (it has other streams to feed); a step queued past the end changes nothing
             self.finished = True
@@ -163,7 +164,7 @@ class _RootState:
         return True
 
     def steps_trace(self):
-        return [int(m) - 1 for m in self.host[:self.it]]
+        return [int(m) - 1 for m in self.host_np[:self.it]]
 
     def result(self):
         return self.p, self.unfinished == 0

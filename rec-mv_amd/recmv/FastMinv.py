@@ -13,7 +13,7 @@ def Fast3x3Minv(ms):
     N = ms.size(0)
     invs = torch.empty((N, 3, 3), dtype=ms.dtype, device=ms.device)
     checks = torch.empty((N,), dtype=torch.bool, device=ms.device)
-    with torch.cuda.device(ms.device):
+    with L.device_guard(ms.device):
         L.check(L.lib().recmv_inv3x3_forward(L.ptr(ms), L.ptr(invs), L.ptr(checks), N, L.dtype_code(ms),
                                              L.stream_ptr(ms.device)), "Fast3x3Minv")
     return [invs, checks]
@@ -31,7 +31,7 @@ def Fast3x3Minv_backward(grads, invs):
         raise RuntimeError("invs must have same type with grads")
     N = invs.size(0)
     outs = torch.empty((N, 3, 3), dtype=invs.dtype, device=invs.device)
-    with torch.cuda.device(invs.device):
+    with L.device_guard(invs.device):
         L.check(L.lib().recmv_inv3x3_backward(L.ptr(grads), L.ptr(invs), L.ptr(outs), N, L.dtype_code(invs),
                                               L.stream_ptr(invs.device)), "Fast3x3Minv_backward")
     return outs

@@ -40,7 +40,7 @@ def forward(input, grid, interpolation_mode, padding_mode):
     N, C = input.size(0), input.size(1)
     out = torch.empty((N, C, grid.size(1), grid.size(2), grid.size(3)), dtype=input.dtype, device=input.device)
     di, dg, do = L.desc5(input), L.desc5(grid), L.desc5(out)
-    with torch.cuda.device(input.device):
+    with L.device_guard(input.device):
         L.check(L.lib().recmv_grid_sample3d_forward(L.ptr(input), di, L.ptr(grid), dg, L.ptr(out), do,
                                                     interpolation_mode, padding_mode, L.dtype_code(input),
                                                     L.stream_ptr(input.device)), "GridSamplerMine.forward")
@@ -53,7 +53,7 @@ def backward(input, grid, grad_output, interpolation_mode, padding_mode, need_gr
     grad_grid = torch.empty(grid.shape, dtype=grid.dtype, device=grid.device)  # contiguous
     di, dg, dgo = L.desc5(input), L.desc5(grid), L.desc5(grad_output)
     dgi = L.desc5(grad_input) if grad_input is not None else di
-    with torch.cuda.device(input.device):
+    with L.device_guard(input.device):
         L.check(L.lib().recmv_grid_sample3d_backward(L.ptr(input), di, L.ptr(grid), dg, L.ptr(grad_output), dgo,
                                                      L.ptr(grad_input), dgi, L.ptr(grad_grid),
                                                      interpolation_mode, padding_mode, L.dtype_code(input),
@@ -71,7 +71,7 @@ def dbackward(grad_output_input, grad_output_grid, input, grid, grad_output, int
     dgI = L.desc5(grad_output_input) if grad_output_input is not None else di
     dgG = L.desc5(grad_output_grid)
     dgi = L.desc5(grad_input) if grad_input is not None else di
-    with torch.cuda.device(input.device):
+    with L.device_guard(input.device):
         L.check(L.lib().recmv_grid_sample3d_dbackward(
             L.ptr(grad_output_input), dgI, L.ptr(grad_output_grid), dgG, L.ptr(input), di, L.ptr(grid), dg,
             L.ptr(grad_output), dgo, L.ptr(grad_input), dgi, L.ptr(grad_grid), L.ptr(ggo), L.desc5(ggo),

@@ -172,7 +172,7 @@ class Seg3dLossless(nn.Module):
         done = [torch.full((words(D * H * W),), -1, dtype=torch.int32, device=dev) for _ in range(K)]   # level 0: all
         keep = self.query_func
         try:
-            with torch.cuda.device(dev):
+            with L.device_guard(dev):
                 st = lambda: L.stream_ptr(dev)
                 for res in self.resolutions[1:]:
                     W, H, D = (int(v) for v in res)

@@ -57,7 +57,7 @@ def mc_gpu(sdfs, xstep=1.0, ystep=1.0, zstep=1.0, xmin=0.0, ymin=0.0, zmin=0.0, 
         return []
     nx, ny, nz = sdfs.shape
     lib = L.lib()
-    with torch.cuda.device(sdfs.device):
+    with L.device_guard(sdfs.device):
         nbytes = int(lib.recmv_mc_workspace_bytes(nx, ny, nz))
         if nbytes <= 0:
             raise RuntimeError(f"mc_gpu: volume {tuple(sdfs.shape)} is outside the supported range "

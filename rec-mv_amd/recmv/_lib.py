@@ -167,8 +167,39 @@ def check(rc: int, what: str = ""):
         raise RuntimeError(f"{what or 'recmv'}: {msg} (code {rc})")
 
 
+def raw_stream(device) -> int:
+    """The current HIP stream of `device` as a raw handle (no Stream object: this runs once per launch)."""
+    idx = device.index
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice() if idx is None else idx)
+
+
 def stream_ptr(device) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return C.c_void_p(raw_stream(device))
+
+
+class device_guard:
+    """`with torch.cuda.device(dev)` for the launch wrappers, free when `dev` already is the current device (the usual
+    case: one process per GPU) — the torch context manager costs two device-index resolutions per launch."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = device.index
+        self.prev = -1
+
+    def __enter__(self):
+        idx = self.idx
+        if idx is not None:
+            cur = torch._C._cuda_getDevice()
+            if cur != idx:
+                self.prev = cur
+                torch._C._cuda_setDevice(idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch._C._cuda_setDevice(self.prev)
+            self.prev = -1
+        return False
 
 
 def ptr(t) -> C.c_void_p:

@@ -69,7 +69,7 @@ class MlpChain:
             ld_cond = cond.stride(0)
             if cond_index is not None:
                 assert cond_index.dtype == torch.int64 and cond_index.is_contiguous() and cond_index.numel() == P
-        with torch.cuda.device(x.device):
+        with L.device_guard(x.device):
             L.check(L.lib().recmv_mlp_forward(C.byref(self.m), L.ptr(x), L.ptr(cond), ld_cond, L.ptr(cond_index), P,
                                               n_out, L.ptr(out), out.stride(0) if P > 1 else n_out, L.ptr(ws), ws.numel(),
                                               int(keep), L.stream_ptr(x.device)), "mlp_forward")
@@ -85,7 +85,7 @@ class MlpChain:
         if g_out is not None:
             assert g_out.dtype == torch.float32 and g_out.stride(1) == 1 and g_out.shape == (P, n_out)
             ldg = g_out.stride(0) if P > 1 else n_out
-        with torch.cuda.device(x.device):
+        with L.device_guard(x.device):
             L.check(L.lib().recmv_mlp_vjp_input(C.byref(self.m), L.ptr(x), P, n_out, L.ptr(g_out), ldg, L.ptr(gx),
                                                 L.ptr(ws), ws.numel(), L.stream_ptr(x.device)), "mlp_vjp_input")
         return gx
@@ -114,7 +114,7 @@ def lbs_forward(ps, frame, A, trans, grid, cam=None, rays=None):
         loss2 = torch.empty(P, dtype=torch.float32, device=dev)
         angle = torch.empty(P, dtype=torch.float32, device=dev)
         g_d = torch.empty((P, 3), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         L.check(L.lib().recmv_lbs_forward(L.ptr(ps), L.ptr(frame), P, L.ptr(A), L.ptr(trans), B, C.byref(grid),
                                           L.ptr(cam), L.ptr(rays), L.ptr(d), L.ptr(loss2), L.ptr(angle), L.ptr(g_d),
                                           L.stream_ptr(dev)), "lbs_forward")
@@ -124,14 +124,14 @@ def lbs_forward(ps, frame, A, trans, grid, cam=None, rays=None):
 def lbs_vjp_input(ps, frame, A, grid, g_d):
     P, B = ps.shape[0], A.shape[0]
     g_p = torch.empty((P, 3), dtype=torch.float32, device=ps.device)
-    with torch.cuda.device(ps.device):
+    with L.device_guard(ps.device):
         L.check(L.lib().recmv_lbs_vjp_input(L.ptr(ps), L.ptr(frame), P, L.ptr(A), B, C.byref(grid), L.ptr(g_d),
                                             L.ptr(g_p), L.stream_ptr(ps.device)), "lbs_vjp_input")
     return g_p
 
 
 def rootfind_update(p, f, gf, loss2, angle, gd, unfinished, counter, dthreshold, athreshold, w1, w2, do_update):
-    with torch.cuda.device(p.device):
+    with L.device_guard(p.device):
         L.check(L.lib().recmv_rootfind_update(L.ptr(p), L.ptr(f), L.ptr(gf), L.ptr(loss2), L.ptr(angle), L.ptr(gd),
                                               L.ptr(unfinished), L.ptr(counter), p.shape[0], float(dthreshold),
                                               float(athreshold), float(w1), float(w2), int(do_update),
@@ -140,7 +140,7 @@ def rootfind_update(p, f, gf, loss2, angle, gd, unfinished, counter, dthreshold,
 
 def rootfind_step(p, f, gf, loss2, angle, gd, unfinished, counters, marks, state, dthreshold, athreshold, w1, w2, times):
     """recmv_rootfind_step: the update with its step index on the device (every step is the same launch)."""
-    with torch.cuda.device(p.device):
+    with L.device_guard(p.device):
         L.check(L.lib().recmv_rootfind_step(L.ptr(p), L.ptr(f), L.ptr(gf), L.ptr(loss2), L.ptr(angle), L.ptr(gd),
                                             L.ptr(unfinished), L.ptr(counters), L.ptr(marks), L.ptr(state), p.shape[0],
                                             float(dthreshold), float(athreshold), float(w1), float(w2), int(times),
@@ -197,7 +197,7 @@ class MlpJet(torch.autograd.Function):
         if cond_d is not None:
             assert cond_d.dim() == 2 and cond_d.stride(1) == 1 and cond_d.dtype == torch.float32
         eye = _eye(dev)
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             L.check(lib.recmv_mlp_jet_forward(C.byref(ch.m), L.ptr(xd), L.ptr(cond_d), ld_cond, L.ptr(cidx), L.ptr(eye),
                                               P, n_j, L.ptr(y), n_out, L.ptr(tang), L.ptr(ws), ws.numel(),
                                               L.stream_ptr(dev)), "mlp_jet_forward")
@@ -229,7 +229,7 @@ class MlpJet(torch.autograd.Function):
         g_in = torch.empty((4 * P, ld_in), dtype=torch.float32, device=dev) if want_cond else None
         gx = torch.empty((P, 3), dtype=torch.float32, device=dev) if need[1] else None
         eye = _eye(dev)
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             L.check(lib.recmv_mlp_jet_backward(C.byref(ch.m), L.ptr(xd), L.ptr(eye), P, n_j, L.ptr(gy),
                                                gy.stride(0) if gy is not None else 0, L.ptr(gtang),
                                                C.cast(gW_arr, C.c_void_p), C.cast(gb_arr, C.c_void_p), L.ptr(g_in),
@@ -277,7 +277,7 @@ def lbs_vjp_params(ps, frame, A_shape, grid, g_d):
     Q = torch.empty((P, B * 12), dtype=torch.float32, device=dev)
     Gs = torch.empty((P, B * 3), dtype=torch.float32, device=dev)
     lib = L.lib()
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         L.check(lib.recmv_lbs_vjp_params_stage(L.ptr(ps), L.ptr(frame), P, B, C.byref(grid), L.ptr(g_d), L.ptr(W),
                                                L.ptr(Q), L.ptr(Gs), L.stream_ptr(dev)), "lbs_vjp_params_stage")
         gAm = ops.gemm_tn(W, Q)                                            # [24, B*12]

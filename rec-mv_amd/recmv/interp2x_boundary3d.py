@@ -10,7 +10,7 @@ def forward(input, balance_value):
     B, C, d, h, w = input.shape
     out = torch.empty((B, C, 2 * d - 1, 2 * h - 1, 2 * w - 1), dtype=input.dtype, device=input.device)
     bnd = torch.empty(out.shape, dtype=torch.bool, device=input.device)
-    with torch.cuda.device(input.device):
+    with L.device_guard(input.device):
         L.check(L.lib().recmv_interp2x_boundary3d_forward(L.ptr(input), L.ptr(out), L.ptr(bnd), B * C, d, h, w,
                                                           float(balance_value), L.dtype_code(input),
                                                           L.stream_ptr(input.device)), "interp2x_boundary3d.forward")
@@ -23,7 +23,7 @@ def backward(grad_output):
     B, C, D, H, W = grad_output.shape
     gi = torch.empty((B, C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2), dtype=grad_output.dtype,
                      device=grad_output.device)
-    with torch.cuda.device(grad_output.device):
+    with L.device_guard(grad_output.device):
         L.check(L.lib().recmv_interp2x_boundary3d_backward(L.ptr(grad_output), L.ptr(gi), B * C, D, H, W,
                                                            L.dtype_code(grad_output),
                                                            L.stream_ptr(grad_output.device)),

@@ -49,7 +49,7 @@ class KinematicChain(torch.autograd.Function):
         G = torch.empty((B, 24, 4, 4), dtype=torch.float32, device=poses.device)
         A = torch.empty_like(G) if init_pose is not None else None
         ip = init_pose.detach().contiguous() if init_pose is not None else None
-        with torch.cuda.device(poses.device):
+        with L.device_guard(poses.device):
             L.check(L.lib().recmv_kinematic_chain_forward(L.ptr(poses_c), js_host, parents_host, L.ptr(ip), L.ptr(G),
                                                           L.ptr(A), B, L.stream_ptr(poses.device)), "kinematic_chain")
         ctx.save_for_backward(poses_c, ip)
@@ -67,7 +67,7 @@ class KinematicChain(torch.autograd.Function):
         gG = gG.contiguous() if gG is not None else None
         gA = gA.contiguous() if (gA is not None and ip is not None) else None
         gp = torch.empty_like(poses_c)
-        with torch.cuda.device(poses_c.device):
+        with L.device_guard(poses_c.device):
             L.check(L.lib().recmv_kinematic_chain_backward(L.ptr(poses_c), js_host, parents_host, L.ptr(ip), L.ptr(gG),
                                                            L.ptr(gA), L.ptr(gp), poses_c.shape[0],
                                                            L.stream_ptr(poses_c.device)), "kinematic_chain_backward")

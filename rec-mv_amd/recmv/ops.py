@@ -25,7 +25,7 @@ _lb_ws = {}
 
 
 def _ws_key(dev):
-    return (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    return (dev.index, L.raw_stream(dev))
 
 
 def transposed(W):
@@ -34,17 +34,15 @@ def transposed(W):
     recorded behind the transpose, and a hit from another stream waits for it."""
     hit = getattr(W, "_recmv_t", None)
     if hit is not None and hit[0] == W._version:
-        if hit[2] is not None:
-            cur = torch.cuda.current_stream(W.device)
-            if cur.cuda_stream != hit[3]:
-                cur.wait_event(hit[2])
+        if hit[2] is not None and L.raw_stream(W.device) != hit[3]:
+            torch.cuda.current_stream(W.device).wait_event(hit[2])
         return hit[1]
     Wt = W.detach().t().contiguous()
     ev = sid = None
     if W.is_cuda:
         ev = torch.cuda.Event()
         ev.record()
-        sid = torch.cuda.current_stream(W.device).cuda_stream
+        sid = L.raw_stream(W.device)
     try:
         W._recmv_t = (W._version, Wt, ev, sid)
     except Exception:
@@ -70,7 +68,7 @@ def linear_backward(gy, y, x, W, act, act_param, need_gx=True, need_gW=True, nee
     gb = torch.empty((N,), dtype=torch.float32, device=dev) if need_gb else None
     Wt = transposed(W) if need_gx else None
     yd = y.detach() if y is not None else None
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         L.check(lib.recmv_linear_backward(L.ptr(gy), gy.stride(0) if M > 1 else N, L.ptr(yd),
                                           (yd.stride(0) if M > 1 else N) if yd is not None else 0, L.ptr(x),
                                           x.stride(0) if M > 1 else K, L.ptr(Wt), N, M, N, K, act, float(act_param),
@@ -108,7 +106,7 @@ def gemm_nt(A, B, bias=None, act=ACT_NONE, act_param=0.0, out_scale=1.0, out=Non
     lda = A.stride(0) if M > 1 else max(K, 1)
     ldb = B.stride(0) if N > 1 else max(K, 1)
     ldc = out.stride(0) if M > 1 else max(N, 1)
-    with torch.cuda.device(A.device):
+    with L.device_guard(A.device):
         L.check(L.lib().recmv_gemm_nt(L.ptr(A), lda, L.ptr(B), ldb, L.ptr(bias), L.ptr(out), ldc, M, N, K, act,
                                       float(act_param), float(out_scale), L.stream_ptr(A.device)), "gemm_nt")
     return out
@@ -123,7 +121,7 @@ def gemm_tn(A, B):
         raise RuntimeError(f"gemm_tn: reduction dimensions differ ({K} vs {K2})")
     out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     lib = L.lib()
-    with torch.cuda.device(A.device):
+    with L.device_guard(A.device):
         need = int(lib.recmv_gemm_tn_workspace_bytes(M, N, K))
         key = _ws_key(A.device)
         ws = _tn_ws.get(key)
@@ -157,7 +155,7 @@ def posenc(x, multires, weights=None, out_scale=1.0, out=None, ld_fill=None):
     if weights is not None:
         assert len(weights) == 2 * multires
         wbuf = (C.c_float * (2 * multires))(*[float(w) for w in weights])
-    with torch.cuda.device(x.device):
+    with L.device_guard(x.device):
         L.check(L.lib().recmv_posenc_forward(L.ptr(x), x.stride(0) if P > 1 else 3, L.ptr(out), ldo, fill, P,
                                              multires, C.cast(wbuf, C.c_void_p) if wbuf is not None else None,
                                              float(out_scale), L.stream_ptr(x.device)), "posenc")
@@ -291,7 +289,7 @@ def _pe_vjp(x, g, t, multires, weights):
     if t is not None:
         t = t.contiguous()
     P = x.shape[0]
-    with torch.cuda.device(x.device):
+    with L.device_guard(x.device):
         L.check(L.lib().recmv_posenc_vjp(L.ptr(x), 3, L.ptr(g), g.stride(0) if P > 1 else g.shape[1], L.ptr(t), 3,
                                          L.ptr(out), P, multires, _cptr(_wbuf(weights, multires)),
                                          L.stream_ptr(x.device)), "posenc_vjp")
@@ -302,7 +300,7 @@ def _pe_jvp(x, t, multires, weights):
     x, t = x.contiguous(), t.contiguous()
     P = x.shape[0]
     out = torch.empty((P, 3 + 6 * multires), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with L.device_guard(x.device):
         L.check(L.lib().recmv_posenc_jvp(L.ptr(x), 3, L.ptr(t), 3, L.ptr(out), out.shape[1], P, multires,
                                          _cptr(_wbuf(weights, multires)), L.stream_ptr(x.device)), "posenc_jvp")
     return out
@@ -387,7 +385,7 @@ def act_grad(gy, y, act, act_param):
     """gy * act'(z) through y = act(z), no autograd."""
     gy, y = gy.contiguous(), y.contiguous()
     out = torch.empty_like(gy)
-    with torch.cuda.device(gy.device):
+    with L.device_guard(gy.device):
         L.check(L.lib().recmv_act_grad(L.ptr(gy), L.ptr(y), L.ptr(out), out.numel(), act, float(act_param),
                                        L.stream_ptr(gy.device)), "act_grad")
     return out
@@ -402,7 +400,7 @@ class ActGrad(torch.autograd.Function):
         ctx.cfg = (act, act_param)
         gy_c, y_c = gy.detach().contiguous(), y.detach().contiguous()
         out = torch.empty_like(gy_c)
-        with torch.cuda.device(gy.device):
+        with L.device_guard(gy.device):
             L.check(L.lib().recmv_act_grad(L.ptr(gy_c), L.ptr(y_c), L.ptr(out), out.numel(), act, float(act_param),
                                            L.stream_ptr(gy.device)), "act_grad")
         return out
@@ -428,7 +426,7 @@ def act_grad2(a, b, y, act, act_param):
     """a * b * d(act')/dy, no autograd."""
     a_c, b_c, y_c = a.detach().contiguous(), b.detach().contiguous(), y.detach().contiguous()
     out = torch.empty_like(a_c)
-    with torch.cuda.device(a.device):
+    with L.device_guard(a.device):
         L.check(L.lib().recmv_act_grad2(L.ptr(a_c), L.ptr(b_c), L.ptr(y_c), L.ptr(out), out.numel(), act,
                                         float(act_param), L.stream_ptr(a.device)), "act_grad2")
     return out
@@ -454,7 +452,7 @@ class WeightNorm(torch.autograd.Function):
         rows, cols = v_c.shape
         W = torch.empty_like(v_c)
         norms = torch.empty(rows, dtype=torch.float32, device=v.device)
-        with torch.cuda.device(v.device):
+        with L.device_guard(v.device):
             L.check(L.lib().recmv_weight_norm_forward(L.ptr(v_c), L.ptr(g_c), L.ptr(W), L.ptr(norms), rows, cols,
                                                       L.stream_ptr(v.device)), "weight_norm")
         ctx.save_for_backward(v_c, g_c, norms)
@@ -467,7 +465,7 @@ class WeightNorm(torch.autograd.Function):
         gW = gW.contiguous()
         gv = torch.empty_like(v)
         gg = torch.empty_like(g)
-        with torch.cuda.device(v.device):
+        with L.device_guard(v.device):
             L.check(L.lib().recmv_weight_norm_backward(L.ptr(v), L.ptr(g), L.ptr(norms), L.ptr(gW), L.ptr(gv),
                                                        L.ptr(gg), v.shape[0], v.shape[1], L.stream_ptr(v.device)),
                     "weight_norm_backward")

@@ -45,7 +45,7 @@ def rasterize_meshes(face_verts, mesh_first_face, mesh_num_faces, image_size, bl
     bary = torch.empty((N, H, W, 1, 3), dtype=torch.float32, device=dev)
     dists = torch.empty((N, H, W, 1), dtype=torch.float32, device=dev)
     lib = L.lib()
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         nbytes = int(lib.recmv_rasterize_meshes_workspace_bytes(N, H, W, F))
         ws = torch.empty(max(nbytes, 64), dtype=torch.uint8, device=dev)
         L.check(lib.recmv_rasterize_meshes(L.ptr(face_verts), L.ptr(mesh_first_face), L.ptr(mesh_num_faces), N, F,
@@ -108,7 +108,7 @@ class _RasterizePoints(torch.autograd.Function):
         zbuf = torch.empty((N, H, W, K), dtype=torch.float32, device=dev)
         dists = torch.empty((N, H, W, K), dtype=torch.float32, device=dev)
         lib = L.lib()
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             nbytes = int(lib.recmv_rasterize_points_workspace_bytes(N, H, W, P, float(radius)))
             if nbytes < 0:
                 raise ValueError("rasterize_points: bad sizes / radius")
@@ -128,7 +128,7 @@ class _RasterizePoints(torch.autograd.Function):
         points, idx, cloud_first, cloud_num = ctx.saved_tensors
         N, H, W, K = idx.shape
         g_points = torch.empty_like(points)
-        with torch.cuda.device(points.device):
+        with L.device_guard(points.device):
             L.check(L.lib().recmv_rasterize_points_backward(
                 L.ptr(points), L.ptr(cloud_first), L.ptr(cloud_num), L.ptr(idx),
                 L.ptr(g_dists.contiguous()) if g_dists is not None else None,
@@ -161,7 +161,7 @@ class _AlphaComposite(torch.autograd.Function):
         N, H, W, K = idx.shape
         C, P = features.shape
         images = torch.empty((N, C, H, W), dtype=torch.float32, device=idx.device)
-        with torch.cuda.device(idx.device):
+        with L.device_guard(idx.device):
             L.check(L.lib().recmv_alpha_composite_forward(L.ptr(idx), L.ptr(alphas), L.ptr(features), N, H, W, K, C, P,
                                                           float(radius2), L.ptr(images), L.stream_ptr(idx.device)),
                     "alpha_composite_forward")
@@ -177,7 +177,7 @@ class _AlphaComposite(torch.autograd.Function):
         C, P = features.shape
         g_alphas = torch.empty_like(alphas)
         g_features = torch.empty_like(features) if ctx.needs_input_grad[2] else None
-        with torch.cuda.device(idx.device):
+        with L.device_guard(idx.device):
             L.check(L.lib().recmv_alpha_composite_backward(
                 L.ptr(idx), L.ptr(alphas), L.ptr(features), L.ptr(g_images.contiguous()), N, H, W, K, C, P,
                 ctx.radius2, L.ptr(g_alphas), L.ptr(g_features) if g_features is not None else None,

@@ -71,9 +71,10 @@ class _RootState:
 
     Every step is the SAME sequence of launches on the same buffers (the step index lives on the device,
     recmv_rootfind_step).  With `RECMV_ROOT_GRAPH=1` the first step runs eagerly, the second is captured into a hipGraph
-    and the remaining ones replay it; on ROCm 7.2 that is SLOWER than the plain launches (capture + instantiate per
-    iteration and a replay that costs about as much as the launches: 149.9 vs 131.4 ms per iteration), so it is off by
-    default; results are bit-identical either way.
+    and the remaining ones replay it.  That cuts the host's share (capture 0.3 ms per garment, replay 32 us per step
+    against ~360 us of launches) but not the step's time on the device — 21 steps take 21 ms on a garment's stream either
+    way (1 ms per step: ~26 products of 23-27 us at 3 k rows), 39 ms beside the mask loss — and the iteration as a whole
+    measured slower with it (149.9 vs 131.4 ms), so it is off by default; results are bit-identical either way.
     The early exit polls a pinned copy of the per-step unfinished-ray marks and never blocks the host; the extra steps
     this can cost change nothing (no unfinished ray = no update)."""
 
@@ -207,11 +208,20 @@ def _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, 
                     streams[g].wait_event(dep)
         states.append(_RootState(cam_pos, rays, initTmpPs, batch_inds, tmpSdf_nets[g], ratio, deformer, defconds,
                                  smpl_conds, name, dthreshold, athreshold, w1, w2, times, streams[g]))
+    trace = bool(os.environ.get('RECMV_ROOT_TRACE'))
+    if trace:
+        for st in states:
+            st.ev0 = torch.cuda.Event(enable_timing=True)
+            st.ev0.record(st.stream)
     live = True
     while live:
         live = False
         for st in states:
             live = st.step() or live
+    if trace:
+        for st in states:
+            st.ev1 = torch.cuda.Event(enable_timing=True)
+            st.ev1.record(st.stream)
     outs, oks = [], []
     for st in states:
         main.wait_stream(st.stream)
@@ -222,7 +232,8 @@ def _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, 
         ok.record_stream(main)
         if os.environ.get('RECMV_ROOT_TRACE'):
             torch.cuda.synchronize()
-            print('rootfind unfinished per step:', st.steps_trace(), flush=True)
+            print('rootfind %d steps on its stream: %.2f ms; unfinished per step:' % (st.it, st.ev0.elapsed_time(st.ev1)),
+                  st.steps_trace(), flush=True)
         outs.append(p)
         oks.append(ok)
     return outs, oks

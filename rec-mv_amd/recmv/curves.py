@@ -111,9 +111,14 @@ def fl_proj_loss(fl_pts_list, gt_fl_pts_list, fl_masks, proj_fl_weights=None):
     """engineer/core/fl_optimizer.py:72-110.  Per feature line: chamfer between the VISIBLE projected samples of each
     frame and that frame's 2-D ground-truth curve, averaged over the frames that see the line and over the visible
     samples, then over the lines."""
-    loss = fl_pts_list[0].new_zeros(())          # (no host tensor: a pageable H2D copy would block the host on this stream)
     if proj_fl_weights is None:
         proj_fl_weights = [1. for _ in range(len(fl_pts_list))]
+    if (len(fl_pts_list) > 0 and fl_pts_list[0].dim() == 3 and isinstance(gt_fl_pts_list[0], torch.Tensor)
+            and all(p.shape == fl_pts_list[0].shape for p in fl_pts_list)
+            and all(m.shape == fl_masks[0].shape for m in fl_masks)
+            and all(g.dim() == 3 and g.shape == gt_fl_pts_list[0].shape for g in gt_fl_pts_list)):
+        return _fl_proj_loss_batched(fl_pts_list, gt_fl_pts_list, fl_masks, proj_fl_weights)
+    loss = fl_pts_list[0].new_zeros(())          # (no host tensor: a pageable H2D copy would block the host on this stream)
     for fl_pts, gt_fl_pts, fl_mask, w in zip(fl_pts_list, gt_fl_pts_list, fl_masks, proj_fl_weights):
         screen_fl_pts = fl_pts[..., :2]
         screen_fl_masks = fl_mask[..., :2]
@@ -129,6 +134,44 @@ def fl_proj_loss(fl_pts_list, gt_fl_pts_list, fl_masks, proj_fl_weights=None):
         n_vis = torch.div(screen_fl_masks.sum(), 2, rounding_mode='floor')
         loss = loss + torch.where(n_vis != 0, batch_loss / n_vis.clamp(min=1.), batch_loss)
     return loss / len(fl_pts_list)
+
+
+_WEIGHT_ROWS = {}
+
+
+def _fl_proj_loss_batched(fl_pts_list, gt_fl_pts_list, fl_masks, weights):
+    """fl_proj_loss when every line has the same number of samples and of ground-truth points (what the loop produces):
+    all (line, frame) chamfers as ONE distance tensor [L,N,S,M] — a dozen launches instead of a dozen per pair.  The sums
+    over frames and over lines are taken in the loop version's order (a sequence of adds)."""
+    X = torch.stack([p[..., :2] for p in fl_pts_list], dim=0)                       # [L,N,S,2]
+    Y = torch.stack([g.reshape(g.shape[0], -1, 2) for g in gt_fl_pts_list], dim=0)  # [L,N,M,2]
+    Mk = torch.stack([m[..., :2] for m in fl_masks], dim=0)                         # [L,N,S,2]
+    V = Mk[..., 0] == 1                                                             # [L,N,S]
+    L_, N = X.shape[0], X.shape[1]
+    w = None
+    if any(float(v) != 1. for v in weights):
+        key = (tuple(float(v) for v in weights), X.device, X.dtype)
+        w = _WEIGHT_ROWS.get(key)                 # uploaded once: a per-call host tensor would stall the stream's feeder
+        if w is None:
+            w = _WEIGHT_ROWS[key] = torch.tensor(key[0], dtype=X.dtype, device=X.device)
+    d = ((X[..., :, None, :] - Y[..., None, :, :]) ** 2).sum(-1)                    # [L,N,S,M]
+    rows = torch.where(V, d.min(dim=-1).values, d.new_zeros(())).sum(-1)            # [L,N]
+    cols = torch.where(V[..., None], d, d.new_full((), float('inf'))).min(dim=-2).values
+    cols = torch.where(V.any(-1)[..., None], cols, cols.new_zeros(())).sum(-1)      # [L,N]
+    per = rows + cols
+    if w is not None:
+        per = w.view(-1, 1) * per
+    batch_loss = per[:, 0]
+    for j in range(1, N):
+        batch_loss = batch_loss + per[:, j]                                         # [L]
+    valid_batch = (Mk[..., 0].sum(dim=-1) > 0).to(X.dtype).sum(-1)                  # [L]
+    batch_loss = torch.where(valid_batch != 0, batch_loss / valid_batch.clamp(min=1.), batch_loss)
+    n_vis = torch.div(Mk.reshape(L_, -1).sum(-1), 2, rounding_mode='floor')         # [L]
+    terms = torch.where(n_vis != 0, batch_loss / n_vis.clamp(min=1.).to(X.dtype), batch_loss)
+    loss = terms[0]
+    for i in range(1, L_):
+        loss = loss + terms[i]
+    return loss / L_
 
 
 def zbuff_check(z_buff, uv):

@@ -571,10 +571,22 @@ class HotLoop:
         with torch.no_grad():
             fl_cat = torch.cat(def_fl_vs, dim=1).detach()
             garment_check = fl.surface_depth_check(cameras, (W, H), gfrags.zbuf, def_garment_vs, fl_cat)
-            def_smpl_fl = torch.cat([self.deformer.defs[1](v.expand(N, -1, 3), smpl_conds)
-                                     for v in cano_smpl_verts_list], dim=1)
-            body = self.deformer.defs[1](self.tmpBodyVs.view(1, -1, 3).expand(N, -1, 3), smpl_conds)
-            bfrags = rast(body, self.tmpBodyFs)
+            # (rows of the skinner are independent: the lines' canonical-SMPL points as one batch, :1424-1433)
+            def_smpl_fl = self.deformer.defs[1](torch.cat([v.reshape(-1, 3) for v in cano_smpl_verts_list], dim=0)
+                                                .view(1, -1, 3).expand(N, -1, 3), smpl_conds)
+            # the posed body and its z-buffer are the same for every garment of the iteration (:1436-1446 redoes them)
+            hit = self._frag_cache.get('body')
+            if hit is None:
+                body = self.deformer.defs[1](self.tmpBodyVs.view(1, -1, 3).expand(N, -1, 3), smpl_conds)
+                bfrags = rast(body, self.tmpBodyFs)
+                ev = torch.cuda.Event() if body.is_cuda else None
+                if ev is not None:
+                    ev.record()
+                self._frag_cache['body'] = (body, bfrags, ev, L_raw_stream(body))
+            else:
+                body, bfrags, ev, sid = hit
+                if ev is not None and L_raw_stream(body) != sid:
+                    torch.cuda.current_stream(body.device).wait_event(ev)
             smpl_check = fl.surface_depth_check(cameras, (W, H), bfrags.zbuf, body, def_smpl_fl)
         return torch.stack([garment_check, smpl_check], dim=-1)
 
@@ -628,12 +640,15 @@ class HotLoop:
         for g_i, name in enumerate(self.garment_names):
             names = self.fl_extract[name]
             d_cond = d_cond_list[g_i + 1]
-            def_fl_vs = [self.deformer(fl_vs_dict[n].view(-1, 3).expand(N, -1, 3), [d_cond, smpl_conds], ratio=ratio,
-                                       offset_type=n) for n in names]                     # :1568
+            # the reference deforms the lines one by one (:1568); rows of the deformer are independent, so the garment's
+            # lines go through it as one batch (same values, a third of the launches)
+            split = [fl_vs_dict[n].view(-1, 3).shape[0] for n in names]
+            def_all = self.deformer(torch.cat([fl_vs_dict[n].view(-1, 3) for n in names], dim=0).expand(N, -1, 3),
+                                    [d_cond, smpl_conds], ratio=ratio, offset_type=names[0])
+            def_fl_vs = list(torch.split(def_all, split, dim=1))
             cano_smpl = self.inter_free_curve.query_canosmpl_verts(names)
             checks = self.fl_visible_by_body_zbuff(cameras, d_cond, smpl_conds, ratio, def_fl_vs, cano_smpl, g_i,
                                                    name, N)                               # [N,P,2]
-            split = [v.shape[1] for v in def_fl_vs]
             fl_masks = torch.cat([mask_dict[n] for n in names], dim=-1)                   # [N, lines]
             garment_proj_loss = self.compute_fl_proj_loss(def_fl_vs, checks, fl_masks,
                                                           torch.cat([gt_dict[n] for n in names], dim=1), name, split,
@@ -1215,6 +1230,14 @@ def sample_fan_mesh(verts, faces, count, generator=None):
     r = torch.rand(count, 2, device=verts.device, generator=generator)
     r = torch.where((r.sum(1, keepdim=True) > 1.0), r - 1.0, r).abs()
     return tri[f, 0] + e1[f] * r[:, 0:1] + e2[f] * r[:, 1:2]
+
+
+def L_raw_stream(t):
+    """Raw handle of the current stream of t's device (None for CPU tensors)."""
+    if not t.is_cuda:
+        return None
+    from . import _lib
+    return _lib.raw_stream(t.device)
 
 
 def iters_per_epoch(n_frames, batch_size, world_size=1):

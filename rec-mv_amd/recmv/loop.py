@@ -921,10 +921,12 @@ class HotLoop:
                 sdfs = net(p, ratio, jet=True)
                 rend_feat = net.rendcond
                 nx = net.gradient(p, sdfs)           # = autograd.grad(sdfs, p, ones, create_graph=True) (:1169-1172)
+                onx = nx.detach()
                 nx = nx / nx.norm(dim=1, keepdim=True)
                 defconds = [d_cond, [poses, trans]]
                 crays, defVs = utils.compute_cardinal_rays(self.deformer, p, self.rays[g_i], defconds, b, ratio,
                                                            'train', offset_type=name)
+                grad_d_p = None                      # d(defVs)/dp, formed once for the two terms below that use it
                 if conf.get_float('color_weight') > 0.:
                     colors = utils.compute_netRender_color(self.netRender, p, defVs, nx, crays, rend_feat,
                                                            rendcond[b], ratio)
@@ -934,9 +936,18 @@ class HotLoop:
                     total_loss = total_loss + conf.get_float('color_weight') * color_loss
                 if 'normal_weight' in conf and conf.get_float('normal_weight') > 0. and gtNs is not None:  # :1191-1217
                     if 'weighted_normal' in conf and conf.get_bool('weighted_normal'):
-                        cnx, _ = utils.compute_deformed_normals(net, self.deformer, p, defconds, b, ratio, 'test',
-                                                                offset_type=name)
-                        weights = torch.clamp((-self.rays[g_i] * cnx.detach()).sum(1).detach(), max=1., min=0.) ** 2
+                        # compute_deformed_normals(..., 'test') of the reference (:1196) evaluates the SDF gradient and
+                        # the deformer Jacobian at p once more without a graph; both are at hand already (the SDF jet
+                        # above, the deformer jet of compute_cardinal_rays): J^-T grad f, J grad f where J is singular
+                        if grad_d_p is None:
+                            grad_d_p = utils.compute_Jacobian(p, defVs, True, True)
+                        with torch.no_grad():
+                            Jd = grad_d_p.detach()
+                            Jd_inv, inv_ok = utils.FastDiff3x3MinvFunction.apply(Jd)
+                            cnx = torch.where(inv_ok.view(-1, 1), (Jd_inv.transpose(-2, -1) * onx.unsqueeze(-2)).sum(-1),
+                                              (Jd * onx.unsqueeze(-2)).sum(-1))
+                            cnx = cnx / cnx.norm(dim=1, keepdim=True)
+                        weights = torch.clamp((-self.rays[g_i] * cnx).sum(1).detach(), max=1., min=0.) ** 2
                     else:
                         weights = torch.ones(nx.shape[0], device=dev)
                     gtn = gtNs[b, self.row_inds[g_i], self.col_inds[g_i], :]
@@ -947,8 +958,10 @@ class HotLoop:
                     gtnorms = gtn.norm(dim=1, keepdim=True)
                     valid_mask = (gtnorms > 0.0001)[..., 0]
                     gtn = torch.where(valid_mask.unsqueeze(-1), gtn / gtnorms.clamp(min=1e-12), gtn)
-                    ds = self.deformer(p, defconds, b, ratio=ratio, offset_type=name, jet=True)
-                    grad_d_p = utils.compute_Jacobian(p, ds, True, True)
+                    # d(deformed)/dp: the Jacobian carried by compute_cardinal_rays' jet pass over the same points with
+                    # the same parameters (the reference evaluates the deformer once more, :1207-1208)
+                    if grad_d_p is None:
+                        grad_d_p = utils.compute_Jacobian(p, defVs, True, True)
                     gtn = (grad_d_p.transpose(-2, -1) * gtn.unsqueeze(-2)).sum(-1)
                     normal_loss = (gtn - nx).norm(2, dim=1) * weights
                     w = valid_mask.to(normal_loss.dtype)
@@ -1113,13 +1126,11 @@ class HotLoop:
             params = [q for q in self.deformer.parameters() if q.requires_grad]
             d = self.deformer(p, defconds, self.batch_inds[g_i], ratio=ratio, offset_type=name)
             temp = -(rhs_1[:, :, -3:].transpose(1, 2) * v_cross).sum(1)                      # rhs[1:4] @ (-[v]_x)
-            pg = torch.autograd.grad(d, params, temp, retain_graph=len(opt_defconds) > 0)
-            targets += params
+            # one reverse sweep for the deformer's parameters and the per-frame tensors (the reference's two `backward`
+            # calls, :2286-2301, walk the same graph twice)
+            pg = torch.autograd.grad(d, params + opt_defconds, temp)
+            targets += params + opt_defconds
             grads += list(pg)
-            if len(opt_defconds):
-                pg = torch.autograd.grad(d, opt_defconds, temp, retain_graph=False)
-                targets += opt_defconds
-                grads += list(pg)
             if v.requires_grad:
                 dc = d.detach() - c.detach().view(1, 3)
                 dc_cross = torch.stack([torch.stack([zeros, -dc[:, 2], dc[:, 1]], -1),

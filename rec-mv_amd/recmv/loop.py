@@ -59,26 +59,31 @@ RESOLUTIONS = {
 }
 
 
+_SV_CONST = {}
+
+
 def singular_values_3x3(J):
     """Singular values of [P,3,3] matrices, descending, closed form on the device: square roots of the
     eigenvalues of J^T J (trigonometric solution of the symmetric 3x3 characteristic polynomial).
-    Replaces `torch.svd(Jacobs.cpu())` (OptimGarmentNetwork.py:1148).  Differentiable."""
+    Replaces `torch.svd(Jacobs.cpu())` (OptimGarmentNetwork.py:1148).  Differentiable.  Written on whole [P,3,3] / [P,3]
+    tensors (about twenty launches forward; the element-by-element form of round 1 took sixty)."""
+    key = (J.device, J.dtype)
+    const = _SV_CONST.get(key)
+    if const is None:
+        const = _SV_CONST[key] = (torch.eye(3, device=J.device, dtype=J.dtype),
+                                  torch.arange(2, device=J.device, dtype=J.dtype) * (2.0 * math.pi / 3.0))
+    eye, shifts = const
     A = (J.transpose(-1, -2).unsqueeze(-1) * J.unsqueeze(-3)).sum(-2)        # J^T J without BLAS
-    a00, a11, a22 = A[:, 0, 0], A[:, 1, 1], A[:, 2, 2]
-    a01, a02, a12 = A[:, 0, 1], A[:, 0, 2], A[:, 1, 2]
-    q = (a00 + a11 + a22) / 3.0
-    p1 = a01 * a01 + a02 * a02 + a12 * a12
-    p2 = (a00 - q) ** 2 + (a11 - q) ** 2 + (a22 - q) ** 2 + 2.0 * p1
-    p = torch.sqrt(torch.clamp(p2 / 6.0, min=1e-30))
-    b00, b11, b22 = (a00 - q) / p, (a11 - q) / p, (a22 - q) / p
-    b01, b02, b12 = a01 / p, a02 / p, a12 / p
-    detB = (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02))
+    q = torch.diagonal(A, dim1=-2, dim2=-1).sum(-1) / 3.0                    # trace / 3
+    B0 = A - q.view(-1, 1, 1) * eye
+    p = torch.sqrt(torch.clamp((B0 * B0).sum((-2, -1)) / 6.0, min=1e-30))    # sum (a_ii - q)^2 + 2 sum_{i<j} a_ij^2
+    B = B0 / p.view(-1, 1, 1)
+    detB = (B[:, 0] * torch.linalg.cross(B[:, 1], B[:, 2], dim=-1)).sum(-1)
     r = torch.clamp(detB / 2.0, -1.0 + 1e-7, 1.0 - 1e-7)
     phi = torch.acos(r) / 3.0
-    e0 = q + 2.0 * p * torch.cos(phi)
-    e2 = q + 2.0 * p * torch.cos(phi + 2.0 * math.pi / 3.0)
-    e1 = 3.0 * q - e0 - e2
-    ev = torch.stack([e0, e1, e2], dim=1)
+    e02 = q.unsqueeze(-1) + 2.0 * p.unsqueeze(-1) * torch.cos(phi.unsqueeze(-1) + shifts)   # largest, smallest
+    e1 = 3.0 * q - e02.sum(-1)
+    ev = torch.stack([e02[:, 0], e1, e02[:, 1]], dim=1)
     return torch.sqrt(torch.clamp(ev, min=1e-20))
 
 

@@ -31,12 +31,12 @@ print("# by self CPU time")
 for r in sorted(prof.key_averages(), key=lambda r: -r.self_cpu_time_total)[:25]:
     print(f"{r.key[:60]:<60} {r.count / steps:>10.1f} {r.self_cpu_time_total / steps / 1e3:>18.3f}")
 print()
-print("# slow aten::empty calls (> 100 us): duration us, shapes, innermost python frames")
+print("# slow host-blocking calls (> 100 us): duration us, shapes, innermost python frames")
 n = 0
 for e in prof.events():
-    if e.name == "aten::empty" and e.self_cpu_time_total > 100:
+    if e.name in ("aten::empty", "aten::_local_scalar_dense", "aten::nonzero", "aten::copy_") and e.self_cpu_time_total > 100:
         n += 1
-        if n <= 25:
+        if n <= 60:
             st = [f for f in (e.stack or []) if "recmv" in f or "tools" in f][:3]
-            print(f"{e.self_cpu_time_total:9.0f} {e.input_shapes} {st}")
-print("slow empties per step:", n / steps)
+            print(f"{e.name[6:]:<20} {e.self_cpu_time_total:9.0f} {e.input_shapes} {st}")
+print("slow calls per step:", n / steps)

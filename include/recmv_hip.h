@@ -193,6 +193,12 @@ int recmv_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, cons
 int recmv_gemm_nt_actgrad(const float* G, int64_t ldg, const float* Y, int64_t ldy, const float* B, int64_t ldb,
                           float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param,
                           float y_scale, float g_scale, void* stream);
+/* C[M,N] = (A . B^T) (.) act'(y_scale * Y) * scale with Y [M,N] (row stride ldy): the activation-gradient step of the
+ * NEXT layer of a backward chain applied in the epilogue of the product that creates its cotangent — each element
+ * once (recmv_gemm_nt_actgrad, the operand-side fusion, recomputes it in every column tile). */
+int recmv_gemm_nt_mulgrad(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                          int64_t N, int64_t K, const float* Y, int64_t ldy, int act, float act_param, float y_scale,
+                          float scale, void* stream);
 /* Matrix mode of recmv_gemm_nt (and everything built on it): 0 = f32-input MFMA, the default — bit-for-bit an f32
  * fma chain; 1 = "bf16x6": every f32 operand element is split into three bf16 pieces in registers and each tile step
  * issues the six bf16 MFMA products of weight >= 2^-18 with f32 accumulation (f32-level accuracy, up to 2.7x the f32

@@ -152,10 +152,31 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int64
 // compact loop — each thread owns a fixed 4-column strip, adds its bias float4, applies the activation and
 // issues 16-byte row-contiguous stores.  (A fully unrolled per-accumulator-register epilogue costs 64 copies
 // of the activation per thread: more instruction bytes than the instruction cache holds, and 4-byte stores.)
+// Optional OUTPUT transform of the kernels without the operand transform: C (.)= act'(y_scale * Y[row, col]) * a_scale —
+// the dZ = dY (.) act'(Z) step of the NEXT layer of a backward chain applied where dY is produced (each element once;
+// the operand transform above recomputes it in every column tile that reads the element).
+__device__ __forceinline__ float4 emul4(float4 v, const AMul& m, int gm, int gn, int N) {
+  const float* y = m.Y + (int64_t)gm * m.ldy + gn;
+  float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (gn + 4 <= N && (m.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(m.Y) & 15) == 0) {
+    yv = *reinterpret_cast<const float4*>(y);
+  } else {
+    yv.x = y[0];
+    if (gn + 1 < N) yv.y = y[1];
+    if (gn + 2 < N) yv.z = y[2];
+    if (gn + 3 < N) yv.w = y[3];
+  }
+  v.x *= dact_y(yv.x * m.y_scale, m.act, m.param) * m.a_scale;
+  v.y *= dact_y(yv.y * m.y_scale, m.act, m.param) * m.a_scale;
+  v.z *= dact_y(yv.z * m.y_scale, m.act, m.param) * m.a_scale;
+  v.w *= dact_y(yv.w * m.y_scale, m.act, m.param) * m.a_scale;
+  return v;
+}
+
 template <int T, int ACT>
 __device__ __forceinline__ void nt_epilogue(const float* __restrict__ Cs, const float* __restrict__ bias,
                                             float* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
-                                            float act_param, float out_scale, bool c_vec) {
+                                            float act_param, float out_scale, bool c_vec, const AMul& em) {
   constexpr int TBM = 64 * T, TBN = 64 * T, LDC = TBN + 4;
   constexpr int C4 = TBN / 4;                 // float4 strips per tile row (32 or 16): divides kBlk
   constexpr int ROWS_PER_PASS = kBlk / C4;    // 8 or 16
@@ -181,6 +202,7 @@ __device__ __forceinline__ void nt_epilogue(const float* __restrict__ Cs, const 
     v.y = apply_act<ACT>(v.y + bv.y, act_param, inv_p) * out_scale;
     v.z = apply_act<ACT>(v.z + bv.z, act_param, inv_p) * out_scale;
     v.w = apply_act<ACT>(v.w + bv.w, act_param, inv_p) * out_scale;
+    if (em.Y) v = emul4(v, em, gm, gn, N);
     float* dst = C + (int64_t)gm * ldc + gn;
     if (full4) {
       *reinterpret_cast<float4*>(dst) = v;
@@ -344,16 +366,16 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
   __syncthreads();
   switch (act) {
     case RECMV_ACT_RELU:
-      nt_epilogue<T, RECMV_ACT_RELU>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      nt_epilogue<T, RECMV_ACT_RELU>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec, AMUL ? AMul{nullptr, 0, 0, 0.f, 1.f, 1.f} : am);
       break;
     case RECMV_ACT_SOFTPLUS:
-      nt_epilogue<T, RECMV_ACT_SOFTPLUS>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      nt_epilogue<T, RECMV_ACT_SOFTPLUS>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec, AMUL ? AMul{nullptr, 0, 0, 0.f, 1.f, 1.f} : am);
       break;
     case RECMV_ACT_TANH:
-      nt_epilogue<T, RECMV_ACT_TANH>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      nt_epilogue<T, RECMV_ACT_TANH>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec, AMUL ? AMul{nullptr, 0, 0, 0.f, 1.f, 1.f} : am);
       break;
     default:
-      nt_epilogue<T, RECMV_ACT_NONE>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      nt_epilogue<T, RECMV_ACT_NONE>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec, AMUL ? AMul{nullptr, 0, 0, 0.f, 1.f, 1.f} : am);
   }
 }
 
@@ -600,16 +622,16 @@ __global__ __launch_bounds__(kBlk, 2) void gemm_nt_b3_kernel(const float* __rest
   __syncthreads();
   switch (act) {
     case RECMV_ACT_RELU:
-      nt_epilogue<T, RECMV_ACT_RELU>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      nt_epilogue<T, RECMV_ACT_RELU>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec, AMUL ? AMul{nullptr, 0, 0, 0.f, 1.f, 1.f} : am);
       break;
     case RECMV_ACT_SOFTPLUS:
-      nt_epilogue<T, RECMV_ACT_SOFTPLUS>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      nt_epilogue<T, RECMV_ACT_SOFTPLUS>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec, AMUL ? AMul{nullptr, 0, 0, 0.f, 1.f, 1.f} : am);
       break;
     case RECMV_ACT_TANH:
-      nt_epilogue<T, RECMV_ACT_TANH>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      nt_epilogue<T, RECMV_ACT_TANH>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec, AMUL ? AMul{nullptr, 0, 0, 0.f, 1.f, 1.f} : am);
       break;
     default:
-      nt_epilogue<T, RECMV_ACT_NONE>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec);
+      nt_epilogue<T, RECMV_ACT_NONE>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec, AMUL ? AMul{nullptr, 0, 0, 0.f, 1.f, 1.f} : am);
   }
 }
 
@@ -776,6 +798,7 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_narrow_kernel(const float* __res
     v.y *= out_scale;
     v.z *= out_scale;
     v.w *= out_scale;
+    if (!AMUL && am.Y) v = emul4(v, am, gm, gn, N);
     float* dst = C + (int64_t)gm * ldc + gn;
     if (full4) {
       *reinterpret_cast<float4*>(dst) = v;
@@ -1162,6 +1185,21 @@ extern "C" int recmv_gemm_nt_actgrad(const float* G, int64_t ldg, const float* Y
   RECMV_REQUIRE(act >= RECMV_ACT_NONE && act <= RECMV_ACT_TANH, "gemm_nt_actgrad: unknown activation %d", act);
   AMul am = {Y, ldy, act, act_param, y_scale, g_scale};
   return dispatch_nt<true>(G, ldg, B, ldb, nullptr, C, ldc, M, N, K, RECMV_ACT_NONE, 0.f, 1.f, am, (hipStream_t)stream);
+}
+
+// C[M,N] = (A . B^T) (.) act'(y_scale * Y) * scale : the activation-gradient step of the NEXT backward layer fused into the
+// epilogue of the product that creates its cotangent (Y [M,N], row stride ldy).
+extern "C" int recmv_gemm_nt_mulgrad(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                                     int64_t M, int64_t N, int64_t K, const float* Y, int64_t ldy, int act,
+                                     float act_param, float y_scale, float scale, void* stream) {
+  RECMV_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_nt_mulgrad: negative size");
+  if (M == 0 || N == 0) return RECMV_OK;
+  RECMV_REQUIRE(A && B && C && Y, "gemm_nt_mulgrad: NULL pointer");
+  RECMV_REQUIRE(lda >= K && ldb >= K && ldc >= N && ldy >= N, "gemm_nt_mulgrad: leading dimension too small");
+  RECMV_REQUIRE(M < (1ll << 31) - BM && N < (1ll << 31) - BN && K < (1ll << 31) - BK, "gemm_nt_mulgrad: size overflow");
+  RECMV_REQUIRE(act >= RECMV_ACT_NONE && act <= RECMV_ACT_TANH, "gemm_nt_mulgrad: unknown activation %d", act);
+  AMul em = {Y, ldy, act, act_param, y_scale, scale};
+  return dispatch_nt<false>(A, lda, B, ldb, nullptr, C, ldc, M, N, K, RECMV_ACT_NONE, 0.f, 1.f, em, (hipStream_t)stream);
 }
 
 extern "C" int64_t recmv_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {

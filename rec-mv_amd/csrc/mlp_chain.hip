@@ -278,6 +278,7 @@ extern "C" int recmv_mlp_vjp_input(const recmv_mlp* m, const float* x, int64_t P
     ld = L.ld_act;
     cur ^= 1;
   }
+  bool have_dz = false;            // g already is dZ of the layer about to be differentiated (fused into the product before)
   for (int l = n - 2; l >= 0; --l) {
     const float* y = base + L.off_act[l] / 4;
     const bool skip_next = l + 1 == m->skip_layer;
@@ -293,12 +294,27 @@ extern "C" int recmv_mlp_vjp_input(const recmv_mlp* m, const float* x, int64_t P
     }
     // dZ = g (.) act'(z) once per element, then gin = dZ W.  (Fusing the activation gradient into the product's operand
     // staging, recmv_gemm_nt_actgrad, recomputes it in every column tile — 16x with the 64x32 tiles these row counts
-    // get: 39 us against 5 + 20 us per layer at 3-6 k rows.)
-    float* dz = base + L.off_g[2] / 4;
-    RECMV_TRY(recmv_act_grad_2d(g, ld, y, L.ld_act, dz, L.ld_act, P, m->rows[l], m->hidden_act, m->act_param,
-                                skip_next ? kSqrt2 : 1.f, skip_next ? kInvSqrt2 : 1.f, stream));
-    RECMV_TRY(recmv_gemm_nt(dz, L.ld_act, m->Wt[l], m->rows[l], nullptr, gin, L.ld_act, P, m->dims[l], m->rows[l],
-                            RECMV_ACT_NONE, 0.f, 1.f, stream));
+    // get.)  Where the next layer's input is this product's output as it stands, ITS activation gradient is applied in
+    // this product's epilogue (recmv_gemm_nt_mulgrad): one launch per layer.
+    const float* dzp = g;
+    int64_t lddz = ld;
+    if (!have_dz) {
+      float* dz = base + L.off_g[2] / 4;
+      RECMV_TRY(recmv_act_grad_2d(g, ld, y, L.ld_act, dz, L.ld_act, P, m->rows[l], m->hidden_act, m->act_param,
+                                  skip_next ? kSqrt2 : 1.f, skip_next ? kInvSqrt2 : 1.f, stream));
+      dzp = dz;
+      lddz = L.ld_act;
+    }
+    const bool fuse = l >= 1 && l != m->skip_layer;       // layer l-1's output is layer l's whole input
+    if (fuse) {
+      RECMV_TRY(recmv_gemm_nt_mulgrad(dzp, lddz, m->Wt[l], m->rows[l], gin, L.ld_act, P, m->dims[l], m->rows[l],
+                                      base + L.off_act[l - 1] / 4, L.ld_act, m->hidden_act, m->act_param, 1.f, 1.f,
+                                      stream));
+    } else {
+      RECMV_TRY(recmv_gemm_nt(dzp, lddz, m->Wt[l], m->rows[l], nullptr, gin, L.ld_act, P, m->dims[l], m->rows[l],
+                              RECMV_ACT_NONE, 0.f, 1.f, stream));
+    }
+    have_dz = fuse;
     cur ^= 1;
     g = gin;
     ld = L.ld_act;

@@ -84,6 +84,7 @@ def _declare(lib):
                                    vp]),
         "recmv_gemm_nt": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, f32, f32, vp]),
         "recmv_gemm_nt_actgrad": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, f32, f32, f32, vp]),
+        "recmv_gemm_nt_mulgrad": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, f32, f32, f32, vp]),
         "recmv_set_gemm_mode": (C.c_int, [i32]),
         "recmv_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),
         "recmv_gemm_tn": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),

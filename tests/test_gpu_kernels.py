@@ -580,3 +580,25 @@ def test_rootfind_step_equals_rootfind_update():
     assert torch.equal(pa, pb) and torch.equal(ua, ub)
     assert torch.equal(cnt_a[:times + 1], counters[:times + 1])
     assert torch.equal(marks[:times + 1], counters[:times + 1] + 1) and int(marks[times + 1]) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(3100, 512, 512), (6144, 39, 512), (300, 473, 512), (20000, 512, 512), (9000, 257, 168)])
+def test_gemm_nt_mulgrad_equals_product_then_activation_gradient(M, N, K):
+    """recmv_gemm_nt_mulgrad: (A B^T) (.) softplus'(Y) * scale in the product's epilogue == the plain product followed by
+    recmv_act_grad_2d (narrow / 64x64 / 128x128 tiles, ragged N and K)."""
+    from recmv import _lib as L
+    from recmv import ops
+    g0 = torch.Generator().manual_seed(M + N)
+    A = gpu(torch.randn(M, K, generator=g0))
+    B = gpu(torch.randn(N, K, generator=g0) / np.sqrt(K))
+    Y = gpu(torch.rand(M, N, generator=g0) * 0.05)
+    out = torch.empty(M, N, device=A.device)
+    L.check(L.lib().recmv_gemm_nt_mulgrad(L.ptr(A), K, L.ptr(B), K, L.ptr(out), N, M, N, K, L.ptr(Y), N, ops.ACT_SOFTPLUS,
+                                          100.0, 1.25, 0.5, L.stream_ptr(A.device)), "gemm_nt_mulgrad")
+    prod = ops.gemm_nt(A, B)
+    want = 0.5 * prod * (-torch.expm1(-100.0 * 1.25 * Y))
+    assert torch.allclose(out, want, rtol=3e-6, atol=1e-6 * float(prod.abs().max()))
+    # ReLU: exact
+    L.check(L.lib().recmv_gemm_nt_mulgrad(L.ptr(A), K, L.ptr(B), K, L.ptr(out), N, M, N, K, L.ptr(Y - 0.025), N, ops.ACT_RELU,
+                                          0.0, 1.0, 1.0, L.stream_ptr(A.device)), "gemm_nt_mulgrad")
+    assert torch.equal(out, prod * ((Y - 0.025) > 0).float())

@@ -976,6 +976,9 @@ class HotLoop:
                     normal_loss = (num / den.clamp(min=1)).mean()
                     self.info['{}_normal_loss'.format(name)] = normal_loss.detach()
                     total_loss = total_loss + conf.get_float('normal_weight') * normal_loss
+                # for propagateTmpPsGrad: the two jets at these points (same parameters until the optimiser steps)
+                self.__dict__.setdefault('_prop_pre', {})[g_i] = (
+                    p, onx, grad_d_p.detach() if grad_d_p is not None else None, _param_versions(net, self.deformer))
         return total_loss
 
     def dct_poses_loss(self, poses, trans, frame_ids, N):
@@ -1102,11 +1105,17 @@ class HotLoop:
             c = cameras.cam_pos()
             p = self.TmpPs[g_i]
             net = self.garment_nets[g_i]
-            f = net(p, ratio, jet=True)
-            grad_f_p = net.gradient(p, f).detach()
-            d = self.deformer(p, defconds, self.batch_inds[g_i], ratio=ratio, offset_type=name, jet=True)
             opt_defconds = [t for t in (defconds[0], defconds[1][0], defconds[1][1]) if t.requires_grad]
-            grad_d_p = utils.compute_Jacobian(p, d, False, False)
+            # grad f(p) and d(deformed)/dp at the surface points (:2176-2190): the render loss evaluated both jets at these
+            # very points with these very parameters a moment ago (surface_render_loss keeps them); recomputed otherwise
+            pre = getattr(self, '_prop_pre', {}).get(g_i)
+            if pre is not None and pre[0] is p and pre[3] == _param_versions(net, self.deformer) and pre[2] is not None:
+                grad_f_p, grad_d_p = pre[1], pre[2]
+            else:
+                f = net(p, ratio, jet=True)
+                grad_f_p = net.gradient(p, f).detach()
+                d = self.deformer(p, defconds, self.batch_inds[g_i], ratio=ratio, offset_type=name, jet=True)
+                grad_d_p = utils.compute_Jacobian(p, d, False, False)
             vd = v.detach()
             zeros = torch.zeros_like(vd[:, 0])
             v_cross = torch.stack([torch.stack([zeros, -vd[:, 2], vd[:, 1]], -1),
@@ -1246,6 +1255,11 @@ def sample_fan_mesh(verts, faces, count, generator=None):
     r = torch.rand(count, 2, device=verts.device, generator=generator)
     r = torch.where((r.sum(1, keepdim=True) > 1.0), r - 1.0, r).abs()
     return tri[f, 0] + e1[f] * r[:, 0:1] + e2[f] * r[:, 1:2]
+
+
+def _param_versions(*modules):
+    """In-place version counters of the modules' parameters (they change at optimizer.step())."""
+    return tuple(q._version for m in modules for q in m.parameters())
 
 
 def L_raw_stream(t):

@@ -289,7 +289,10 @@ class HotLoop:
         self.next_conf = self.next_train_conf = None
         self.body_vs = self.body_fs = None
         self.garment_vs, self.garment_fs = [], []
-        self.dctnull = dct_nullspace(min(30, n_frames), min(10, max(n_frames // 3, 1)), device)
+        # 30-frame windows (OptimGarmentNetwork.py:1222); a caller's dataset insists on windows shorter than the video
+        # (dataset/dataset.py:442), the synthetic frames allow a window as long as it
+        nlen = min(30, n_frames if hasattr(dataset, 'F') else n_frames - 1)
+        self.dctnull = dct_nullspace(nlen, min(10, max(nlen // 3, 1)), device)
         self.info = {}
         self.world_size, self.rank = world_size, rank
         # feature-curve branch (project_2d_loss, SURVEY.md §8f "next" row 3): off unless asked for
@@ -558,11 +561,16 @@ class HotLoop:
         cams = self._cameras()
         idx = torch.linspace(0, samples - 1, gt_samples).long()
         gt = torch.stack([cams.project(c[idx].to(dev)) for c in curves_list], 0)            # [L,M,2]
-        k = self.dataset.n_img
-        noise = torch.randn(k, gt.shape[0] * gt_samples, 2, generator=g).to(dev)
-        self.dataset.gt_fl_pts = (gt.reshape(1, -1, 2) + noise).detach()                     # [k, L*M, 2]
-        self.dataset.fl_masks = torch.ones(k, len(self.fl_names), device=dev)
-        self.dataset.fl_weights = {n: 1.0 for n in self.fl_names}
+        if hasattr(self.dataset, 'n_img'):
+            k = self.dataset.n_img
+            noise = torch.randn(k, gt.shape[0] * gt_samples, 2, generator=g).to(dev)
+            self.dataset.gt_fl_pts = (gt.reshape(1, -1, 2) + noise).detach()                     # [k, L*M, 2]
+            self.dataset.fl_masks = torch.ones(k, len(self.fl_names), device=dev)
+            self.dataset.fl_weights = {n: 1.0 for n in self.fl_names}
+        elif not hasattr(self.dataset, 'fl_weights'):
+            # a caller's dataset (recmv.dataset.SceneDataset, or the reference's): its 2-D feature lines arrive with every
+            # mini-batch (`datas['fl_pts']`), its per-line weights come from `area_size_statistic`
+            self.dataset.fl_weights = {n: 1.0 for n in self.fl_names}
         self.fl_optimizer = torch.optim.AdamW(self.inter_free_curve.parameters(), lr=1e-4)
 
     def fl_visible_by_body_zbuff(self, cameras, d_cond, smpl_conds, ratio, def_fl_vs, cano_smpl_verts_list, g_i,
@@ -1161,7 +1169,7 @@ class HotLoop:
     def iters_per_epoch(self):
         """ceil(F / (batch_size * world_size)): the reference's DataLoader keeps the short last batch (drop_last=False,
         dataset/dataset.py:1159-1183; train.py:250-260 counts ceil(len/bs) iterations per epoch)."""
-        return iters_per_epoch(self.dataset.F, self.batch_size, self.world_size)
+        return iters_per_epoch(_n_frames(self.dataset), self.batch_size, self.world_size)
 
     def frame_batch_at(self, epoch, pos):
         """Frames of this rank for position `pos` of `epoch`: a seeded permutation of all frames dealt round-robin over
@@ -1170,7 +1178,7 @@ class HotLoop:
         frame per rank, the permutation wraps so that every rank still has a frame (all ranks must enter the
         collectives)."""
         per_it = self.batch_size * self.world_size
-        perm = torch.randperm(self.dataset.F, generator=torch.Generator().manual_seed(1234 + epoch))
+        perm = torch.randperm(_n_frames(self.dataset), generator=torch.Generator().manual_seed(1234 + epoch))
         ids = perm[pos * per_it:(pos + 1) * per_it]
         if ids.numel() < self.world_size:
             ids = torch.cat([ids, perm[:self.world_size - ids.numel()]])
@@ -1255,6 +1263,11 @@ def sample_fan_mesh(verts, faces, count, generator=None):
     r = torch.rand(count, 2, device=verts.device, generator=generator)
     r = torch.where((r.sum(1, keepdim=True) > 1.0), r - 1.0, r).abs()
     return tri[f, 0] + e1[f] * r[:, 0:1] + e2[f] * r[:, 1:2]
+
+
+def _n_frames(dataset):
+    """Frames of the synthetic dataset (`F`) or of a caller's dataset (`frame_num`, dataset/dataset.py:185)."""
+    return int(dataset.F) if hasattr(dataset, 'F') else int(getattr(dataset, 'frame_num', len(dataset)))
 
 
 def _param_versions(*modules):

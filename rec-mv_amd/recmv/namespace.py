@@ -11,6 +11,7 @@ that a script written against the reference runs on this package unchanged:
     from engineer.core.beta_optimizer import smpl_beta_optimizer
     from MCAcc import Seg3dLossless, create_grid3D, GridSamplerMine3dFunction
     import FastMinv, MCGpu, GridSamplerMine, interp2x_boundary3d, utils
+    from dataset.dataset import getDatasetAndLoader
 
 It refuses to shadow a module that is already imported under one of these names (e.g. the reference itself).
 """
@@ -25,6 +26,10 @@ ALIASES = {
     "model.Embedder": "recmv.model.Embedder", "model.RenderNet": "recmv.model.RenderNet",
     "model.CameraMine": "recmv.model.CameraMine",
     "utils": "recmv.utils", "utils.utils": "recmv.utils.utils", "utils.FindSurfacePs": "recmv.utils.FindSurfacePs",
+    "utils.constant": "recmv.utils.constant",
+    "dataset": "recmv.dataset", "dataset.dataset": "recmv.dataset.dataset",
+    "engineer.utils": "recmv.engineer.utils", "engineer.utils.featureline_utils": "recmv.engineer.utils.featureline_utils",
+    "engineer.utils.polygons": "recmv.engineer.utils.polygons",
     "engineer": "recmv.engineer", "engineer.core": "recmv.engineer.core",
     "engineer.core.fl_optimizer": "recmv.engineer.core.fl_optimizer",
     "engineer.core.beta_optimizer": "recmv.engineer.core.beta_optimizer",

@@ -16,9 +16,11 @@ at the stage switches and `latest.pth` every epoch in the reference's checkpoint
 load_model), resume with the scheduler fast-forwarded and `opt_times` recomputed (train.py:232-260).
 `train_large_pose.py` is the same driver on the large-pose variant (SDF nets frozen, resume from `a-pose.pth`).
 
-What differs: the dataset loaders, the SDF / feature-curve initialisers and wandb are outside this tier,
-so the frames are synthetic (`recmv.loop.SyntheticFrames`; `--frames` sets their number) and `--data` is only the
-root under which `--save-folder` is created.  One process per GPU: under
+What differs: the SDF / feature-curve / SMPL-shape initialisers and wandb are outside this tier: the
+canonical surfaces and curves start from the synthetic initialisation.  `--data <capture> --data_type scene|people_snap`
+reads a capture directory in the reference's layout through `recmv.dataset` (images, masks, garment regions, 2-D feature
+lines, SMPL poses, camera); without a capture the frames are synthetic (`recmv.loop.SyntheticFrames`; `--frames` sets
+their number) and `--data` is only the root under which `--save-folder` is created.  One process per GPU: under
 `python -m torch.distributed.run --nproc-per-node N train.py ...` the frames of every mini-batch are sharded over the
 ranks and the shared gradients all-reduced with RCCL (recmv.dist); `--gpu-ids` picks the device of a single process.
 """
@@ -45,6 +47,8 @@ def build_parser(large_pose=False):
     parser.add_argument('--exp_name', type=str, default='run', help='exp name show by wandb (unused: no wandb)')
     parser.add_argument('--data_type', type=str, default='synthetic', help='the type of dataset')
     parser.add_argument('--curve_sampling', type=int, default=1, help='the type of dataset')
+    parser.add_argument('--garment_type', type=str, default=None,
+                        help='capture name in utils/constant.py FL_INFOS (default: the basename of --data)')
     if not large_pose:                           # train_large_pose.py:20-37 has neither flag: it resumes from a-pose.pth
         parser.add_argument('--a_pose', action='store_true', help='the type of dataset')
         parser.add_argument('--resume', default=None, metavar='M', help='pretrained scene model')
@@ -54,6 +58,38 @@ def build_parser(large_pose=False):
     parser.add_argument('--frames', type=int, default=64, help='number of synthetic frames')
     parser.add_argument('--max-iters', type=int, default=-1, help='stop after this many optimiser iterations (smoke runs)')
     return parser
+
+
+class CaptureLoader:
+    """`DataLoader(dataset, batch_size, sampler=RandomSampler(dataset, 1, shuffle))` of the reference (dataset/dataset.py:
+    1179-1182) rebuilt per epoch with the current stage's batch size (utils/utils.py:342-346 rebuilds it at every stage
+    switch), the epoch's permutation seeded so that frame-sharded ranks deal it round-robin among themselves."""
+
+    def __init__(self, dataset, loop, epoch=0):
+        self.dataset, self.loop, self.epoch = dataset, loop, epoch
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+        return self
+
+    def __len__(self):
+        per_it = self.loop.batch_size * self.loop.world_size
+        return (len(self.dataset) + per_it - 1) // per_it
+
+    def __iter__(self):
+        import random
+
+        import torch
+        from recmv.dataset import RandomSampler
+        random.seed(1234 + self.epoch)
+        state = torch.random.get_rng_state()
+        torch.manual_seed(1234 + self.epoch)
+        order = list(iter(RandomSampler(self.dataset, 1, True)))
+        torch.random.set_rng_state(state)
+        mine = order[self.loop.rank::self.loop.world_size]
+        loader = torch.utils.data.DataLoader(torch.utils.data.Subset(self.dataset, mine), self.loop.batch_size,
+                                             shuffle=False, num_workers=0)
+        return iter(loader)
 
 
 def stage_of_epoch(config, epoch):
@@ -106,12 +142,26 @@ def main(argv=None, large_pose=False):
     batch_size = config.get_int('train.coarse.point_render.batch_size')
     sample_pix_num = config.get_int('train.sample_pix_num')
 
-    # train.py:170-171 (bmins / bmaxs None: the synthetic pipeline sizes the canonical box from its initial surfaces)
-    optNet, sdf_initialized = getOptNet(None, args.save_folder, batch_size, None, None, resolutions['coarse'], device,
+    # train.py:150-160: a capture directory (`--data` with imgs/ masks/ ... , `--data_type scene | people_snap`) is read by
+    # recmv.dataset with the reference's conds_lens; without one the frames are synthetic
+    capture = None
+    if args.data is not None and args.data_type in ('scene', 'people_snap') and osp.isdir(osp.join(args.data, 'imgs')):
+        from recmv.dataset import getDatasetAndLoader
+        garment_type = args.garment_type or osp.basename(osp.normpath(args.data))
+        conds_lens = {'deformer': config.get_int('mlp_deformer.condlen') * 3,      # body + two garments (train.py:107)
+                      'renderer': config.get_int('render_net.condlen')}
+        capture, _ = getDatasetAndLoader(args.data, conds_lens, batch_size, True, 0, config.get_bool('train.opt_pose'),
+                                         config.get_bool('train.opt_trans'), config.get_config('train.opt_camera'),
+                                         garment_type, data_type=args.data_type, curve_sampling=args.curve_sampling,
+                                         a_pose=bool(getattr(args, 'a_pose', False)))
+        for t in capture.conds + [capture.poses, capture.trans, capture.shape] + list(capture.camera_params.values()):
+            t.data = t.data.to(device)            # the reference keeps these on the host and moves batches per call
+    # train.py:170-171 (bmins / bmaxs None: the canonical box is sized from the initial surfaces)
+    optNet, sdf_initialized = getOptNet(capture, args.save_folder, batch_size, None, None, resolutions['coarse'], device,
                                         config, opt_large=large_pose, n_frames=args.frames, H=512, W=512,
                                         world_size=world, rank=rank, curves=not args.no_curves)
     dataset = optNet.dataset
-    dataloader = FrameLoader(optNet)
+    dataloader = FrameLoader(optNet) if capture is None else CaptureLoader(capture, optNet)
     optNet, dataloader = utils.set_hierarchical_config(config, 'coarse', optNet, dataloader, resolutions['coarse'])
     rdist.broadcast_state([p for p in optNet.shared_parameters()] + list(optNet.sdf.parameters())
                           + (list(optNet.inter_free_curve.parameters()) if optNet.curves else []))

@@ -33,6 +33,10 @@ from MCAcc import Seg3dLossless, create_grid3D, GridSamplerMine3dFunction
 import utils
 from utils import set_hierarchical_config, save_model, load_model, FastDiff3x3MinvFunction
 import FastMinv, MCGpu, GridSamplerMine, interp2x_boundary3d
+from dataset.dataset import getDatasetAndLoader, SceneDataset, People_Snapshot_SceneDataset, RandomSampler
+from utils.constant import FL_INFOS, ATR_PARSING
+from engineer.utils.featureline_utils import obtain_feature_lines, check_feature_lines
+from engineer.utils.polygons import uniformsample
 assert issubclass(OptimGarmentNetwork_LargePose, OptimGarmentNetwork)
 for fn in (scale_rigid_optimizer, rigid_optimizer, smpl_beta_optimizer):
     try:

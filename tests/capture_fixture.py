@@ -22,7 +22,8 @@ def _polyline(rng, n, closed_gap):
     return pts
 
 
-def write_capture(root, seed=7):
+def write_capture(root, seed=7, H=H, W=W, loop_camera=False):
+    """`loop_camera`: the pinhole the synthetic frames of recmv.loop use (object at z = 3 in view), for runs of the loop."""
     from PIL import Image
     import joblib
     rng = np.random.RandomState(seed)
@@ -58,8 +59,13 @@ def write_capture(root, seed=7):
     np.savez(os.path.join(root, 'smpl_rec.npz'), poses=rng.randn(FRAMES, 72).astype(np.float32) * 0.2,
              trans=rng.randn(FRAMES, 3).astype(np.float32) * 0.05, shape=rng.randn(10).astype(np.float32), gender='female')
     q = rng.randn(4)
-    np.savez(os.path.join(root, 'camera.npz'), fx=np.float32(900.), fy=np.float32(910.), cx=np.float32(W / 2), cy=np.float32(H / 2),
-             quat=(q / np.linalg.norm(q)).astype(np.float32), T=np.array([0.02, -0.01, 2.5], np.float32))
+    if loop_camera:
+        np.savez(os.path.join(root, 'camera.npz'), fx=np.float32(1000. * W / 512), fy=np.float32(1000. * H / 512),
+                 cx=np.float32(W / 2), cy=np.float32(H / 2), quat=np.array([0., 0., 0., 1.], np.float32),
+                 T=np.array([0., 0., 3.], np.float32))
+    else:
+        np.savez(os.path.join(root, 'camera.npz'), fx=np.float32(900.), fy=np.float32(910.), cx=np.float32(W / 2),
+                 cy=np.float32(H / 2), quat=(q / np.linalg.norm(q)).astype(np.float32), T=np.array([0.02, -0.01, 2.5], np.float32))
     joblib.dump([None, {'gt_joints2d': rng.rand(FRAMES, 49, 3).astype(np.float32), 'frame_ids': np.arange(FRAMES),
                         'pose': rng.randn(FRAMES, 72).astype(np.float32), 'betas': rng.randn(FRAMES, 10).astype(np.float32)}],
                 os.path.join(root, '%s_tcmr_output.pkl' % GARMENT_TYPE))

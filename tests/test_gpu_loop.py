@@ -91,3 +91,46 @@ def test_feature_curve_branch_on_gpu():
     moved = max(float((a - b.detach()).abs().max()) for a, b in zip(before, loop.inter_free_curve.parameters()))
     assert 1e-5 < moved < 1e-2
     assert loop.tmpBodyVs.shape[0] > 500 and loop.tmpBodyFs.shape[0] > 1000
+
+
+def test_iterations_on_a_capture_directory_read_by_recmv_dataset(tmp_path):
+    """train.py's sequence on the device with a capture directory in the reference's layout (recmv.dataset.SceneDataset) in
+    place of the synthetic frames: the mini-batch dict of a DataLoader goes into OptimGarmentNetwork.forward, the tensors the
+    optimiser moves are the dataset's own."""
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import capture_fixture as cf
+    from recmv import utils
+    from recmv.dataset import getDatasetAndLoader
+    from recmv.hocon import ConfigFactory
+    from recmv.model.network import getOptNet
+    dev = torch.device("cuda:0")
+    root = cf.write_capture(str(tmp_path / "capture"), H=160, W=128, loop_camera=True)
+    conf = ConfigFactory.parse_file(CONF)
+    conf.put('train.sample_pix_num', 256)
+    conds_lens = {'deformer': conf.get_int('mlp_deformer.condlen') * 3, 'renderer': conf.get_int('render_net.condlen')}
+    torch.manual_seed(3)
+    ds, _ = getDatasetAndLoader(root, conds_lens, 3, True, 0, True, True, conf.get_config('train.opt_camera'),
+                                cf.GARMENT_TYPE, data_type='scene')
+    for t in ds.conds + [ds.poses, ds.trans, ds.shape] + list(ds.camera_params.values()):
+        t.data = t.data.to(dev)
+    res = [(9, 13, 7), (17, 25, 13), (33, 49, 25), (65, 97, 49)]
+    optNet, _ = getOptNet(ds, 'result', 3, None, None, res, dev, conf, curves=True, skin_grid=(17, 33, 17))
+    optNet, _ = utils.set_hierarchical_config(conf, 'coarse', optNet, None, res)
+    optimizer = optNet.rebuild_optimizer()
+    before = ds.poses.detach().clone(), ds.conds[0].detach().clone(), ds.camera_params['focal_length'].detach().clone()
+    for it, frames in enumerate(([0, 2, 3], [5, 6, 8])):                      # frames that have a normal map
+        datas = torch.utils.data.default_collate([ds[i][1] for i in frames])
+        frame_ids = torch.tensor(frames, device=dev)
+        ratio = {'sdfRatio': 1., 'deformerRatio': optNet.opt_times / 2500. + 0.5, 'renderRatio': 1.}
+        optimizer.zero_grad()
+        loss = optNet(datas, 256, ratio, frame_ids, str(tmp_path), global_optimizer=optimizer)
+        loss.backward()
+        optNet.propagateTmpPsGrad(frame_ids, ratio)
+        optimizer.step()
+        optNet.opt_times += 1.
+        assert torch.isfinite(loss), it
+    torch.cuda.synchronize()
+    assert not torch.equal(ds.poses.detach()[[0, 2, 3]], before[0][[0, 2, 3]])
+    assert not torch.equal(ds.conds[0].detach(), before[1])
+    assert not torch.equal(ds.camera_params['focal_length'].detach(), before[2])
+    assert torch.isfinite(optNet.info['fl_loss']['total']) and optNet.info['rays_total'] > 0

@@ -17,9 +17,8 @@ the colour net is trained on that order), 'mask' [H,W], 'fl_pts' [L*S,2], 'fl_ma
 region masks 'upper' / 'bottom' / 'upper_bottom' / 'body', 'gt_joints2d'})`; the learnable per-frame tensors live on the dataset
 (`poses`, `trans`, `conds`, `camera_params`) and are fetched by frame id (`get_grad_parameters`, :425-433).
 
-Images are decoded with Pillow (no OpenCV in this image) into OpenCV's channel order.  The loaders `scene` and `people_snap` are
-provided; `large_pose` / `snug` / `synthe` raise (their pre-processing — one-euro smoothing, SNUG motion files — is outside
-this tier)."""
+Images are decoded with Pillow (no OpenCV in this image) into OpenCV's channel order.  The loaders `scene`, `people_snap` and
+`large_pose` are provided; `snug` / `synthe` raise (SNUG motion files and the synthetic-outfit renders are outside this tier)."""
 import os
 import os.path as osp
 import random
@@ -32,7 +31,7 @@ from ..engineer.utils.featureline_utils import check_feature_lines, obtain_featu
 from ..engineer.utils.polygons import uniformsample
 from ..utils.constant import ATR_PARSING, FL_INFOS
 
-__all__ = ["SceneDataset", "People_Snapshot_SceneDataset", "ClipSampler", "RandomSampler", "getDatasetAndLoader",
+__all__ = ["SceneDataset", "People_Snapshot_SceneDataset", "Large_Pose_SceneDataset", "one_euro_smooth", "ClipSampler", "RandomSampler", "getDatasetAndLoader",
            "read_image_bgr", "dct_space"]
 
 
@@ -371,6 +370,93 @@ class People_Snapshot_SceneDataset(SceneDataset):
         return idx, out
 
 
+def one_euro_smooth(seq, min_cutoff=0.004, beta=1.5, d_cutoff=1.):
+    """One-euro filter (Casiez et al. 2012: an exponential smoother whose cutoff grows with the smoothed speed) along the first
+    axis of `seq`, unit time steps, as `smooth_poses` of the reference applies it (engineer/utils/smooth_poses.py:34-71 over
+    engineer/utils/filter.py:14-58): x_hat_0 = x_0, dx_hat_0 = 0;  a(c) = 2 pi c / (2 pi c + 1);
+    dx_hat = a(d_cutoff) (x - x_hat_prev) + (1 - a(d_cutoff)) dx_hat_prev;  x_hat = a(c) x + (1 - a(c)) x_hat_prev with
+    c = min_cutoff + beta |dx_hat|.  For axis-angle sequences [F,J,3] a sample that jumped by more than 0.5 (L1) from the
+    previous estimate is first replaced by its equivalent rotation about the opposite axis (angle 2 pi - theta)."""
+    x = seq.detach().clone()
+    out = torch.zeros_like(x)
+    out[0] = x[0]
+    x_prev, dx_prev = x[0], torch.zeros_like(x[0])
+
+    def alpha(cutoff):
+        r = 2 * np.pi * cutoff
+        return r / (r + 1)
+
+    for i in range(1, x.shape[0]):
+        cur = x[i]
+        jump = torch.abs(x[i] - out[i - 1]).sum(-1)
+        if cur.dim() >= 2 and bool(jump.max() > 0.5):
+            angle = torch.norm(cur + 1e-8, p=2, dim=1).unsqueeze(-1)
+            flip = 1 + (2 * np.pi - 2 * angle) / angle
+            mask = jump > 0.5
+            cur = cur.clone()
+            cur[mask] = -cur[mask]
+            cur[mask] *= flip[mask]
+        dx = cur - x_prev
+        dx_hat = alpha(d_cutoff) * dx + (1 - alpha(d_cutoff)) * dx_prev
+        a = alpha(min_cutoff + beta * torch.abs(dx_hat))
+        x_hat = a * cur + (1 - a) * x_prev
+        x_prev, dx_prev = x_hat, dx_hat
+        out[i] = x_hat
+    return out
+
+
+def _lower_bound(arr, target):
+    """First position whose value is >= target (utils/common_utils.py:30-39)."""
+    lo, hi = 0, len(arr)
+    while lo < hi:
+        mid = (lo + hi) >> 1
+        if arr[mid] < target:
+            lo = mid + 1
+        else:
+            hi = mid
+    return lo
+
+
+class Large_Pose_SceneDataset(People_Snapshot_SceneDataset):
+    """Large-pose captures (:681-892): as PeopleSnapshot, with the depth of the translation frozen after the A-pose turn and
+    the translations smoothed, the SMPL shape taken from the TCMR betas of the A-pose turn, the poses after it replaced by the
+    TCMR poses of the nearest annotated frame; samples are addressed relative to `start_idx`."""
+
+    def __init__(self, data_root, conds_lens={}, garment_type="", fl_sampling=100, curve_sampling=1, a_pose=False):
+        SceneDataset.__init__(self, data_root, conds_lens, garment_type, fl_sampling, curve_sampling=curve_sampling)
+        self.a_pose = a_pose
+        n_all = len(self)
+        joints_idx = [_lower_bound(self.joints_frame_ids, idx) for idx in range(n_all)]
+        self.trans[self.a_pose_end:, -1] = self.trans[self.a_pose_end, -1]
+        self.trans = one_euro_smooth(self.trans.detach().cpu(), min_cutoff=0.004, beta=0.7, d_cutoff=1.)
+        self.shape = torch.from_numpy(self.tcmr_betas[self.a_pose_start:self.a_pose_end + 1].mean(0)).float()
+        tcmr_poses = torch.from_numpy(self.tcmr_poses[joints_idx]).view(-1, 24, 3).float()
+        self.poses[self.a_pose_end + 1:len(tcmr_poses)] = tcmr_poses[self.a_pose_end + 1:]
+        fl_dir = osp.join(data_root, 'mask2fl')
+        self.start_idx = 0
+        if osp.exists(fl_dir):
+            self.read_feature_lines(fl_dir)
+            self.area_size_statistic()
+            if self.a_pose:
+                self.frame_num = self.a_pose_end - self.a_pose_start + 1
+                self.start_idx = 0
+            else:
+                self.frame_num = n_all - self.a_pose_end - 1
+                self.start_idx = self.a_pose_end + 1
+
+    def all_size(self):
+        return self.poses.shape[0]
+
+    def __getitem__(self, idx):
+        idx = self.start_idx + idx
+        out = self._sample(idx)
+        out['gt_joints2d'] = self.gt_joints2d[self.joints_frame_ids[_lower_bound(self.joints_frame_ids, idx)]]
+        if self.require_albedo:
+            alb = read_image_bgr(osp.join(self.root, 'albedos/%d.png' % idx)).astype(np.float32)
+            out['albedo'] = torch.from_numpy((alb / 255. - 0.5) * 2.).view(self.H, self.W, 3)
+        return idx, out
+
+
 class ClipSampler(torch.utils.data.Sampler):
     """Consecutive clips of `clip_size` frames in random order, from a random offset (:1113-1133)."""
 
@@ -424,7 +510,9 @@ def getDatasetAndLoader(root, conds_lens, batch_size, shuffle, num_workers, opt_
         dataset = SceneDataset(root, conds_lens, garment_type, curve_sampling=curve_sampling)
     elif data_type == 'people_snap':
         dataset = People_Snapshot_SceneDataset(root, conds_lens, garment_type, curve_sampling=curve_sampling, a_pose=a_pose)
-    elif data_type in ('large_pose', 'snug', 'synthe'):
+    elif data_type == 'large_pose':
+        dataset = Large_Pose_SceneDataset(root, conds_lens, garment_type, curve_sampling=curve_sampling, a_pose=a_pose)
+    elif data_type in ('snug', 'synthe'):
         raise NotImplementedError("data type {}: its pre-processing is outside this package (recmv/dataset/dataset.py)".format(
             data_type))
     else:

@@ -17,7 +17,7 @@ load_model), resume with the scheduler fast-forwarded and `opt_times` recomputed
 `train_large_pose.py` is the same driver on the large-pose variant (SDF nets frozen, resume from `a-pose.pth`).
 
 What differs: the SDF / feature-curve / SMPL-shape initialisers and wandb are outside this tier: the
-canonical surfaces and curves start from the synthetic initialisation.  `--data <capture> --data_type scene|people_snap`
+canonical surfaces and curves start from the synthetic initialisation.  `--data <capture> --data_type scene|people_snap|large_pose`
 reads a capture directory in the reference's layout through `recmv.dataset` (images, masks, garment regions, 2-D feature
 lines, SMPL poses, camera); without a capture the frames are synthetic (`recmv.loop.SyntheticFrames`; `--frames` sets
 their number) and `--data` is only the root under which `--save-folder` is created.  One process per GPU: under
@@ -142,10 +142,10 @@ def main(argv=None, large_pose=False):
     batch_size = config.get_int('train.coarse.point_render.batch_size')
     sample_pix_num = config.get_int('train.sample_pix_num')
 
-    # train.py:150-160: a capture directory (`--data` with imgs/ masks/ ... , `--data_type scene | people_snap`) is read by
+    # train.py:150-160: a capture directory (`--data` with imgs/ masks/ ... , `--data_type scene | people_snap | large_pose`) is read by
     # recmv.dataset with the reference's conds_lens; without one the frames are synthetic
     capture = None
-    if args.data is not None and args.data_type in ('scene', 'people_snap') and osp.isdir(osp.join(args.data, 'imgs')):
+    if args.data is not None and args.data_type in ('scene', 'people_snap', 'large_pose') and osp.isdir(osp.join(args.data, 'imgs')):
         from recmv.dataset import getDatasetAndLoader
         garment_type = args.garment_type or osp.basename(osp.normpath(args.data))
         conds_lens = {'deformer': config.get_int('mlp_deformer.condlen') * 3,      # body + two garments (train.py:107)

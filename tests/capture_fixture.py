@@ -72,13 +72,14 @@ def write_capture(root, seed=7, H=H, W=W, loop_camera=False):
     return root
 
 
-def collect(ds, kind):
+def collect(ds, kind, samples=(0, 1, 5, 11)):
     """What the golden pins of a dataset object (reference's or recmv's): samples, per-line weights, windows, camera."""
     import torch
     out = {}
-    for idx in (0, 1, 5, 11):
+    for idx in samples:
         i, s = ds[idx]
-        assert i == idx
+        assert i == idx + getattr(ds, 'start_idx', 0) * int(type(ds).__name__.startswith('Large_Pose'))
+        out['%s_s%d_index' % (kind, idx)] = torch.tensor([float(i)])
         for k, v in s.items():
             out['%s_s%d_%s' % (kind, idx, k)] = torch.as_tensor(np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v).float()
     out[kind + '_fl_weights'] = torch.tensor([ds.fl_weights[n] for n in ds.fl_names]).float()

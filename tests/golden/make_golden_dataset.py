@@ -1,7 +1,7 @@
 """Golden vectors for the data path, from the REAL reference dataset classes (dataset/dataset.py) reading the synthetic capture
 of tests/capture_fixture.py:
 
-  dataset.npz   `SceneDataset` and `People_Snapshot_SceneDataset` (a_pose False / True): four samples each (image, mask,
+  dataset.npz   `SceneDataset`, `People_Snapshot_SceneDataset` and `Large_Pose_SceneDataset` (a_pose False / True): four samples each (image, mask,
                 feature-line points and flags, normal map, garment regions, 2-D joints), the per-line projection weights
                 (`area_size_statistic`), which frames carry an annotation, temporal windows (`get_batchframe_data`), camera
                 tuple, per-frame tensors incl. the DCT-initialised codes (seeded), lengths; the samplers' index streams; the
@@ -58,6 +58,22 @@ def main():
             ds.gt_joints2d = None if False else ds.gt_joints2d
             out.update(cf.collect(ds, 'ps%d' % int(a_pose)))
             out['ps%d_apose' % int(a_pose)] = torch.tensor([float(ds.a_pose_start), float(ds.a_pose_end)])
+        for a_pose in (False, True):
+            torch.manual_seed(13)
+            ds = refds.Large_Pose_SceneDataset(root, dict(CONDS), cf.GARMENT_TYPE, fl_sampling=30, curve_sampling=1,
+                                               a_pose=a_pose)
+            kind = 'lp%d' % int(a_pose)
+            out.update(cf.collect(ds, kind, samples=(0, 1, len(ds) - 1)))
+            out[kind + '_apose'] = torch.tensor([float(ds.a_pose_start), float(ds.a_pose_end)])
+            out[kind + '_all_trans'], out[kind + '_all_poses'], out[kind + '_shape'] = ds.trans.clone(), ds.poses.clone(), ds.shape.clone()
+        # the smoother on an axis-angle sequence with a sign flip of one joint (the branch that re-expresses the rotation)
+        smooth = ref_loader.ref_module("engineer.utils.smooth_poses").smooth_poses
+        g = torch.Generator().manual_seed(9)
+        seq = 0.3 * torch.randn(1, 5, 3, generator=g) + 0.02 * torch.randn(14, 5, 3, generator=g).cumsum(0)
+        seq[6:, 2] = -seq[6:, 2] * (1 + (2 * np.pi - 2 * seq[6:, 2].norm(dim=-1, keepdim=True)) / seq[6:, 2].norm(dim=-1, keepdim=True))
+        out['smooth_in'] = seq.clone()
+        out['smooth_out'] = smooth(seq, min_cutoff=0.004, beta=0.7, d_cutoff=1.)
+        out['smooth_out_default'] = smooth(seq)
         ds = refds.SceneDataset(root, dict(CONDS), cf.GARMENT_TYPE, fl_sampling=30)
         for name, cls, arg in (('random', refds.RandomSampler, 3), ('clip', refds.ClipSampler, 5)):
             for shuffle in (False, True):

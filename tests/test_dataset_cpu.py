@@ -170,3 +170,25 @@ def test_capture_loader_deals_an_epoch_over_ranks(capture):
         assert sorted(per_rank[0] + per_rank[1]) == list(range(cf.FRAMES)) and not set(per_rank[0]) & set(per_rank[1])
         seen[epoch] = per_rank
     assert seen[0] != seen[1]
+
+
+@pytest.mark.parametrize("a_pose", [False, True])
+def test_large_pose_dataset_matches_the_reference_class(capture, golden, a_pose):
+    """Large_Pose_SceneDataset (:681-892): frozen depth + smoothed translations, shape from the TCMR betas of the A-pose turn,
+    TCMR poses after it, samples addressed from `start_idx`."""
+    from recmv.dataset import Large_Pose_SceneDataset
+    torch.manual_seed(13)
+    ds = Large_Pose_SceneDataset(capture, dict(CONDS), cf.GARMENT_TYPE, fl_sampling=30, curve_sampling=1, a_pose=a_pose)
+    kind = 'lp%d' % int(a_pose)
+    got = cf.collect(ds, kind, samples=(0, 1, len(ds) - 1))
+    got[kind + '_apose'] = torch.tensor([float(ds.a_pose_start), float(ds.a_pose_end)])
+    got[kind + '_all_trans'], got[kind + '_all_poses'], got[kind + '_shape'] = ds.trans, ds.poses, ds.shape
+    _compare(got, golden, kind)
+
+
+def test_one_euro_smoother_matches_the_reference_function(golden):
+    from recmv.dataset import one_euro_smooth
+    x = golden['smooth_in']
+    assert torch.allclose(one_euro_smooth(x, min_cutoff=0.004, beta=0.7, d_cutoff=1.), golden['smooth_out'], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(one_euro_smooth(x), golden['smooth_out_default'], rtol=1e-6, atol=1e-7)
+    assert not torch.allclose(golden['smooth_out'][7:, 2], x[7:, 2], atol=0.5)        # the flipped joint was re-expressed

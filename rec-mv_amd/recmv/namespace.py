@@ -33,6 +33,8 @@ ALIASES = {
     "engineer": "recmv.engineer", "engineer.core": "recmv.engineer.core",
     "engineer.core.fl_optimizer": "recmv.engineer.core.fl_optimizer",
     "engineer.core.beta_optimizer": "recmv.engineer.core.beta_optimizer",
+    "engineer.visualizer": "recmv.engineer.visualizer",
+    "engineer.visualizer.wandb_visualizer": "recmv.engineer.visualizer.wandb_visualizer",
     "engineer.networks": "recmv.engineer.networks",
     "engineer.networks.OptimGarmentNetwork": "recmv.engineer.networks.OptimGarmentNetwork",
     "engineer.networks.OptimGarmentNetwork_Large_Pose": "recmv.engineer.networks.OptimGarmentNetwork_Large_Pose",

@@ -17,7 +17,8 @@ load_model), resume with the scheduler fast-forwarded and `opt_times` recomputed
 `train_large_pose.py` is the same driver on the large-pose variant (SDF nets frozen, resume from `a-pose.pth`).
 
 What differs: the SDF / feature-curve / SMPL-shape initialisers and wandb are outside this tier: the
-canonical surfaces and curves start from the synthetic initialisation.  `--data <capture> --data_type scene|people_snap|large_pose`
+canonical surfaces and curves start from the synthetic initialisation; scalars go to wandb when it is installed, to
+`<save-folder>/logs/<exp_name>.jsonl` otherwise.  `--data <capture> --data_type scene|people_snap|large_pose`
 reads a capture directory in the reference's layout through `recmv.dataset` (images, masks, garment regions, 2-D feature
 lines, SMPL poses, camera); without a capture the frames are synthetic (`recmv.loop.SyntheticFrames`; `--frames` sets
 their number) and `--data` is only the root under which `--save-folder` is created.  One process per GPU: under
@@ -43,8 +44,8 @@ def build_parser(large_pose=False):
     parser.add_argument('--model-rm-prefix', nargs='+', type=str, metavar='rm prefix', help='rm model prefix')
     parser.add_argument('--sdf-model', default=None, metavar='M', help='substitute sdf model')
     parser.add_argument('--save-folder', default=None, metavar='M', help='save folder')
-    parser.add_argument('--project_name', type=str, default='recmv', help='exp name show by wandb (unused: no wandb)')
-    parser.add_argument('--exp_name', type=str, default='run', help='exp name show by wandb (unused: no wandb)')
+    parser.add_argument('--project_name', type=str, default='recmv', help='exp name show by wandb')
+    parser.add_argument('--exp_name', type=str, default='run', help='exp name show by wandb')
     parser.add_argument('--data_type', type=str, default='synthetic', help='the type of dataset')
     parser.add_argument('--curve_sampling', type=int, default=1, help='the type of dataset')
     parser.add_argument('--garment_type', type=str, default=None,
@@ -90,6 +91,18 @@ class CaptureLoader:
         loader = torch.utils.data.DataLoader(torch.utils.data.Subset(self.dataset, mine), self.loop.batch_size,
                                              shuffle=False, num_workers=0)
         return iter(loader)
+
+
+def _scalars(loss, info):
+    """The 0-d entries of optNet.info (per-garment losses, ray counts) + the total, for the visualizer."""
+    import torch
+    out = {'loss': float(loss)}
+    for k, v in info.items():
+        if isinstance(v, torch.Tensor) and v.numel() == 1:
+            out[k] = float(v)
+        elif isinstance(v, (int, float)):
+            out[k] = float(v)
+    return out
 
 
 def stage_of_epoch(config, epoch):
@@ -162,6 +175,9 @@ def main(argv=None, large_pose=False):
                                         world_size=world, rank=rank, curves=not args.no_curves)
     dataset = optNet.dataset
     dataloader = FrameLoader(optNet) if capture is None else CaptureLoader(capture, optNet)
+    if rank == 0:                                 # train.py:86: wandb when it is there, a jsonl file under logs/ otherwise
+        from recmv.engineer.visualizer import wandb_visualizer
+        optNet.visualizer = wandb_visualizer(args.project_name, args.exp_name, resume=False, log_dir=osp.join(save_root, 'logs'))
     optNet, dataloader = utils.set_hierarchical_config(config, 'coarse', optNet, dataloader, resolutions['coarse'])
     rdist.broadcast_state([p for p in optNet.shared_parameters()] + list(optNet.sdf.parameters())
                           + (list(optNet.inter_free_curve.parameters()) if optNet.curves else []))
@@ -231,6 +247,8 @@ def main(argv=None, large_pose=False):
                     msg += ' | %s: eik %.4f pc_sdf %.5f' % (name, float(info.get(name + '_grad_loss', 0.)),
                                                            float(info.get('pc_%s_loss_sdf' % name, 0.)))
                 print(msg + ' (%.0f ms)' % ((time.perf_counter() - t0) * 1e3), flush=True)
+                if optNet.visualizer is not None and done % 10 == 0:
+                    optNet.visualizer.add_scalar(_scalars(loss, info), int(optNet.opt_times))
             optNet.opt_times += 1.
             done += 1
             if 0 <= args.max_iters <= done:

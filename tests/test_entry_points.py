@@ -153,3 +153,17 @@ def test_large_pose_driver_cli():
     assert a.data_type == 'large_pose' and not hasattr(a, 'resume') and not hasattr(a, 'a_pose')
     with pytest.raises(SystemExit):
         train.build_parser(large_pose=True).parse_args(['--resume', 'x.pth'])
+
+
+def test_visualizer_without_wandb_writes_scalars_to_a_file(tmp_path, monkeypatch):
+    """engineer/visualizer/wandb_visualizer.py:7-21 as an optional sink: no wandb (or WANDB_MODE=disabled) -> jsonl."""
+    import json
+    monkeypatch.setenv('WANDB_MODE', 'disabled')
+    from recmv.engineer.visualizer import wandb_visualizer
+    wv = wandb_visualizer('proj', 'exp', log_dir=str(tmp_path))
+    wv.add_scalar({'loss': torch.tensor(1.5), 'rays': 7}, 3)
+    wv.add_scalar({'loss': 1.25}, 4)
+    wv.add_image({'img': torch.zeros(4, 4, 3)}, 4)
+    wv.watch_model(torch.nn.Linear(2, 2))
+    rows = [json.loads(l) for l in open(tmp_path / 'exp.jsonl')]
+    assert rows == [{'loss': 1.5, 'rays': 7.0, 'step': 3}, {'loss': 1.25, 'step': 4}]

@@ -841,7 +841,35 @@ __global__ __launch_bounds__(kBlk) void gemm_tn_kernel(const float* __restrict__
 
   // staging: BK rows x 128 floats = 1024 float4 per operand; krow = idx/32, c4 = idx%32
   float4 ra[4], rb[4];
+  // `fast` (uniform): 16-byte aligned operands whose widths are multiples of 4 — a float4 of a row is entirely inside or
+  // outside the matrix, so every staging load is one unconditional 16-byte load (an outside one reads a clamped address and
+  // is zeroed); whole tiles (the common case: M, N multiples of 128, K-tile inside the split) skip the zeroing too.
+  // Otherwise the element-guarded loader, whose per-lane branches keep the eight loads of a K-tile from overlapping.
+  const bool fast = a_vec && b_vec && (M & 3) == 0 && (N & 3) == 0 && M >= 4 && N >= 4;
+  const bool whole_mn = m0 + BM <= M && n0 + BN <= N;
   auto gload = [&](int64_t k0) {
+    if (fast) {
+      const bool whole = whole_mn && k0 + BK <= kend;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = tid + kBlk * r;
+        const int krow = idx >> 5, c4 = idx & 31;
+        const int64_t k = k0 + krow;
+        const int cm = m0 + c4 * 4, cn = n0 + c4 * 4;
+        if (whole) {
+          ra[r] = *reinterpret_cast<const float4*>(A + k * lda + cm);
+          rb[r] = *reinterpret_cast<const float4*>(B + k * ldb + cn);
+        } else {
+          const bool kin = k < kend, ain = kin && cm < M, bin = kin && cn < N;
+          const int64_t kc = kin ? k : kend - 1;
+          float4 a = *reinterpret_cast<const float4*>(A + kc * lda + (cm < M ? cm : M - 4));
+          float4 b = *reinterpret_cast<const float4*>(B + kc * ldb + (cn < N ? cn : N - 4));
+          ra[r] = make_float4(ain ? a.x : 0.f, ain ? a.y : 0.f, ain ? a.z : 0.f, ain ? a.w : 0.f);
+          rb[r] = make_float4(bin ? b.x : 0.f, bin ? b.y : 0.f, bin ? b.z : 0.f, bin ? b.w : 0.f);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int idx = tid + kBlk * r;

@@ -296,3 +296,33 @@ def test_curve_aware_loss_matches_the_reference_method():
         cc.run_curve_aware("cpu")
     finally:
         cpu_port.uninstall()
+
+
+def test_fl_proj_loss_batched_and_per_pair_routes_agree():
+    """curves.fl_proj_loss takes all (line, frame) chamfers as one distance tensor when every line has the same number of
+    samples and of ground-truth points, and falls back to one chamfer per pair otherwise: same value and gradients either
+    way (hidden samples, a frame that does not see a line, a line no frame sees, non-unit weights)."""
+    from recmv import curves
+    g = torch.Generator().manual_seed(21)
+    L, N, S, M = 3, 4, 17, 11
+    pts = [torch.randn(N, S, 3, generator=g).requires_grad_(True) for _ in range(L)]
+    gts = [torch.randn(N, M, 2, generator=g) for _ in range(L)]
+    masks = [(torch.rand(N, S, 1, generator=g) < 0.6).float().expand(N, S, 2).clone() for _ in range(L)]
+    masks[0][1] = 0.                      # frame 1 does not see line 0
+    masks[2][:] = 0.                      # nobody sees line 2
+    w = [1.0, 2.5, 0.7]
+    batched = curves.fl_proj_loss(pts, gts, masks, w)
+    gb = torch.autograd.grad(batched, pts, allow_unused=True)
+    # a ragged copy of the same problem (one extra hidden sample on line 1) takes the per-pair route
+    pts2 = [p.detach().clone().requires_grad_(True) for p in pts]
+    extra = torch.zeros(N, 1, 3)
+    ragged_pts = [pts2[0], torch.cat([pts2[1], extra], dim=1), pts2[2]]
+    ragged_masks = [masks[0], torch.cat([masks[1], torch.zeros(N, 1, 2)], dim=1), masks[2]]
+    looped = curves.fl_proj_loss(ragged_pts, gts, ragged_masks, w)
+    gl = torch.autograd.grad(looped, pts2, allow_unused=True)
+    assert torch.allclose(batched, looped, rtol=1e-6, atol=1e-7)
+    for a, b in zip(gb, gl):
+        if a is None or b is None:
+            assert (a is None or float(a.abs().max()) == 0.0) and (b is None or float(b.abs().max()) == 0.0)
+        else:
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)

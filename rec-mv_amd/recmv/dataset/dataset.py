@@ -110,15 +110,15 @@ class SceneDataset(torch.utils.data.Dataset):
             self.parsing_mask_ns.append(osp.join(self.root, 'parsing_SCH_ATR/%s.npy' % stem))
             assert osp.isfile(self.mask_ns[-1]) and osp.isfile(self.parsing_mask_ns[-1])
         self.H, self.W, _ = read_image_bgr(self.mask_ns[0]).shape
-        data = np.load(osp.join(self.root, 'smpl_rec.npz'))
-        self.poses = torch.from_numpy(data['poses'].astype(np.float32)).view(-1, 24, 3)
-        self.trans = torch.from_numpy(data['trans'].astype(np.float32)).view(-1, 3)
-        self.shape = torch.from_numpy(data['shape'].astype(np.float32)).view(-1)
-        self.gender = str(data['gender']) if 'gender' in data else 'neutral'
-        self.video_segmented_index = []
-        if 'vid_seg_indices' in data:
-            seg = data['vid_seg_indices']
-            self.video_segmented_index = seg[0:-1].tolist() if type(seg) == np.ndarray else seg[0:-1]
+        smpl = np.load(osp.join(self.root, 'smpl_rec.npz'))
+
+        def f32(key, *shape):
+            return torch.from_numpy(smpl[key].astype(np.float32)).view(*shape)
+
+        self.poses, self.trans, self.shape = f32('poses', -1, 24, 3), f32('trans', -1, 3), f32('shape', -1)
+        self.gender = str(smpl['gender']) if 'gender' in smpl else 'neutral'
+        seg = smpl['vid_seg_indices'] if 'vid_seg_indices' in smpl else []
+        self.video_segmented_index = list(np.asarray(seg).tolist()[:-1])          # cut points between concatenated videos
         cam = np.load(osp.join(self.root, 'camera.npz'))
         fl_dir = osp.join(self.root, self.FEATURE_LINE_DIR)
         assert osp.exists(fl_dir)
@@ -427,11 +427,12 @@ class Large_Pose_SceneDataset(People_Snapshot_SceneDataset):
         self.a_pose = a_pose
         n_all = len(self)
         joints_idx = [_lower_bound(self.joints_frame_ids, idx) for idx in range(n_all)]
-        self.trans[self.a_pose_end:, -1] = self.trans[self.a_pose_end, -1]
+        first, last = self.a_pose_start, self.a_pose_end
+        self.trans[last:, 2] = self.trans[last, 2]                                   # depth frozen after the A-pose turn
         self.trans = one_euro_smooth(self.trans.detach().cpu(), min_cutoff=0.004, beta=0.7, d_cutoff=1.)
-        self.shape = torch.from_numpy(self.tcmr_betas[self.a_pose_start:self.a_pose_end + 1].mean(0)).float()
-        tcmr_poses = torch.from_numpy(self.tcmr_poses[joints_idx]).view(-1, 24, 3).float()
-        self.poses[self.a_pose_end + 1:len(tcmr_poses)] = tcmr_poses[self.a_pose_end + 1:]
+        self.shape = torch.from_numpy(self.tcmr_betas[first:last + 1].mean(0)).float()
+        tcmr = torch.from_numpy(self.tcmr_poses[joints_idx]).float().view(-1, 24, 3)
+        self.poses[last + 1:len(tcmr)] = tcmr[last + 1:]
         fl_dir = osp.join(data_root, 'mask2fl')
         self.start_idx = 0
         if osp.exists(fl_dir):
@@ -469,9 +470,9 @@ class ClipSampler(torch.utils.data.Sampler):
         self.start = n_frames - self.n * clip_size
 
     def __iter__(self):
-        start = random.sample(list(range(0, self.start + 1)), 1)[0] if self.shuffle else 0
-        assert start + self.n * self.clip_size <= len(self.data_source)
-        clips = torch.arange(start, start + self.n * self.clip_size).view(self.n, self.clip_size)
+        first = random.sample(range(self.start + 1), 1)[0] if self.shuffle else 0
+        assert first + self.n * self.clip_size <= len(self.data_source)
+        clips = torch.arange(first, first + self.n * self.clip_size).view(self.n, self.clip_size)
         if self.shuffle:
             clips = clips[torch.randperm(self.n)]
         return iter(clips.view(-1).tolist())
@@ -489,14 +490,12 @@ class RandomSampler(torch.utils.data.Sampler):
         self.start = self.length - intersect * (self.n - 1)
 
     def __iter__(self):
+        first = random.sample(range(self.start), 1)[0] if self.shuffle else 0      # (one draw of Python's generator)
+        picks = torch.arange(first, self.length, self.intersect)
+        assert picks.numel() == self.n
         if self.shuffle:
-            start = random.sample(list(range(0, self.start)), 1)[0]
-            index = torch.arange(start, self.length, self.intersect)
-            index = index[torch.randperm(self.n)]
-        else:
-            index = torch.arange(0, self.length, self.intersect)
-        assert index.numel() == self.n
-        return iter(index.view(-1).tolist())
+            picks = picks[torch.randperm(self.n)]                                  # (one permutation of torch's)
+        return iter(picks.tolist())
 
     def __len__(self):
         return self.n
@@ -506,22 +505,20 @@ def getDatasetAndLoader(root, conds_lens, batch_size, shuffle, num_workers, opt_
                         data_type=None, curve_sampling=1, a_pose=False):
     """dataset/dataset.py:1159-1183: the capture as a dataset with its learnable tensors switched on, and a DataLoader
     over a shuffled RandomSampler."""
+    with_a_pose = {'people_snap': People_Snapshot_SceneDataset, 'large_pose': Large_Pose_SceneDataset}
     if data_type == 'scene':
         dataset = SceneDataset(root, conds_lens, garment_type, curve_sampling=curve_sampling)
-    elif data_type == 'people_snap':
-        dataset = People_Snapshot_SceneDataset(root, conds_lens, garment_type, curve_sampling=curve_sampling, a_pose=a_pose)
-    elif data_type == 'large_pose':
-        dataset = Large_Pose_SceneDataset(root, conds_lens, garment_type, curve_sampling=curve_sampling, a_pose=a_pose)
+    elif data_type in with_a_pose:
+        dataset = with_a_pose[data_type](root, conds_lens, garment_type, curve_sampling=curve_sampling, a_pose=a_pose)
     elif data_type in ('snug', 'synthe'):
         raise NotImplementedError("data type {}: its pre-processing is outside this package (recmv/dataset/dataset.py)".format(
             data_type))
     else:
         raise NotImplementedError('data type {} is not implemented'.format(data_type))
-    if opt_pose:
-        dataset.poses.requires_grad_(True)
-    if opt_trans:
-        dataset.trans.requires_grad_(True)
+    for tensor, learn in ((dataset.poses, opt_pose), (dataset.trans, opt_trans)):
+        if learn:
+            tensor.requires_grad_(True)
     dataset.opt_camera_params(opt_camera)
-    sampler = RandomSampler(dataset, 1, shuffle)
-    dataloader = torch.utils.data.DataLoader(dataset, batch_size, sampler=sampler, num_workers=num_workers)
-    return dataset, dataloader
+    loader = torch.utils.data.DataLoader(dataset, batch_size, sampler=RandomSampler(dataset, 1, shuffle),
+                                         num_workers=num_workers)
+    return dataset, loader

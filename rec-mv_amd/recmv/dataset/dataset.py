@@ -31,7 +31,7 @@ from ..engineer.utils.featureline_utils import check_feature_lines, obtain_featu
 from ..engineer.utils.polygons import uniformsample
 from ..utils.constant import ATR_PARSING, FL_INFOS
 
-__all__ = ["SceneDataset", "People_Snapshot_SceneDataset", "Large_Pose_SceneDataset", "one_euro_smooth", "ClipSampler", "RandomSampler", "getDatasetAndLoader",
+__all__ = ["SceneDataset", "Init_Fl_SceneDataset", "People_Snapshot_SceneDataset", "Large_Pose_SceneDataset", "one_euro_smooth", "ClipSampler", "RandomSampler", "getDatasetAndLoader",
            "read_image_bgr", "dct_space"]
 
 
@@ -276,6 +276,15 @@ class SceneDataset(torch.utils.data.Dataset):
             out['albedo'] = torch.from_numpy((alb / 255. - 0.5) * 2.).view(self.H, self.W, 3)
         return idx, out
 
+    def get_init_fl_datasets(self, batch_size, sampler, num_workers):
+        """The frames that supervise the feature lines, as a loader of their own for the start-up registration of the
+        line templates (:97-106; same in every capture class).  `sampler` is accepted and replaced, as in the reference."""
+        sampler_idx = np.where(np.asarray(self.fl_supervised))[0].tolist()
+        init_fl = Init_Fl_SceneDataset(self.root, self.conds_lens, self.garment_type, self.fl_sampling, self.curve_sampling,
+                                       sampler_idx)
+        return torch.utils.data.DataLoader(init_fl, batch_size, sampler=RandomSampler(init_fl, 1, True),
+                                           num_workers=num_workers)
+
     # ---------------------------------------------------------------------------------------------- learnable state
     def opt_camera_params(self, conf):
         keys = {'focal_length': 'focal_length', 'princeple_points': 'princeple_points', 'cam2world_coord_quat': 'quat',
@@ -364,6 +373,38 @@ class People_Snapshot_SceneDataset(SceneDataset):
 
     def __getitem__(self, idx):
         out = self._sample(idx)
+        if self.require_albedo:
+            alb = read_image_bgr(osp.join(self.root, 'albedos/%d.png' % idx)).astype(np.float32)
+            out['albedo'] = torch.from_numpy((alb / 255. - 0.5) * 2.).view(self.H, self.W, 3)
+        return idx, out
+
+
+class Init_Fl_SceneDataset(SceneDataset):
+    """A capture restricted to the frames `sample_idx` (:894-1000): what `get_init_fl_datasets` hands to the start-up
+    registration.  Feature lines come from `mask2fl/` when the capture has it, else `featurelines/`; a frame without an
+    annotation file of its own has every line flagged absent."""
+
+    def __init__(self, data_root, conds_lens={}, garment_type="", fl_sampling=100, curve_sampling=1, sample_idx=[]):
+        super().__init__(data_root, conds_lens, garment_type, fl_sampling, curve_sampling=curve_sampling)
+        fl_dir = osp.join(data_root, 'mask2fl')
+        if not osp.exists(fl_dir):
+            fl_dir = osp.join(data_root, 'featurelines')
+        self.read_feature_lines(fl_dir)
+        self.frame_num = len(sample_idx)
+        self.idx = list(sample_idx)
+
+    def read_feature_lines(self, path):
+        files, self.fl_paths, self.fl_supervised = self._assign_feature_line_files(path)
+        self.a_pose_start, self.a_pose_end = _frame_number(files[0]), _frame_number(files[-1])
+
+    def _annotated(self, idx):
+        return bool(self.fl_supervised[idx])
+
+    def __getitem__(self, idx):
+        idx = self.idx[idx]
+        out = self._sample(idx)
+        if self.gt_joints2d is not None:
+            out['gt_joints2d'] = self.gt_joints2d[idx]
         if self.require_albedo:
             alb = read_image_bgr(osp.join(self.root, 'albedos/%d.png' % idx)).astype(np.float32)
             out['albedo'] = torch.from_numpy((alb / 255. - 0.5) * 2.).view(self.H, self.W, 3)

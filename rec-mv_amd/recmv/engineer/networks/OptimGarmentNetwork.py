@@ -9,7 +9,7 @@ reference), with the reference's call signatures on top of the MI355X hot loop (
 `forward` takes the mini-batch dict the reference's DataLoader collates (`datas`: img, normal, mask, one segmentation
 per garment, fl_pts, fl_masks — dataset/dataset.py:617-680) and reads its ground truth from it; the per-frame learnable
 tensors and the camera come from `optNet.dataset`, as in the reference (:1888-1910).  Everything else
-(`propagateTmpPsGrad`, `discretizeSDF`, `marching_cube_update`, `mask_loss`, `sample_train_ray`, `surface_render_loss`,
+(`initializeTmpSDF`, `initializeSDF`, `initializeFL`, `propagateTmpPsGrad`, `discretizeSDF`, `marching_cube_update`, `mask_loss`, `sample_train_ray`, `surface_render_loss`,
 `project_2d_loss`, `curve_aware_loss`, `dct_poses_loss`, `opt_times`, `info`, `engine`, ...) is HotLoop's.
 """
 import torch
@@ -46,13 +46,11 @@ class OptimGarmentNetwork(HotLoop):
         return self
 
     def align_fl(self, path=None):
-        """train.py:209.  The reference registers template curves to the first frames here (`engineer.core`
-        initialisers, out of scope); the synthetic pipeline draws the curves on the initial garment surfaces."""
+        """train.py:209.  The reference rebuilds its template feature lines from the SMPL garment assets, applies the
+        registration stored in `path` (`fl_init/init_trans_matrix.pth`, written by `initializeFL` /
+        `engineer.core.fl_optimizer.scale_rigid_optimizer`) and samples the explicit curves from them (:3485-3546).  The
+        asset pipeline is outside this package: without templates the curves are drawn on the initial garment surfaces."""
         if not self.curves:
             self.curves = True
             self._init_curves(0)
         return self
-
-    def initializeTmpSDF(self, *args, **kwargs):
-        raise NotImplementedError("initializeTmpSDF (OptimGarmentNetwork.py:490-578, the 1200-epoch IGR fit of the SDF to "
-                                  "SMPL before the loop) is a start-up step outside the hot-path scope (SURVEY.md §8)")

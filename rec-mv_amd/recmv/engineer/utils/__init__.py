@@ -1,2 +1,3 @@
-"""engineer.utils of the reference: the two helpers the data path uses (feature-line annotation files, polyline resampling)."""
-from . import featureline_utils, polygons  # noqa: F401
+"""engineer.utils of the reference: the helpers the data path uses (feature-line annotation files, polyline resampling) and the
+rigid / scale transforms of the feature-line templates (start-up registration)."""
+from . import featureline_utils, matrix_transform, polygons  # noqa: F401

@@ -466,6 +466,100 @@ class HotLoop:
         if getattr(self, 'curves', False):
             self.fl_optimizer = torch.optim.AdamW(self.inter_free_curve.parameters(), lr=1e-4)              # :712
 
+    # ------------------------------------------------------------------------------------------ start-up stage
+    def initializeSDF(self, network, optimizer, sche, batch_size, nepochs, device, vs, ns, with_normals, save_name, log=print):
+        """OptimGarmentNetwork.py:387-443 — fit an SDF net to an oriented point cloud before the loop (IGR): |f| on the
+        surface points, the eikonal term on points scattered around them and in the box, and (with normals) ∇f against the
+        point normals; `nepochs` passes over shuffled mini-batches of `batch_size` points, the scheduler stepped per epoch,
+        the state dict written to `save_name`.  Positional-encoding weights are off (ratio -1), as in the reference.
+        On the GPU the value and ∇ₓf come from one jet pass per batch (csrc/mlp_jet.hip) instead of a double backward."""
+        for epoch in range(1, nepochs + 1):
+            permute = torch.randperm(vs.shape[0])
+            evs, ens = torch.split(vs[permute], batch_size), torch.split(ns[permute], batch_size)
+            for data_index, (mnfld_pnts, normals) in enumerate(zip(evs, ens)):
+                mnfld_pnts = mnfld_pnts.to(device)
+                nonmnfld_pnts = utils.sample_points(mnfld_pnts, 1.8, 0.01)      # local (sigma 0.01) + uniform in the box
+                mnfld_pnts.requires_grad_()
+                nonmnfld_pnts.requires_grad_()
+                mnfld_pred = network(mnfld_pnts, -1, jet=True, features=False)
+                mnfld_grad = network.gradient(mnfld_pnts, mnfld_pred)
+                nonmnfld_pred = network(nonmnfld_pnts, -1, jet=True, features=False)
+                nonmnfld_grad = network.gradient(nonmnfld_pnts, nonmnfld_pred)
+                mnfld_loss = mnfld_pred.abs().mean()
+                grad_loss = ((nonmnfld_grad.norm(2, dim=-1) - 1) ** 2).mean()
+                loss = mnfld_loss + 0.1 * grad_loss
+                if with_normals:
+                    normals_loss = (mnfld_grad - normals.to(device).view(-1, 3)).abs().norm(2, dim=1).mean()
+                    loss = loss + 1.0 * normals_loss
+                else:
+                    normals_loss = torch.zeros(1)
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+                if log is not None and data_index == len(evs) - 1:
+                    log('Train Epoch: {}\tTrain Loss: {:.6f}\tManifold loss: {:.6f}\tGrad loss: {:.6f}\tNormals Loss: {:.6f}'
+                        .format(epoch, loss.item(), mnfld_loss.item(), grad_loss.item(), normals_loss.item()))
+            sche.step()
+        torch.save(network.state_dict(), save_name)
+
+    def initializeFL(self, dataloader, n_epochs, device, save_mesh_name):
+        """OptimGarmentNetwork.py:470-486 — register the template feature lines (`self.garment_fl_templates`: {line name:
+        mesh}) to the annotated frames; writes `<folder of save_mesh_name>/fl_init/init_trans_matrix.pth`."""
+        from .engineer.core.fl_optimizer import scale_rigid_optimizer
+        from .utils.constant import FL_INFOS
+        save_fl_path = os.path.join(os.path.dirname(save_mesh_name), 'fl_init')
+        os.makedirs(save_fl_path, exist_ok=True)
+        return scale_rigid_optimizer(self.deformer.defs[1], self.garment_fl_templates, (self.tmpBodyVs, self.tmpBodyFs), None,
+                                     self.dataset, dataloader, save_fl_path, FL_INFOS[self.garment_type], device=device)
+
+    def initializeTmpSDF(self, nepochs, save_name, with_normals=False, dataloader=None, body_points=None,
+                         garment_points=None, fl_templates=None, log=print):
+        """OptimGarmentNetwork.py:490-578 — the pre-fit train.py runs when there is no `initial_sdf_idr_*.pth` yet: register
+        the template feature lines (when `fl_templates` and a loader are given), then fit the body net to the SMPL
+        template and every garment net to its closed garment template, each for `nepochs` epochs of 5000-point batches
+        (Adam 5e-3, halved every 500 epochs), saved under the reference's file names (`..sdf..` / `..sdf_<garment>..`).
+
+        The reference cuts the garment templates and their feature lines out of its SMPL garment assets
+        (`../smpl_clothes_template`, laplacian registration to the registered lines, hole closing — mesh tools outside this
+        package); here the caller passes the result: `body_points` = (vertices, normals or None) of the canonical body
+        (default `self.tmpBodyVs` / `self.tmpBodyNs`), `garment_points` = one (vertices, normals) per garment."""
+        if fl_templates is not None:
+            self.garment_fl_templates = fl_templates
+            if dataloader is not None:
+                self.initializeFL(dataloader, nepochs, self.device, save_name)
+        if body_points is None:
+            body_points = (getattr(self, 'tmpBodyVs', None), getattr(self, 'tmpBodyNs', None))
+        if body_points[0] is None or garment_points is None or len(garment_points) != self.garment_size:
+            raise ValueError("initializeTmpSDF needs the canonical body points and one (vertices, normals) pair per garment "
+                             "(%s): the reference builds them from its SMPL garment template assets" % ', '.join(self.garment_names))
+
+        def fit(network, points, name):
+            vs, ns = points[0].to(self.device), points[1]
+            use_normals = bool(with_normals) and ns is not None
+            ns = ns.to(self.device) if ns is not None else torch.ones_like(vs) / math.sqrt(3)
+            for p in network.parameters():
+                p.requires_grad_(True)
+            optimizer = torch.optim.Adam([{"params": network.parameters(), "lr": 0.005, "weight_decay": 0}])
+            sche = torch.optim.lr_scheduler.StepLR(optimizer, 500, 0.5)
+            self.initializeSDF(network, optimizer, sche, 5000, nepochs, self.device, vs, ns, use_normals, name, log=log)
+
+        log and log('Fitting_body_net!')
+        fit(self.sdf, body_points, save_name)
+        for g_name, points, net in zip(self.garment_names, garment_points, self.garment_nets):
+            template = self.FL_GARMENT.get(g_name, g_name)
+            log and log('Fitting_garment_net {}!'.format(template))
+            fit(net, points, save_name.replace("sdf", 'sdf_{}'.format(template)))
+        if self.large_pose:
+            self.freeze_sdf()
+
+    def load_init_sdf_vertices(self, verts, faces=None):
+        """OptimGarmentNetwork.py:176-178 — keep the body mesh extracted from the pre-fitted SDF (train.py:198); accepts the
+        (vertices, faces) pair or a mesh object with `.vertices` / `.faces`."""
+        if faces is None:
+            verts, faces = verts.vertices, verts.faces
+        self.tmp_sdf_body_vs = torch.as_tensor(verts).float().to(self.device)
+        self.tmp_sdf_face_vs = torch.as_tensor(faces).float().to(self.device)
+
     def _deform_garments(self, N, frame_ids, ratio):
         """The deformed garment vertices of this iteration, with their autograd graph (mask_loss :910).  The reference
         evaluates the same expression a second time per garment inside fl_visible_by_body_zbuff (:1396) — same

@@ -30,6 +30,7 @@ ALIASES = {
     "dataset": "recmv.dataset", "dataset.dataset": "recmv.dataset.dataset",
     "engineer.utils": "recmv.engineer.utils", "engineer.utils.featureline_utils": "recmv.engineer.utils.featureline_utils",
     "engineer.utils.polygons": "recmv.engineer.utils.polygons",
+    "engineer.utils.matrix_transform": "recmv.engineer.utils.matrix_transform",
     "engineer": "recmv.engineer", "engineer.core": "recmv.engineer.core",
     "engineer.core.fl_optimizer": "recmv.engineer.core.fl_optimizer",
     "engineer.core.beta_optimizer": "recmv.engineer.core.beta_optimizer",

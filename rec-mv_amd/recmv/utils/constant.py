@@ -1,7 +1,8 @@
 """Name tables the data path needs (utils/constant.py of the reference): which feature lines a capture has
 (FL_INFOS, :133-175) and which ATR human-parsing classes make up a garment region (ATR_PARSING, :199-208).  These are data the
 reference's directory layout is keyed on, kept verbatim; everything else of that module (colour maps, template lists) belongs
-to tools outside the hot path."""
+to tools outside the hot path.  INI_FL_SCALE (:236-244): the radial scale every template feature line starts from in the
+start-up registration (engineer/core/fl_optimizer.py:141)."""
 
 _UPPER_LOWER = ['neck', 'left_cuff', 'right_cuff', 'upper_bottom', 'left_pant', 'right_pant']
 
@@ -37,3 +38,6 @@ ATR_PARSING = {
     'bottom': [5, 6, 8],
     'upper_bottom': [1, 2, 3, 4, 5, 7, 8, 11, 16, 17, 14, 15, 6],
 }
+
+INI_FL_SCALE = {'neck': 1.5, 'right_cuff': 1.5, 'left_cuff': 1.5, 'left_pant': 1.5, 'right_pant': 1.5, 'upper_bottom': 2.,
+                'bottom_curve': 2.}

@@ -84,6 +84,38 @@ class Intersect_Free_Curve(nn.Module):
         return {'center_offset': 0 * center_loss, 'diff_a_loss': diff_a_loss.sum()}
 
 
+def longest_boundary_loop(faces):
+    """Vertex indices along the longer of the two boundary loops of a ribbon mesh — the curve a template feature line stands
+    for (`Intersect_Free_Curve.extract_edge`, engineer/utils/garment_structure.py:149-173, which asks trimesh's `outline()`
+    for the boundary paths and keeps the one with more points).  trimesh is third party and absent: the loops are found here
+    by walking the edges that belong to exactly one face, starting at each loop's lowest vertex index towards its lower
+    neighbour — the same point set; start and direction of trimesh's path are not reproduced (parity unpinned)."""
+    import numpy as np
+    f = np.asarray(faces.detach().cpu().numpy() if torch.is_tensor(faces) else faces, dtype=np.int64)
+    edges = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], axis=0), axis=1)
+    uniq, count = np.unique(edges, axis=0, return_counts=True)
+    border = uniq[count == 1]
+    nbrs = {}
+    for a, b in border:
+        nbrs.setdefault(int(a), []).append(int(b))
+        nbrs.setdefault(int(b), []).append(int(a))
+    assert all(len(v) == 2 for v in nbrs.values()), "a feature-line template is a band: every boundary vertex has two boundary edges"
+    loops, seen = [], set()
+    for start in sorted(nbrs):
+        if start in seen:
+            continue
+        loop, prev, cur = [start], start, min(nbrs[start])
+        seen.add(start)
+        while cur != start:
+            loop.append(cur)
+            seen.add(cur)
+            a, b = nbrs[cur]
+            prev, cur = cur, (b if a == prev else a)
+        loops.append(loop)
+    assert len(loops) == 2, "a feature-line template has two boundary loops, found %d" % len(loops)
+    return loops[0] if len(loops[0]) > len(loops[1]) else loops[1]
+
+
 def chamfer_distance_sum(x, y):
     """pytorch3d `chamfer_distance(x, y, point_reduction='sum')[0]` for one cloud pair x [1,n,D], y [1,m,D]: squared
     distance of every point to its nearest neighbour in the other set, summed over both directions.  An empty side

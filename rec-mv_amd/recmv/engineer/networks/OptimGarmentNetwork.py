@@ -45,12 +45,53 @@ class OptimGarmentNetwork(HotLoop):
     def eval(self):
         return self
 
-    def align_fl(self, path=None):
-        """train.py:209.  The reference rebuilds its template feature lines from the SMPL garment assets, applies the
-        registration stored in `path` (`fl_init/init_trans_matrix.pth`, written by `initializeFL` /
-        `engineer.core.fl_optimizer.scale_rigid_optimizer`) and samples the explicit curves from them (:3485-3546).  The
-        asset pipeline is outside this package: without templates the curves are drawn on the initial garment surfaces."""
-        if not self.curves:
-            self.curves = True
-            self._init_curves(0)
+    def align_fl(self, fl_align_path=None, epoch=0, fl_templates=None, sample_num=200):
+        """train.py:209, OptimGarmentNetwork.py:3485-3546.  With template feature lines (`fl_templates` or
+        `self.garment_fl_templates`: {line name: ribbon mesh}) and the registration `fl_align_path`
+        (`fl_init/init_trans_matrix.pth`, written by `initializeFL`): apply the stored scale / translation / rotation to every
+        line, remember how to take a registered line back onto the canonical body (`cano_fl_to_body_trans`), and sample the
+        explicit curves the loop optimises from the longer boundary of every registered ribbon (`inter_free_curve`).
+        The reference rebuilds the templates from its SMPL garment assets here (mesh tools outside this package); without
+        templates the curves are rings drawn on the initial garment surfaces."""
+        import os
+        import numpy as np
+        from ... import curves as fl
+        from ...model import Inverse_Fl_Body
+        from ...utils.constant import FL_INFOS
+        from ..utils.matrix_transform import FeatureLineMesh, scale_icp_rotate_center_transform
+        from ..utils.polygons import uniformsample3d
+        templates = fl_templates if fl_templates is not None else getattr(self, 'garment_fl_templates', None)
+        if templates is None or fl_align_path is None or not os.path.isfile(fl_align_path):
+            if not self.curves:
+                self.curves = True
+                self._init_curves(0)
+            return self
+        dev = self.device
+        names = FL_INFOS[self.garment_type]
+        lines = [templates[n].to(dev) for n in names]
+        stored = torch.load(fl_align_path)
+        if 'rigid_scale' not in stored:
+            raise NotImplementedError
+        rigid_R, rigid_T, rigid_scale = (stored[k].to(dev) for k in ('rigid_R', 'rigid_T', 'rigid_scale'))
+        self.fl_names = list(names)
+        self.cano_fl_to_body_trans = Inverse_Fl_Body(lines, self.fl_names, rigid_T, rigid_scale)
+        moved = scale_icp_rotate_center_transform(lines, rigid_R, rigid_T, rigid_scale)
+        self.cano_fl_to_body_trans.set_rigid_center([v.mean(0, keepdim=True) for v in moved], self.fl_names)
+        self.fl_meshes = [FeatureLineMesh(v, m.faces_packed()) for v, m in zip(moved, lines)]
+        curves = []
+        for mesh in self.fl_meshes:
+            loop = fl.longest_boundary_loop(mesh.faces_packed())
+            pts = uniformsample3d(mesh.verts_packed()[loop].detach().cpu().numpy(), sample_num)
+            curves.append(torch.from_numpy(np.ascontiguousarray(pts)).float().to(dev))
+        shortest = min(c.shape[0] for c in curves)     # (sample_num or sample_num - 1 points per line, see uniformsample3d; the
+        curves = [c[:shortest] for c in curves]        #  reference stacks them as they come and needs them equal)
+        # their counterparts on the canonical body: the sampled curves with translation and scale undone
+        # (Intersect_Free_Curve.initialize_parameters, engineer/utils/garment_structure.py:77)
+        smpl_curves = self.cano_fl_to_body_trans(curves, self.fl_names)
+        self.fl_extract = {g: [n for n in fl.FL_EXTRACT[self.FL_GARMENT[g]] if n in self.fl_names] for g in self.garment_names}
+        self.inter_free_curve = fl.Intersect_Free_Curve(curves, smpl_curves, self.fl_names).to(dev)
+        self._ensure_body_template()
+        self.curves = True
+        if getattr(self, 'garment_vs', None):
+            self.fl_optimizer = torch.optim.AdamW(self.inter_free_curve.parameters(), lr=1e-4)
         return self

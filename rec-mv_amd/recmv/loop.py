@@ -222,7 +222,7 @@ class HotLoop:
 
     def __init__(self, conf, device, n_frames=64, H=512, W=512, stage='coarse', seed=0, resolutions=None,
                  skin_grid=(65, 225, 129), bbox=None, world_size=1, rank=0, curves=False, large_pose=False,
-                 dataset=None):
+                 dataset=None, skinner_state=None):
         self.conf_all = conf
         self.conf = conf.get_config('loss_' + stage)
         self.device = device
@@ -237,6 +237,20 @@ class HotLoop:
         self.sdf = getTmpSdf(device, mult, bias=0.5)
         self.garment_nets = torch.nn.ModuleList([getTmpSdf(device, conf.get_int('garment_sdf_net.multires'), bias=b)
                                                  for b in (0.55, 0.45)])
+        skinner = None
+        if skinner_state is not None:
+            # the reference's `initial_skinner_<pose type>.pth` (model/network.py:225-236): the baked skinning volume (or the
+            # FITE-diffused one beside the capture), its box, the rest skeleton, the A-pose inverse transforms, the SMPL
+            # template in canonical space; the canonical box is the volume's box plus the reference's margins (:291)
+            st = skinner_state
+            skinner = LBSkinner(st['ws'], st['bmins'], st['bmaxs'], st['Js'], st['parents'], init_pose=st['init_pose'],
+                                align_corners=False, extra_trans=st.get('extra_trans'), bbox_center=st['bbox_center'],
+                                bbox_extend=st['bbox_extend'])
+            self.tmpBodyVs = torch.as_tensor(st['tmpBodyVs']).float().to(device)
+            self.tmpBodyFs = torch.as_tensor(st['tmpBodyFs']).long().to(device)
+            if bbox is None:
+                lo, hi = skinner.bbox_size()
+                bbox = (tuple(float(v) for v in lo.view(-1)), tuple(float(v) for v in hi.view(-1)))
         if bbox is None:
             # The geometric initialisation gives only approximately the nominal sphere radius.  Size the canonical
             # box from the measured radius so that the coarse pyramid yields about the vertex counts the reference
@@ -244,23 +258,9 @@ class HotLoop:
             r = max(_zero_level_radius(n, device) for n in self.garment_nets)
             h = 1.45 * r
             bbox = ((-h, -1.44 * h, -h), (h, 1.44 * h, h))
-        D, Hh, Ww = skin_grid
         bmin, bmax = bbox
-        # Synthetic rig: a 24-joint skeleton that fits the canonical box and SMOOTH blend weights (softmax of the
-        # squared distance to the joints), like the diffused SMPL weights the reference bakes into its volume
-        # (model/Deformer.py:289-330).  Smoothness matters for the workload: neighbouring surface points must stay
-        # neighbours after skinning, or the rasterised first hits are no starting points for the root finder.
-        Js = _skeleton(0.5 * (bmax[1] - bmin[1]) / 1.44 / 1.45)
-        axes = [torch.linspace(bmin[i], bmax[i], n + 1)[:-1] + 0.5 * (bmax[i] - bmin[i]) / n
-                for i, n in ((2, D), (1, Hh), (0, Ww))]                       # voxel centres, align_corners=False
-        zz, yy, xx = torch.meshgrid(*axes, indexing='ij')
-        vox = torch.stack([xx, yy, zz], dim=-1)                                # [D,H,W,3] (x,y,z)
-        d2 = (torch.cdist(vox.view(-1, 3), Js) ** 2).view(D, Hh, Ww, 24)
-        sigma = 0.12 * (bmax[1] - bmin[1]) / 1.44 / 1.45
-        ws = torch.softmax(-d2 / (2.0 * sigma * sigma), dim=-1).permute(3, 0, 1, 2).unsqueeze(0).contiguous()
-        skinner = LBSkinner(ws, list(bmin), list(bmax), Js, SMPL_PARENTS, init_pose=_apose(), align_corners=False,
-                            bbox_extend=torch.tensor([bmax[i] - bmin[i] for i in range(3)]),
-                            bbox_center=torch.tensor([(bmax[i] + bmin[i]) / 2 for i in range(3)]))
+        if skinner is None:
+            skinner = self._synthetic_skinner(bmin, bmax, skin_grid)
         self.deformer = CompositeDeformer([getTranslatorNet(device, conf.get_config('mlp_deformer')),
                                            skinner.to(device)])
         self.netRender = getRenderNet(device, conf.get_config('render_net'))
@@ -302,6 +302,25 @@ class HotLoop:
         self.optimizer = self.rebuild_optimizer()
         cams = self._cameras()
         self.angThred = cams.angThreshold(0.5)                                   # OptimNetwork.py:65
+
+    @staticmethod
+    def _synthetic_skinner(bmin, bmax, skin_grid):
+        """Synthetic rig: a 24-joint skeleton that fits the canonical box and SMOOTH blend weights (softmax of the squared
+        distance to the joints), like the diffused SMPL weights the reference bakes into its volume (model/Deformer.py:
+        289-330).  Smoothness matters for the workload: neighbouring surface points must stay neighbours after skinning,
+        or the rasterised first hits are no starting points for the root finder."""
+        D, Hh, Ww = skin_grid
+        Js = _skeleton(0.5 * (bmax[1] - bmin[1]) / 1.44 / 1.45)
+        axes = [torch.linspace(bmin[i], bmax[i], n + 1)[:-1] + 0.5 * (bmax[i] - bmin[i]) / n
+                for i, n in ((2, D), (1, Hh), (0, Ww))]                       # voxel centres, align_corners=False
+        zz, yy, xx = torch.meshgrid(*axes, indexing='ij')
+        vox = torch.stack([xx, yy, zz], dim=-1)                                # [D,H,W,3] (x,y,z)
+        d2 = (torch.cdist(vox.view(-1, 3), Js) ** 2).view(D, Hh, Ww, 24)
+        sigma = 0.12 * (bmax[1] - bmin[1]) / 1.44 / 1.45
+        ws = torch.softmax(-d2 / (2.0 * sigma * sigma), dim=-1).permute(3, 0, 1, 2).unsqueeze(0).contiguous()
+        return LBSkinner(ws, list(bmin), list(bmax), Js, SMPL_PARENTS, init_pose=_apose(), align_corners=False,
+                         bbox_extend=torch.tensor([bmax[i] - bmin[i] for i in range(3)]),
+                         bbox_center=torch.tensor([(bmax[i] + bmin[i]) / 2 for i in range(3)]))
 
     # ------------------------------------------------------------------------------------------ stages / state
     def set_stage(self, stage, resolutions=None):
@@ -602,6 +621,21 @@ class HotLoop:
     # ------------------------------------------------------------------------------------------ feature curves
     FL_GARMENT = {'upper': 'short_sleeve_upper', 'bottom': 'long_pants'}      # female-3-casual, utils/constant.py:116
 
+    def _ensure_body_template(self):
+        """`tmpBodyVs` / `tmpBodyFs`: the SMPL template in canonical space the body z-buffer tests rasterise (6890 vertices in
+        the reference).  A stored skinner file brings it along; otherwise a coarse extraction of the body SDF stands in."""
+        if getattr(self, 'tmpBodyVs', None) is not None:
+            return
+        dev, res = self.device, 41
+        lo, hi = self.engine.b_min.view(-1), self.engine.b_max.view(-1)
+        ax = [torch.linspace(float(lo[i]), float(hi[i]), res, device=dev) for i in range(3)]
+        X, Y, Z = torch.meshgrid(*ax, indexing='ij')
+        with torch.no_grad():
+            vol = self.sdf(torch.stack([X, Y, Z], -1).view(-1, 3), 1.0, features=False).view(res, res, res).contiguous()
+        step = [float(a[1] - a[0]) for a in ax]
+        self.tmpBodyVs, self.tmpBodyFs = MCGpu.mc_gpu(vol, step[0], step[1], step[2], float(ax[0][0]), float(ax[1][0]),
+                                                      float(ax[2][0]), 0.0)
+
     def _init_curves(self, seed, samples=200, gt_samples=100):
         """Synthetic stand-in for `align_fl` + the dataset's 2-D feature lines (OptimGarmentNetwork.py:3380-3546,
         dataset/dataset.py:113-155): closed rings on the initial garment spheres as canonical curves, the same rings
@@ -641,16 +675,7 @@ class HotLoop:
         owner = {n: r for name, r in zip(self.garment_names, radii) for n in self.fl_extract[name]}
         smpl_list = [ring[n] * (r_body / owner[n]) for n in self.fl_names]
         self.inter_free_curve = fl.Intersect_Free_Curve(curves_list, smpl_list, self.fl_names).to(dev)
-        # SMPL-template stand-in: a coarse extraction of the body SDF (the reference's tmpBodyVs has 6890 vertices)
-        res = 41
-        ax = [torch.linspace(float(self.engine.b_min.view(-1)[i]), float(self.engine.b_max.view(-1)[i]), res, device=dev)
-              for i in range(3)]
-        X, Y, Z = torch.meshgrid(*ax, indexing='ij')
-        with torch.no_grad():
-            vol = self.sdf(torch.stack([X, Y, Z], -1).view(-1, 3), 1.0, features=False).view(res, res, res).contiguous()
-        step = [float(a[1] - a[0]) for a in ax]
-        v, f = MCGpu.mc_gpu(vol, step[0], step[1], step[2], float(ax[0][0]), float(ax[1][0]), float(ax[2][0]), 0.0)
-        self.tmpBodyVs, self.tmpBodyFs = v, f
+        self._ensure_body_template()
         # 2-D ground truth per image slot: the rings seen without articulation, jittered by a pixel
         cams = self._cameras()
         idx = torch.linspace(0, samples - 1, gt_samples).long()

@@ -1,6 +1,7 @@
 """Deformer stack of the hot path (model/Deformer.py of the reference):
 
   CompositeDeformer  :22-34    sequential application (offset MLP, then LBS)
+  Inverse_Fl_Body    :36-122   registered feature line -> its place on the canonical body (undo translation and scale)
   MLPTranslator      :141-206  PE(p) (+) per-frame cond -> 4x512 ReLU MLP -> offset, returns p + offset
   LBSkinner          :216-445  SMPL linear-blend skinning with weights sampled from a 3-D grid
 
@@ -136,6 +137,38 @@ class CompositeDeformer(nn.Module):
         g = lbs.backward_input(sv1, g_d)
         g = mlp.backward_input(sv0, g)
         return d, loss2, angle, g
+
+
+class Inverse_Fl_Body(nn.Module):
+    """model/Deformer.py:36-122 — takes a feature line that `align_fl` has registered (translated by `rigid_t`, scaled by
+    `rigid_scale` about the template line's centroid) back to where its template lies on the canonical body:
+    ((v - t) - centre) / scale + centre.  Built from the UNregistered template lines; `set_rigid_center` keeps the
+    registered centroids."""
+
+    def __init__(self, cano_fl_meshes, fl_names, rigid_t_list, rigid_scale_list):
+        super().__init__()
+        self.fl_names = fl_names
+        self.v_dirs_dict, self.init_scale_dict, self.verts_dict, self.center_dict = {}, {}, {}, {}
+        self.rigid_t_dict, self.rigid_scale_dict, self.rigid_center_dict = {}, {}, {}
+        for name, mesh, rigid_t, rigid_s in zip(fl_names, cano_fl_meshes, rigid_t_list, rigid_scale_list):
+            v = mesh.verts_packed() if hasattr(mesh, 'verts_packed') else mesh
+            center = v.mean(0, keepdim=True)
+            v_dirs = (v - center) / ((v - center).norm(dim=1, keepdim=True) + 1e-6)
+            self.v_dirs_dict[name] = v_dirs
+            self.init_scale_dict[name] = ((v - center) * v_dirs).sum(dim=-1, keepdim=True)
+            self.verts_dict[name], self.center_dict[name] = v, center
+            self.rigid_t_dict[name], self.rigid_scale_dict[name] = rigid_t, rigid_s
+
+    def set_rigid_center(self, rigid_center_list, fl_names):
+        assert len(rigid_center_list) == len(fl_names)
+        self.rigid_center_dict = dict(zip(fl_names, rigid_center_list))
+
+    def forward(self, rigid_cano_fl_verts, fl_names):
+        out = []
+        for verts, name in zip(rigid_cano_fl_verts, fl_names):
+            center = self.center_dict[name]
+            out.append(((verts - self.rigid_t_dict[name]) - center) / self.rigid_scale_dict[name] + center)
+        return out
 
 
 class MLPTranslator(nn.Module):

@@ -244,9 +244,15 @@ def getOptNet(dataset, save_folder, N, bmins, bmaxs, resolutions, device, conf, 
     `get_camera_parameters`, `learnable_weights`, `get_batchframe_data`, `poses`, `trans`, `conds`, `camera_params`,
     `frame_num`); `None` builds the synthetic frames.  `bmins` / `bmaxs` the canonical box, `resolutions` the pyramid of
     the current stage (rows (W,H,D)), `N` the batch size (kept for signature compatibility: the stage config sets it).
-    `sdf_initialized` is -1: the networks start from the geometric initialisation (the reference returns the number of
-    IGR pre-fit epochs still to run, :203-221 — a start-up step outside this package's scope).
+    `sdf_initialized` (:201-221): -1 when `<dataset.root>/<save_folder>/initial_sdf_idr_<multires>_<pose type>.pth` (and its
+    `initial_sdf_<garment>_idr_...` companions) exist — they are loaded into the body / garment nets, with the body mesh
+    `...ply` beside them when there is one; otherwise the number of pre-fit epochs the caller still has to run
+    (`optNet.initializeTmpSDF`, `train.initial_iters`, 1200 when that is <= 0).  Synthetic frames (no dataset) start from the
+    geometric initialisation: -1.
+    `<dataset.root>/<save_folder>/initial_skinner_<pose type>.pth` (:223-236), when present and `use_initial_skinner`, supplies
+    the skinning volume, its box, the rest skeleton, the SMPL template and the fitted shape; otherwise the rig is synthetic.
     `opt_large=True` returns the large-pose variant (OptimGarmentNetwork_LargePose, :337-340)."""
+    import os.path as osp
     from ..engineer.networks import OptimGarmentNetwork, OptimGarmentNetwork_LargePose
     cls = OptimGarmentNetwork_LargePose if opt_large else OptimGarmentNetwork
     bbox = None if bmins is None else (tuple(float(v) for v in bmins), tuple(float(v) for v in bmaxs))
@@ -255,6 +261,38 @@ def getOptNet(dataset, save_folder, N, bmins, bmaxs, resolutions, device, conf, 
     if dataset is not None:
         kw.update(n_frames=int(getattr(dataset, 'frame_num', len(dataset))), H=int(dataset.H), W=int(dataset.W))
     kw.update(hotloop_kwargs)
+    root = getattr(dataset, 'root', None)
+    pose_type = conf.get_int('train.skinner_pose_type') if 'train.skinner_pose_type' in conf else 0
+    if root is not None and save_folder is not None and use_initial_skinner and 'skinner_state' not in kw:
+        # :223-236 — the skinner the reference baked on its first run (`initial_skinner_<pose type>.pth`): its volume is
+        # replaced by the FITE-diffused weights beside the capture when they are there, the fitted SMPL shape goes back to
+        # the dataset.  (Building that file — SMPL shape fit, template posing, weight diffusion — needs the SMPL model.)
+        skinner_file = osp.join(root, save_folder, 'initial_skinner_%d.pth' % pose_type)
+        if osp.isfile(skinner_file):
+            data = torch.load(skinner_file, map_location='cpu', weights_only=False)     # (holds numpy arrays: parents)
+            dataset.shape = data['betas']
+            fite = osp.join(root, 'diffused_skinning_weights.npy')
+            if osp.isfile(fite):
+                data = dict(data, ws=torch.from_numpy(np.load(fite)).float()[None])
+            kw['skinner_state'] = data
     optNet = cls(conf, device, **kw)
     optNet.visualizer = visualizer
-    return optNet, -1
+    sdf_initialized = -1
+    if root is not None and save_folder is not None:
+        sdf_initialized = conf.get_int('train.initial_iters') if 'train.initial_iters' in conf else 0
+        stem = 'initial_sdf_idr_%d_%d' % (conf.get_int('sdf_net.multires'), pose_type)
+        sdf_file = osp.join(root, save_folder, stem + '.pth')
+        if osp.isfile(sdf_file) and use_initial_sdf:
+            optNet.sdf.load_state_dict(torch.load(sdf_file, map_location='cpu'))
+            for name, net in zip(optNet.garment_names, optNet.garment_nets):
+                garment_file = sdf_file.replace('sdf', 'sdf_{}'.format(optNet.FL_GARMENT.get(name, name)))      # :213-216
+                assert osp.isfile(garment_file), garment_file
+                net.load_state_dict(torch.load(garment_file, map_location='cpu'))
+            mesh_file = osp.join(root, save_folder, stem + '.ply')
+            if osp.isfile(mesh_file):
+                from ..utils import read_ply
+                optNet.load_init_sdf_vertices(*read_ply(mesh_file))
+            sdf_initialized = -1
+        elif sdf_initialized <= 0:
+            sdf_initialized = 1200
+    return optNet, sdf_initialized

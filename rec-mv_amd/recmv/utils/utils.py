@@ -18,7 +18,7 @@ from ..FastMinv import Fast3x3Minv, Fast3x3Minv_backward
 
 __all__ = ["save_model", "load_model", "set_hierarchical_config", "FastDiff3x3MinvFunction", "quat2mat", "annealing_weights", "GMRobustError", "sample_points",
            "compute_Jacobian", "batch_compute_Jacobian", "compute_deformed_normals", "compute_cardinal_rays",
-           "compute_netRender_color", "scatter_mean"]
+           "compute_netRender_color", "scatter_mean", "write_ply", "read_ply"]
 
 
 class FastDiff3x3MinvFunction(Function):
@@ -217,3 +217,38 @@ def load_model(name, optNet, dataset, device, subsdfmodel=None, model_rm_prefix=
     dataset.shape = restore(dataset.shape, saved['shape'])
     dataset.camera_params = {k: restore(v, saved[k]) for k, v in dataset.camera_params.items()}
     return optNet, dataset, saved['epoch']
+
+
+def write_ply(name, verts, faces):
+    """A triangle mesh as a binary little-endian PLY (float32 vertices, int32 faces) — what train.py exports after the
+    SDF pre-fit (`initial_sdf_idr_*.ply`, train.py:196-206 through trimesh) and getOptNet reads back (model/network.py:210)."""
+    v = np.ascontiguousarray(torch.as_tensor(verts).detach().cpu().numpy(), dtype='<f4').reshape(-1, 3)
+    f = np.ascontiguousarray(torch.as_tensor(faces).detach().cpu().numpy(), dtype='<i4').reshape(-1, 3)
+    rows = np.empty(f.shape[0], dtype=[('n', 'u1'), ('idx', '<i4', (3,))])
+    rows['n'], rows['idx'] = 3, f
+    with open(name, 'wb') as fh:
+        fh.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\n"
+                  "property float z\nelement face %d\nproperty list uchar int vertex_indices\nend_header\n"
+                  % (v.shape[0], f.shape[0])).encode('ascii'))
+        fh.write(v.tobytes())
+        fh.write(rows.tobytes())
+
+
+def read_ply(name):
+    """(vertices float32 [V,3], faces int64 [F,3]) of a PLY written by `write_ply` (x, y, z vertices; triangle faces)."""
+    with open(name, 'rb') as fh:
+        header = b''
+        while not header.endswith(b'end_header\n'):
+            line = fh.readline()
+            if not line:
+                raise ValueError(name + ': not a PLY file')
+            header += line
+        text = header.decode('ascii')
+        if 'format binary_little_endian 1.0' not in text or 'property list uchar int vertex_indices' not in text:
+            raise ValueError(name + ': only the layout write_ply produces is read')
+        count = {ln.split()[1]: int(ln.split()[2]) for ln in text.splitlines() if ln.startswith('element ')}
+        v = np.frombuffer(fh.read(12 * count['vertex']), dtype='<f4').reshape(-1, 3)
+        rows = np.frombuffer(fh.read(13 * count['face']), dtype=[('n', 'u1'), ('idx', '<i4', (3,))])
+    if not (rows['n'] == 3).all():
+        raise ValueError(name + ': non-triangle face')
+    return torch.from_numpy(v.copy()), torch.from_numpy(rows['idx'].astype(np.int64))

@@ -16,8 +16,12 @@ at the stage switches and `latest.pth` every epoch in the reference's checkpoint
 load_model), resume with the scheduler fast-forwarded and `opt_times` recomputed (train.py:232-260).
 `train_large_pose.py` is the same driver on the large-pose variant (SDF nets frozen, resume from `a-pose.pth`).
 
-What differs: the SDF / feature-curve / SMPL-shape initialisers and wandb are outside this tier: the
-canonical surfaces and curves start from the synthetic initialisation; scalars go to wandb when it is installed, to
+What differs: the reference cuts its garment templates (point clouds for the SDF pre-fit, feature-line ribbons) out of SMPL
+garment assets with mesh tools that are outside this tier.  The pre-fit itself is here: with
+`--init-points <npz>` (body / garment point clouds) and no `initial_sdf_idr_*.pth` under the save folder yet, the nets are
+fitted for `train.initial_iters` epochs (`initializeTmpSDF`, train.py:179-206) and the files written under the reference's
+names; a later run loads them (getOptNet).  Without the clouds the canonical surfaces start from the geometric
+initialisation, and the curves from rings on those surfaces.  Scalars go to wandb when it is installed, to
 `<save-folder>/logs/<exp_name>.jsonl` otherwise.  `--data <capture> --data_type scene|people_snap|large_pose`
 reads a capture directory in the reference's layout through `recmv.dataset` (images, masks, garment regions, 2-D feature
 lines, SMPL poses, camera); without a capture the frames are synthetic (`recmv.loop.SyntheticFrames`; `--frames` sets
@@ -57,6 +61,9 @@ def build_parser(large_pose=False):
     parser.add_argument('--no-curves', action='store_true',
                         help='skip the feature-curve branch (project_2d_loss) the reference runs every iteration')
     parser.add_argument('--frames', type=int, default=64, help='number of synthetic frames')
+    parser.add_argument('--init-points', default=None, metavar='NPZ',
+                        help='oriented point clouds for the SDF pre-fit: body_vs, body_ns, <garment>_vs, <garment>_ns '
+                             '(what the reference cuts out of its SMPL garment templates)')
     parser.add_argument('--max-iters', type=int, default=-1, help='stop after this many optimiser iterations (smoke runs)')
     return parser
 
@@ -103,6 +110,33 @@ def _scalars(loss, info):
         elif isinstance(v, (int, float)):
             out[k] = float(v)
     return out
+
+
+def prefit_sdf(optNet, nepochs, config, args, save_root, rank):
+    """train.py:179-206 — no `initial_sdf_idr_*.pth` yet: fit the body net and the garment nets to the template point clouds
+    (`optNet.initializeTmpSDF`), write the state dicts under the reference's names, extract the fitted body at the coarse
+    resolution and keep it (`load_init_sdf_vertices`, `initial_sdf_idr_*.ply`).  The clouds come from `--init-points`; without
+    them the nets keep their geometric initialisation (the reference builds the clouds from its SMPL garment assets)."""
+    import numpy as np
+    import torch
+    from recmv import utils
+    if args.init_points is None:
+        if rank == 0:
+            print('no initial_sdf_idr_*.pth under %s and no --init-points: the SDF nets start from the geometric initialisation' % save_root)
+        return
+    pts = np.load(args.init_points)
+    cloud = lambda key: (torch.from_numpy(pts[key + '_vs']).float(),
+                         torch.from_numpy(pts[key + '_ns']).float() if key + '_ns' in pts else None)
+    stem = 'initial_sdf_idr_%d_%d' % (config.get_int('sdf_net.multires'),
+                                      config.get_int('train.skinner_pose_type') if 'train.skinner_pose_type' in config else 0)
+    optNet.initializeTmpSDF(nepochs, osp.join(save_root, stem + '.pth'), True, body_points=cloud('body'),
+                            garment_points=[cloud(name) for name in optNet.garment_names], log=print if rank == 0 else None)
+    verts_list, faces_list = optNet.discretizeSDF(-1, None)
+    optNet.load_init_sdf_vertices(verts_list[0], faces_list[0])
+    if rank == 0:
+        utils.write_ply(osp.join(save_root, stem + '.ply'), verts_list[0], faces_list[0])
+        for name, v, f in zip(optNet.garment_names, verts_list[1:], faces_list[1:]):
+            utils.write_ply(osp.join(save_root, stem.replace('sdf', 'sdf_' + optNet.FL_GARMENT.get(name, name)) + '.ply'), v, f)
 
 
 def stage_of_epoch(config, epoch):
@@ -175,6 +209,8 @@ def main(argv=None, large_pose=False):
                                         world_size=world, rank=rank, curves=not args.no_curves)
     dataset = optNet.dataset
     dataloader = FrameLoader(optNet) if capture is None else CaptureLoader(capture, optNet)
+    if sdf_initialized > 0:
+        prefit_sdf(optNet, sdf_initialized, config, args, save_root, rank)
     if rank == 0:                                 # train.py:86: wandb when it is there, a jsonl file under logs/ otherwise
         from recmv.engineer.visualizer import wandb_visualizer
         optNet.visualizer = wandb_visualizer(args.project_name, args.exp_name, resume=False, log_dir=osp.join(save_root, 'logs'))

@@ -89,6 +89,7 @@ class TorchOnCpu:
 
 
 def transforms():
+    ref_loader.ref_module("model.network")       # the reference's own entry order (its packages import each other)
     MT = ref_loader.ref_module("engineer.utils.matrix_transform")
     g = torch.Generator().manual_seed(21)
     poses = torch.randn(5, 6, generator=g)
@@ -98,7 +99,28 @@ def transforms():
     T = 0.1 * torch.randn(5, 1, 3, generator=g)
     S = torch.tensor([1.5, 0.7, -0.3, 2.0, 1.0])                                   # a negative scale: clamped to 0
     cat = lambda lst: torch.cat(lst, 0)
-    return dict(mt_poses=poses, mt_lines=cat(lines), mt_split=torch.tensor([float(l.shape[0]) for l in lines]), mt_T=T, mt_S=S,
+    # closed 3-D polylines: fewer points than asked for (both outcomes of the closing test), more (farthest-point branch)
+    PG = ref_loader.ref_module("engineer.utils.polygons")
+    extra = {}
+    for tag, n, newn, flip in (('few', 23, 60, 1.), ('few_flipped', 23, 60, -1.), ('many', 90, 40, 1.)):
+        t = torch.sort(torch.rand(n, generator=g) * 2 * np.pi).values
+        ring = torch.stack([flip * (0.3 + 0.05 * torch.sin(3 * t)) * torch.cos(t), 0.1 * torch.cos(2 * t),
+                            (0.25 + 0.03 * torch.cos(5 * t)) * torch.sin(t)], -1) + torch.tensor([0.1, -0.2, 0.05])
+        extra['us3d_%s_in' % tag] = ring
+        extra['us3d_%s_out' % tag] = torch.from_numpy(np.ascontiguousarray(PG.uniformsample3d(ring.numpy(), newn))).float()
+        extra['us3d_%s_n' % tag] = torch.tensor([float(newn)])
+    cloud = torch.randn(2, 50, 3, generator=g)
+    extra['fps_in'], extra['fps_out'] = cloud, PG.farthest_point_sample(cloud, 12).float()
+    # Inverse_Fl_Body (model/Deformer.py:36-122) on the lines above, their scale-registered versions as input
+    Dref = ref_loader.ref_module("model.Deformer")
+    names = ['a', 'b', 'c', 'd', 'e']
+    holders = [Meshes([l], [torch.zeros(1, 3, dtype=torch.long)]) for l in lines]
+    inv = Dref.Inverse_Fl_Body(holders, names, T, S.abs() + 0.2)
+    registered = MT.scale_icp_rotate_center_transform(lines, R, T, S.abs() + 0.2)
+    inv.set_rigid_center([v.mean(0, keepdim=True) for v in registered], names)
+    extra['inv_S'] = S.abs() + 0.2
+    extra['inv_in'], extra['inv_out'] = cat(registered), cat(inv(registered, names))
+    return dict(extra, mt_poses=poses, mt_lines=cat(lines), mt_split=torch.tensor([float(l.shape[0]) for l in lines]), mt_T=T, mt_S=S,
                 mt_R=R, mt_icp=cat(MT.icp_rotate_transfrom(lines, R, T)),
                 mt_scale_icp=cat(MT.scale_icp_rotate_transfrom(lines, R, T, S)),
                 mt_center=cat(MT.center_transform(lines, R, T)),
@@ -219,7 +241,7 @@ def sdf_prefit(out):
             stored = torch.load(name)
         tag = 'prefit%d_' % int(with_normals)
         for k in sc.PREFIT_KEYS:
-            out[tag + k.replace('.', '_')] = dict(net.named_parameters())[k].detach().clone()
+            out[tag + k.replace('.', '_')] = dict(net.named_parameters())[k].detach()[:sc.PREFIT_ROWS].clone()
             assert torch.equal(stored[k], dict(net.named_parameters())[k].detach())
         out[tag + 'lr'] = torch.tensor([opt.param_groups[0]['lr']])
         probe = sc.prefit_probe()

@@ -38,13 +38,18 @@ from utils.constant import FL_INFOS, ATR_PARSING
 from engineer.utils.featureline_utils import obtain_feature_lines, check_feature_lines
 from engineer.utils.polygons import uniformsample
 assert issubclass(OptimGarmentNetwork_LargePose, OptimGarmentNetwork)
-for fn in (scale_rigid_optimizer, rigid_optimizer, smpl_beta_optimizer):
-    try:
-        fn()
-    except NotImplementedError as e:
-        assert "hot path" in str(e)
-    else:
-        raise SystemExit("initialiser stub did not raise")
+from engineer.utils.matrix_transform import compute_rotation_matrix_from_ortho6d, scale_icp_rotate_center_transform
+from engineer.utils.polygons import uniformsample3d
+from model.Deformer import Inverse_Fl_Body
+from utils.constant import INI_FL_SCALE
+from dataset.dataset import Init_Fl_SceneDataset
+assert callable(scale_rigid_optimizer) and callable(rigid_optimizer) and hasattr(OptimGarmentNetwork, "initializeTmpSDF")
+try:
+    smpl_beta_optimizer()
+except NotImplementedError as e:
+    assert "hot path" in str(e)
+else:
+    raise SystemExit("initialiser stub did not raise")
 import torch
 a = [torch.rand(2, 5, 3) * 50]; b = [torch.rand(2, 4, 2) * 50]; m = [torch.ones(2, 5, 3, dtype=torch.bool)]
 assert float(fl_proj_loss(a, b, m, [1.0])) > 0

@@ -94,3 +94,201 @@ def test_sdf_prefit_matches_the_reference_method():
         sc.run_prefit(load(), "cpu")
     finally:
         cpu_port.uninstall()
+
+
+def test_prefit_files_carry_the_reference_names_and_are_loaded_back(tmp_path):
+    """train.py:179-206 + model/network.py:201-221: no initial_sdf_idr_*.pth -> getOptNet asks for the pre-fit (1200 epochs
+    by default); train.prefit_sdf fits body + garment nets to the clouds of --init-points, writes the state dicts and the
+    extracted meshes under the reference's names; the next getOptNet loads them and asks for nothing."""
+    import argparse
+    import os
+    from oracle import cpu_port
+    import train
+    from recmv.dataset import getDatasetAndLoader
+    from recmv.hocon import ConfigFactory
+    from recmv.model.network import getOptNet
+    from recmv.utils import read_ply
+    conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    root = sc.write_capture(str(tmp_path))
+    conds_lens = {'deformer': conf.get_int('mlp_deformer.condlen') * 3, 'renderer': conf.get_int('render_net.condlen')}
+    torch.manual_seed(3)
+    ds, _ = getDatasetAndLoader(root, conds_lens, 3, True, 0, True, True, conf.get_config('train.opt_camera'), cf.GARMENT_TYPE,
+                                data_type='scene')
+    g = torch.Generator().manual_seed(8)
+    clouds = {}
+    for name, r in (('body', 0.40), ('upper', 0.50), ('bottom', 0.45)):
+        d = torch.nn.functional.normalize(torch.randn(240, 3, generator=g), dim=1)
+        clouds[name + '_vs'], clouds[name + '_ns'] = (d * r).numpy(), d.numpy()
+    del clouds['bottom_ns']                                            # a cloud without normals: fitted without the normal term
+    np.savez(tmp_path / 'clouds.npz', **clouds)
+    save_root = os.path.join(root, 'result')
+    os.makedirs(save_root)
+    cpu_port.install()
+    try:
+        res, box = [(9, 11, 7), (17, 21, 13)], ((-0.9, -1.2, -0.6), (0.9, 1.2, 0.6))
+        make = lambda: getOptNet(ds, 'result', 3, box[0], box[1], res, 'cpu', conf, curves=False, skin_grid=(5, 9, 7))
+        optNet, todo = make()
+        assert todo == 1200
+        before = [p.detach().clone() for p in optNet.garment_nets[0].parameters()]
+        train.prefit_sdf(optNet, 2, conf, argparse.Namespace(init_points=None), save_root, 0)          # no clouds: untouched
+        assert all(torch.equal(a, b) for a, b in zip(before, optNet.garment_nets[0].parameters()))
+        train.prefit_sdf(optNet, 2, conf, argparse.Namespace(init_points=str(tmp_path / 'clouds.npz')), save_root, 0)
+        names = ['initial_sdf_idr_6_0', 'initial_sdf_short_sleeve_upper_idr_6_0', 'initial_sdf_long_pants_idr_6_0']
+        for n in names:
+            assert os.path.isfile(os.path.join(save_root, n + '.pth')) and os.path.isfile(os.path.join(save_root, n + '.ply')), n
+        assert not all(torch.equal(a, b) for a, b in zip(before, optNet.garment_nets[0].parameters()))
+        again, todo = make()
+        assert todo == -1
+        for a, b in zip([optNet.sdf] + list(optNet.garment_nets), [again.sdf] + list(again.garment_nets)):
+            assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+        v, f = read_ply(os.path.join(save_root, names[0] + '.ply'))
+        assert torch.equal(again.tmp_sdf_body_vs, v) and torch.equal(again.tmp_sdf_face_vs, f.float())
+        assert torch.equal(v, optNet.tmp_sdf_body_vs.cpu()) and int(f.max()) < v.shape[0] and f.shape[0] > 0
+    finally:
+        cpu_port.uninstall()
+
+
+def test_a_stored_skinner_file_is_read_in_the_reference_layout(tmp_path):
+    """model/network.py:223-236: `initial_skinner_<pose type>.pth` (ws, bmins, bmaxs, Js, parents, init_pose, tmpBodyVs,
+    tmpBodyFs, betas, extra_trans, bbox_center, bbox_extend) + `diffused_skinning_weights.npy` beside the capture -> the
+    loop's skinner, its SMPL template, the dataset's shape and the canonical box (volume box + margins, :291)."""
+    import os
+    import common_setup as cs
+    from oracle import cpu_port
+    from recmv.dataset import getDatasetAndLoader
+    from recmv.hocon import ConfigFactory
+    from recmv.model import LBSkinner
+    from recmv.model.network import getOptNet
+    conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    root = sc.write_capture(str(tmp_path))
+    conds_lens = {'deformer': conf.get_int('mlp_deformer.condlen') * 3, 'renderer': conf.get_int('render_net.condlen')}
+    torch.manual_seed(3)
+    ds, _ = getDatasetAndLoader(root, conds_lens, 3, True, 0, True, True, conf.get_config('train.opt_camera'), cf.GARMENT_TYPE,
+                                data_type='scene')
+    baked = cs.build_skinner(LBSkinner)                            # plays the skinner of the reference's first run
+    geo = sc.geometry()
+    betas = torch.linspace(-1, 1, 10)
+    os.makedirs(os.path.join(root, 'result'))
+    torch.save({'ws': torch.zeros_like(baked.ws), 'bmins': baked.b_min, 'bmaxs': baked.b_max, 'Js': baked.Js,
+                'parents': baked.parents, 'init_pose': baked.init_pose, 'tmpBodyVs': geo['body_verts'],
+                'tmpBodyFs': geo['body_faces'], 'betas': betas, 'extra_trans': torch.tensor([[0.01, -0.02, 0.03]]),
+                'bbox_center': baked.bbox_center, 'bbox_extend': baked.bbox_extend},
+               os.path.join(root, 'result', 'initial_skinner_0.pth'))
+    np.save(os.path.join(root, 'diffused_skinning_weights.npy'), baked.ws[0].contiguous().numpy())
+    cpu_port.install()
+    try:
+        res = [(9, 11, 7), (17, 21, 13)]
+        optNet, _ = getOptNet(ds, 'result', 3, None, None, res, 'cpu', conf, curves=True)
+        sk = optNet.deformer.defs[1]
+        assert torch.equal(sk.ws, baked.ws) and torch.equal(sk.Js, baked.Js) and torch.equal(sk.init_pose, baked.init_pose)
+        assert torch.equal(sk.extra_trans, torch.tensor([[0.01, -0.02, 0.03]]))
+        assert torch.equal(ds.shape, betas)
+        assert torch.equal(optNet.tmpBodyVs, geo['body_verts']) and torch.equal(optNet.tmpBodyFs, geo['body_faces'])
+        lo, hi = baked.bbox_size()
+        torch.testing.assert_close(optNet.engine.b_min.view(-1).cpu(), lo.view(-1))
+        torch.testing.assert_close(optNet.engine.b_max.view(-1).cpu(), hi.view(-1))
+        pts = 0.3 * torch.randn(2, 40, 3, generator=torch.Generator().manual_seed(1))
+        poses, trans = cs.poses_trans(2, seed=5)
+        want = baked(pts, [poses, trans])
+        baked.extra_trans.copy_(torch.tensor([[0.01, -0.02, 0.03]]))
+        torch.testing.assert_close(sk(pts, [poses, trans]), baked(pts, [poses, trans]))
+        assert not torch.equal(want, baked(pts, [poses, trans]))                   # (the stored extra translation is in effect)
+        ignored, _ = getOptNet(ds, 'result', 3, None, None, res, 'cpu', conf, curves=False, use_initial_skinner=False,
+                               skin_grid=(5, 9, 7))
+        assert ignored.deformer.defs[1].ws.shape[2:] == (5, 9, 7)
+    finally:
+        cpu_port.uninstall()
+
+
+def test_closed_curve_resampling_and_body_inverse_match_the_reference():
+    """engineer/utils/polygons.py `uniformsample3d` (edge-proportional fill and the farthest-point branch that returns one
+    point less), `farthest_point_sample`; model/Deformer.py `Inverse_Fl_Body`."""
+    from recmv.engineer.utils import matrix_transform as mt
+    from recmv.engineer.utils.polygons import farthest_point_sample, uniformsample3d
+    from recmv.model import Inverse_Fl_Body
+    g = load()
+    for tag in ('few', 'few_flipped', 'many'):
+        got = uniformsample3d(g['us3d_%s_in' % tag].numpy(), int(g['us3d_%s_n' % tag]))
+        assert got.shape == tuple(g['us3d_%s_out' % tag].shape), tag
+        torch.testing.assert_close(torch.from_numpy(np.ascontiguousarray(got)).float(), g['us3d_%s_out' % tag], rtol=1e-6, atol=1e-7)
+    assert g['us3d_many_out'].shape[0] == int(g['us3d_many_n']) - 1
+    assert torch.equal(farthest_point_sample(g['fps_in'], 12).float(), g['fps_out'])
+    lines = list(torch.split(g["mt_lines"], [int(n) for n in g["mt_split"]]))
+    names = ['a', 'b', 'c', 'd', 'e']
+    inv = Inverse_Fl_Body([mt.FeatureLineMesh(v, torch.zeros(1, 3, dtype=torch.long)) for v in lines], names, g['mt_T'], g['inv_S'])
+    registered = list(torch.split(g['inv_in'], [int(n) for n in g["mt_split"]]))
+    inv.set_rigid_center([v.mean(0, keepdim=True) for v in registered], names)
+    torch.testing.assert_close(torch.cat(inv(registered, names), 0), g['inv_out'], rtol=1e-6, atol=1e-6)
+
+
+def test_align_fl_turns_a_stored_registration_into_the_loops_curves(tmp_path):
+    """OptimGarmentNetwork.align_fl (:3485-3546) on the registration the reference produced (startup.npz): every explicit
+    curve lies on the longer boundary of its registered ribbon, its canonical-body counterpart on the template's, and the
+    loop's curve branch runs on them."""
+    import os
+    from oracle import cpu_port
+    from recmv import curves as fl
+    from recmv.dataset import getDatasetAndLoader
+    from recmv.engineer.utils.matrix_transform import scale_icp_rotate_center_transform
+    from recmv.hocon import ConfigFactory
+    from recmv.model.network import getOptNet
+    g = load()
+    conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    conf.put('train.garment_type', cf.GARMENT_TYPE)
+    root = sc.write_capture(str(tmp_path))
+    conds_lens = {'deformer': conf.get_int('mlp_deformer.condlen') * 3, 'renderer': conf.get_int('render_net.condlen')}
+    torch.manual_seed(3)
+    ds, _ = getDatasetAndLoader(root, conds_lens, 3, True, 0, True, True, conf.get_config('train.opt_camera'), cf.GARMENT_TYPE,
+                                data_type='scene')
+    os.makedirs(os.path.join(root, 'result', 'fl_init'))
+    path = os.path.join(root, 'result', 'fl_init', 'init_trans_matrix.pth')
+    torch.save({'rigid_R': g['srig_R'], 'rigid_T': g['srig_T'], 'rigid_scale': g['srig_scale']}, path)
+    templates = sc.line_meshes(g, 'cpu')
+    # (the two rims of these ribbons have equally many vertices: the second loop found is kept, the reference's tie rule)
+    loops = {n: fl.longest_boundary_loop(m.faces_packed()) for n, m in templates.items()}
+    assert all(len(l) == m.verts_packed().shape[0] // 2 for l, m in zip(loops.values(), templates.values()))
+    cpu_port.install()
+    try:
+        res, box = [(9, 11, 7), (17, 21, 13)], ((-0.9, -1.2, -0.6), (0.9, 1.2, 0.6))
+        optNet, _ = getOptNet(ds, 'result', 3, box[0], box[1], res, 'cpu', conf, curves=False, skin_grid=(5, 9, 7))
+        assert not optNet.curves
+        optNet.align_fl(path, fl_templates=templates, sample_num=40)
+        assert optNet.curves and optNet.fl_names == sc.LINE_NAMES
+        curves = optNet.inter_free_curve().detach()                                     # [6,S,3]
+        assert curves.shape[0] == 6 and curves.shape[1] in (39, 40) and curves.shape[2] == 3
+        moved = scale_icp_rotate_center_transform([templates[n] for n in sc.LINE_NAMES], g['srig_R'], g['srig_T'], g['srig_scale'])
+        for i, n in enumerate(sc.LINE_NAMES):
+            rim = moved[i][loops[n]]
+            seg_a, seg_b = rim, rim.roll(-1, 0)                        # every sample lies on an edge of the registered rim
+            ab = (seg_b - seg_a)[None]
+            t = (((curves[i][:, None] - seg_a[None]) * ab).sum(-1) / (ab * ab).sum(-1)).clamp(0, 1)
+            d = ((seg_a[None] + t[..., None] * ab) - curves[i][:, None]).norm(dim=-1).min(1).values
+            assert float(d.max()) < 1e-5, (n, float(d.max()))
+            # its canonical-body counterpart: the same samples with translation and scale undone
+            body = optNet.inter_free_curve.query_canosmpl_verts([n])[0]
+            centre = templates[n].verts_packed().mean(0, keepdim=True)
+            want = ((curves[i] - g['srig_T'][i]) - centre) / g['srig_scale'][i] + centre
+            torch.testing.assert_close(body, want, rtol=1e-5, atol=1e-6)
+        assert set(optNet.fl_extract['upper']) == {'neck', 'left_cuff', 'right_cuff', 'upper_bottom'}
+        assert optNet.fl_extract['bottom'] == ['left_pant', 'right_pant']
+        # one iteration of the loop on these curves (train.py's sequence)
+        from recmv import utils
+        optNet, _ = utils.set_hierarchical_config(conf, 'coarse', optNet, None, res)
+        optimizer = optNet.rebuild_optimizer()
+        frames = [0, 3, 4]
+        datas = torch.utils.data.default_collate([ds[i][1] for i in frames])
+        ratio = {'sdfRatio': 1., 'deformerRatio': 0.5, 'renderRatio': 1.}
+        optimizer.zero_grad()
+        before = optNet.inter_free_curve.scale.detach().clone()
+        loss = optNet(datas, 16, ratio, torch.tensor(frames), '/tmp/debug', global_optimizer=optimizer)
+        loss.backward()
+        optNet.propagateTmpPsGrad(torch.tensor(frames), ratio)
+        optimizer.step()
+        assert torch.isfinite(loss) and torch.isfinite(optNet.info['fl_loss']['total'])
+        assert not torch.equal(before, optNet.inter_free_curve.scale.detach())          # the curve optimiser stepped
+        # without a stored file the stand-in rings are drawn instead
+        plain, _ = getOptNet(ds, 'result', 3, box[0], box[1], res, 'cpu', conf, curves=False, skin_grid=(5, 9, 7))
+        plain.align_fl(os.path.join(root, 'missing.pth'), fl_templates=templates)
+        assert plain.curves and plain.inter_free_curve().shape[1] == 200
+    finally:
+        cpu_port.uninstall()

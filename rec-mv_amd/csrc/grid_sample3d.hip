@@ -107,19 +107,20 @@ __global__ __launch_bounds__(kBlk) void gs3d_fwd_kernel(int64_t nthreads, const 
   }
 }
 
-// Forward for a channels-last f32 volume, one WAVE per (64 consecutive points, group of 4 channels): the workgroup's C/4
-// waves share the points (and, through the CU's L1, their 8 corner records); each lane has its 8 sixteen-byte loads in
-// flight at once instead of walking the channel groups one dependent round after the other, and the chip holds C/4
-// times as many of them.  The arithmetic per output element is the one of gs3d_fwd_kernel (same fma chain over the
-// corners): bit-identical.  Output stores are one coalesced run per channel (points along lanes).
-__global__ __launch_bounds__(1024) void gs3d_fwd_cg_kernel(int64_t nthreads, const float* __restrict__ input,
-                                                           Desc5 in, const float* __restrict__ grid, Desc5 gr,
-                                                           float* __restrict__ output, Desc5 out) {
+// Forward for a channels-last f32 volume whose corner record is G float4 (C = 4 G channels): lane t of a 64 G-thread workgroup
+// serves point t / G, channel group t % G, so the G lanes of a point read ONE corner record (16 G contiguous bytes, one or two
+// cache lines) with one instruction — a quarter of the cache lines per instruction that the wave-per-channel-group mapping
+// touches, which is what scattered points are bound by.  Every lane stores its own four channels (runs of 64 / G points per
+// channel row; the L2 merges them).  Arithmetic per output element: the fma chain of gs3d_fwd_kernel (bit-identical).
+template <int G>
+__global__ __launch_bounds__(64 * G) void gs3d_fwd_rec_kernel(int64_t nthreads, const float* __restrict__ input, Desc5 in,
+                                                             const float* __restrict__ grid, Desc5 gr,
+                                                             float* __restrict__ output, Desc5 out) {
   const int64_t D = in.size[2], H = in.size[3], W = in.size[4];
   const int64_t oD = gr.size[1], oH = gr.size[2], oW = gr.size[3];
-  const int lane = threadIdx.x & 63, ch = (threadIdx.x >> 6) * 4;
+  const int t = threadIdx.x, pt = t / G, ch = (t - pt * G) * 4;
   for (int64_t base = (int64_t)blockIdx.x * 64; base < nthreads; base += (int64_t)gridDim.x * 64) {
-    const int64_t index = base + lane;
+    const int64_t index = base + pt;
     if (index >= nthreads) continue;
     int64_t w, h, d, n;
     if (oD * oH == 1 && nthreads < (1ll << 31)) {      // a list of points per batch item: 32-bit index arithmetic
@@ -154,8 +155,7 @@ __global__ __launch_bounds__(1024) void gs3d_fwd_cg_kernel(int64_t nthreads, con
         a2 = fma(val[k].z, wgt[k], a2);
         a3 = fma(val[k].w, wgt[k], a3);
       }
-    float* o = output + n * out.stride[0] + d * out.stride[2] + h * out.stride[3] + w * out.stride[4] +
-               ch * out.stride[1];
+    float* o = output + n * out.stride[0] + d * out.stride[2] + h * out.stride[3] + w * out.stride[4] + ch * out.stride[1];
     o[0] = a0;
     o[out.stride[1]] = a1;
     o[2 * out.stride[1]] = a2;
@@ -382,15 +382,28 @@ extern "C" int recmv_grid_sample3d_forward(const void* input, const recmv_tensor
   hipStream_t s = (hipStream_t)stream;
   const int g = stream_grid(count, kBlk);
   if (dtype == RECMV_F32) {
-    // the wave-per-channel-group kernel wins while the launch is latency-bound (18 vs 24 us at 153 k surface-coherent
-    // points, 35 vs 111 us on random ones); past ~3e5 points the one-lane-per-point kernel amortises the per-point
-    // geometry better (30 vs 44 us at 461 k) — profiles/r02_kernel_only_v2_sampler_cg.txt
-    if (vec4_ok(input, in, dtype) && in.size[1] <= 64 && count >= 4096 && count <= 300000) {
-      const int waves = (int)(in.size[1] / 4);
+    // record-coalesced lanes while the launch is latency-bound: at 153 k points 16.8 us on surface-coherent points and 28.6 us
+    // on random ones, against 24 / 111 us for one lane per point; past ~3e5 points the one-lane-per-point kernel amortises the
+    // per-point geometry better on coherent points (30.7 vs 39.5 us at 461 k) — though not on random ones (346 vs 85 us) —
+    // profiles/r02_sampler_forward_ab.txt
+    const int G = (int)(in.size[1] / 4);
+    if (vec4_ok(input, in, dtype) && in.stride[4] == in.size[1] && count >= 4096 && count <= 300000 &&
+        (G == 1 || G == 2 || G == 3 || G == 4 || G == 6 || G == 8)) {
       const int64_t blocks = ceil_div(count, (int64_t)64);
-      const int64_t cap = (int64_t)kNumCU * (32 / waves > 0 ? 32 / waves : 1) * 2;
-      hipLaunchKernelGGL(gs3d_fwd_cg_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(64 * waves), 0, s, count,
-                         (const float*)input, in, (const float*)grid, gr, (float*)output, out);
+      const int64_t cap = (int64_t)kNumCU * 10;
+      const dim3 gdim((unsigned)(blocks < cap ? blocks : cap));
+#define RECMV_FWD_REC(GG)                                                                                          \
+  hipLaunchKernelGGL(gs3d_fwd_rec_kernel<GG>, gdim, dim3(64 * GG), 0, s, count, (const float*)input, in, (const float*)grid, \
+                     gr, (float*)output, out)
+      switch (G) {
+        case 1: RECMV_FWD_REC(1); break;
+        case 2: RECMV_FWD_REC(2); break;
+        case 3: RECMV_FWD_REC(3); break;
+        case 4: RECMV_FWD_REC(4); break;
+        case 6: RECMV_FWD_REC(6); break;
+        default: RECMV_FWD_REC(8); break;
+      }
+#undef RECMV_FWD_REC
     } else if (vec4_ok(input, in, dtype))
       hipLaunchKernelGGL((gs3d_fwd_kernel<float, 4>), dim3(g), dim3(kBlk), 0, s, count,
                          (const float*)input, in, (const float*)grid, gr, (float*)output, out);

@@ -112,6 +112,20 @@ def test_sampler_forward_backward_dbackward_vs_oracle(oracle, dtype, cl, C):
     assert a2_g is None and torch.equal(b2_g.cpu(), b2_o) and torch.equal(c2_g.cpu(), c2_o)
 
 
+@pytest.mark.parametrize("C", [4, 8, 12, 16, 24, 32, 20])
+def test_sampler_forward_record_lanes_vs_oracle(oracle, C):
+    """The record-coalesced forward (lane -> point, channel group; C / 4 in {1, 2, 3, 4, 6, 8}; 4096 <= P <= 300000) and the
+    fall-back for other widths (C = 20): bit-exact, incl. a ragged last block, points outside the volume and several batch
+    items."""
+    from recmv import GridSamplerMine
+    inp, grid = _sampler_case(torch.float32, C=C, dims=(9, 13, 11), P=4099 + 64 * 37 + 5, channels_last=True, seed=C, spread=2.6)
+    assert torch.equal(GridSamplerMine.forward(gpu(inp), gpu(grid), 0, 1).cpu(), oracle.gs3d_forward(inp, grid))
+    g = torch.Generator().manual_seed(C + 1)
+    inp3 = torch.randn(3, C, 7, 9, 8, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    grid3 = (torch.rand(3, 2, 3, 700, 3, generator=g) - 0.5) * 2.4
+    assert torch.equal(GridSamplerMine.forward(gpu(inp3), gpu(grid3), 0, 1).cpu(), oracle.gs3d_forward(inp3, grid3))
+
+
 def test_sampler_equals_torch_grid_sample_on_gpu():
     from recmv import GridSamplerMine
     inp, grid = _sampler_case(torch.float32, C=24, dims=(17, 29, 21), P=20000, channels_last=True)

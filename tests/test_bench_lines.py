@@ -7,7 +7,7 @@ from pathlib import Path
 import pytest
 
 PROFILES = Path(__file__).resolve().parent.parent / "profiles"
-LINES = sorted(PROFILES.glob("r02_bench_line_v6_*.json"))
+LINES = sorted(PROFILES.glob("r02_bench_line_v[67]_*.json"))
 
 
 def test_final_lines_are_committed():

@@ -4,6 +4,7 @@
   Inverse_Fl_Body    :36-122   registered feature line -> its place on the canonical body (undo translation and scale)
   MLPTranslator      :141-206  PE(p) (+) per-frame cond -> 4x512 ReLU MLP -> offset, returns p + offset
   LBSkinner          :216-445  SMPL linear-blend skinning with weights sampled from a 3-D grid
+  smooth_weights, compute_lbswField, initialLBSkinner  :533-626  start-up: bake SMPL's per-vertex blend weights into the volume
 
 All dense work goes through librecmv_hip.so: the MLP layers are fused MFMA kernels (ops.linear_act), the
 skinning-weight lookup is the double-differentiable HIP sampler (MCAcc.GridSamplerMine3dFunction) on a
@@ -493,7 +494,9 @@ class LBSkinner(nn.Module):
         hit = self.__dict__.get('_grid_cache')
         if hit is None or hit[0] != self.ws.data_ptr():
             center = self.bbox_center.detach().cpu().view(-1).tolist()
-            scale = (2.0 / self.bbox_extend.detach().cpu().view(-1)).tolist()
+            # (a skinner baked by the reference normalises with ONE extent — a cube, model/Deformer.py:609 —, the
+            # synthetic rig with one per axis)
+            scale = (2.0 / self.bbox_extend.detach().cpu().view(-1).expand(3)).tolist()
             hit = (self.ws.data_ptr(), lbs_grid(self.ws, center, scale))
             self.__dict__['_grid_cache'] = hit
         return hit[1]
@@ -533,3 +536,71 @@ class LBSkinner(nn.Module):
         from .. import chains
         ps, frame, A = saved[0], saved[1], saved[2]
         return chains.lbs_vjp_input(ps, frame, A, self._lbs_grid(), g_v.contiguous())
+
+
+# ------------------------------------------------------------------------------------------ start-up: baking the skinner
+def getSMPL(gender):
+    """The SMPL body model of the reference (`smpl_pytorch.SMPL.getSMPL`, un-vendored; its pkl files are not redistributable).
+    Used only by the start-up steps that build a skinner from scratch; pass `smpl=` to them to supply any object with the same
+    surface (`__call__(betas, poses, True) -> (verts, _, _)`, `skeleton(betas, True) -> (Js, _)`, `weight`, `parents`, `faces`,
+    `joint_regressor`)."""
+    try:
+        from smpl_pytorch.SMPL import getSMPL as ref_get
+    except ImportError as e:
+        raise ImportError("the SMPL model (smpl_pytorch + its model files) is not part of this package: pass smpl=<model> or "
+                          "start from an initial_skinner_<pose type>.pth baked by the reference") from e
+    return ref_get(gender)
+
+
+def smooth_weights(weights, times=3):
+    """model/Deformer.py:533-544 — `times` passes of: pull every interior voxel 30 % towards the mean of its six neighbours,
+    renormalise the channels of every voxel to sum 1."""
+    for _ in range(times):
+        c = weights[:, :, 1:-1, 1:-1, 1:-1]
+        mean = (weights[:, :, 2:, 1:-1, 1:-1] + weights[:, :, :-2, 1:-1, 1:-1] + weights[:, :, 1:-1, 2:, 1:-1]
+                + weights[:, :, 1:-1, :-2, 1:-1] + weights[:, :, 1:-1, 1:-1, 2:] + weights[:, :, 1:-1, 1:-1, :-2]) / 6.0
+        weights[:, :, 1:-1, 1:-1, 1:-1] = (c - mean) * 0.7 + mean
+        weights = weights / weights.sum(1, keepdim=True)
+    return weights
+
+
+def compute_lbswField(bmins, bmaxs, resolutions, smpl_verts, smpl_ws, align_corners=False, mean_neighbor=5, smooth_times=30):
+    """model/Deformer.py:546-591 — blend weights of every voxel centre of a (W, H, D) grid over [bmins, bmaxs]: inverse-distance
+    mean of the `mean_neighbor` nearest template vertices' weights (distances clamped to [1e-4, 1]), then `smooth_weights`.
+    Returns [1, J, D, H, W]."""
+    device = smpl_verts.device
+    bmins = torch.as_tensor(bmins).float().to(device).view(1, -1)
+    bmaxs = torch.as_tensor(bmaxs).float().to(device).view(1, -1)
+    W, H, D = resolutions
+    res = torch.tensor(resolutions).float().to(device).view(1, -1)
+    gridD, gridH, gridW = torch.meshgrid(torch.arange(D, device=device), torch.arange(H, device=device),
+                                         torch.arange(W, device=device), indexing='ij')
+    coords = torch.stack([gridW, gridH, gridD]).view(3, -1).t().float()
+    unit = coords / (res - 1) if align_corners else coords / res + (1.0 / res) / 2
+    centres = unit * (bmaxs - bmins) + bmins
+    rows = []
+    for chunk in torch.split(centres, 50000):
+        dists, indices = (chunk[:, None, :] - smpl_verts[None, :, :]).norm(dim=-1).topk(mean_neighbor, dim=-1, largest=False)
+        w = 1. / torch.clamp(dists, 0.0001, 1.)
+        w = w / w.sum(-1, keepdim=True)
+        rows.append((smpl_ws[indices.view(-1)] * w.view(-1, 1)).reshape(w.shape[0], mean_neighbor, -1).sum(1))
+    field = torch.cat(rows, dim=0).transpose(0, 1).reshape(1, -1, D, H, W)
+    return smooth_weights(field, smooth_times)
+
+
+def initialLBSkinner(gender, shape, pose, resolution, bmins=None, bmaxs=None, extra_trans=None, smpl=None):
+    """model/Deformer.py:594-626 — the skinner of a capture from scratch: SMPL posed into the A-pose `pose` with the fitted
+    `shape`, its per-vertex blend weights baked into a `resolution` = (W, H, D) volume over the template's bounding box
+    (30 nearest vertices, 30 smoothing passes); normalisation box = 1.1 x the largest extent around the box centre.
+    Returns (LBSkinner, template vertices [V,3], template faces [F,3]).  (`bmins` / `bmaxs` are accepted and unused: the
+    reference only runs with the adaptive box — with a given box it stops on an undefined name.)"""
+    smpl = (smpl if smpl is not None else getSMPL(gender)).to(shape.device)
+    Js, _ = smpl.skeleton(shape.view(1, -1), True)
+    verts, _, _ = smpl(shape.view(1, -1), pose.view(1, 24, 3), True)
+    verts = verts.view(-1, 3)
+    lo, hi = verts.min(0).values, verts.max(0).values
+    ws = compute_lbswField(lo.tolist(), hi, resolution, verts, smpl.weight.view(verts.shape[0], 24), align_corners=False,
+                           mean_neighbor=30, smooth_times=30)
+    skinner = LBSkinner(ws, lo, hi, Js, smpl.parents, init_pose=pose, align_corners=False, extra_trans=extra_trans,
+                        bbox_extend=(hi - lo).max() * 1.1, bbox_center=(lo + hi) / 2)
+    return skinner, verts, torch.as_tensor(smpl.faces, dtype=torch.long, device=verts.device)

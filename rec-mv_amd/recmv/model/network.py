@@ -250,8 +250,12 @@ def getOptNet(dataset, save_folder, N, bmins, bmaxs, resolutions, device, conf, 
     (`optNet.initializeTmpSDF`, `train.initial_iters`, 1200 when that is <= 0).  Synthetic frames (no dataset) start from the
     geometric initialisation: -1.
     `<dataset.root>/<save_folder>/initial_skinner_<pose type>.pth` (:223-236), when present and `use_initial_skinner`, supplies
-    the skinning volume, its box, the rest skeleton, the SMPL template and the fitted shape; otherwise the rig is synthetic.
+    the skinning volume, its box, the rest skeleton, the SMPL template and the fitted shape.  Without that file a SMPL model
+    (`smpl=<model>` or an importable smpl_pytorch) lets the first run build it as the reference does (:250-276:
+    `smpl_beta_optimizer`, `initialLBSkinner` at `skin_resolution`, default 129 x 225 x 65) and write it; without either the
+    rig is synthetic.
     `opt_large=True` returns the large-pose variant (OptimGarmentNetwork_LargePose, :337-340)."""
+    import os
     import os.path as osp
     from ..engineer.networks import OptimGarmentNetwork, OptimGarmentNetwork_LargePose
     cls = OptimGarmentNetwork_LargePose if opt_large else OptimGarmentNetwork
@@ -275,6 +279,42 @@ def getOptNet(dataset, save_folder, N, bmins, bmaxs, resolutions, device, conf, 
             if osp.isfile(fite):
                 data = dict(data, ws=torch.from_numpy(np.load(fite)).float()[None])
             kw['skinner_state'] = data
+        else:
+            # :250-276 — first run on a capture: fit the SMPL shape and one shared translation to the 2-D joints, bake the
+            # skinner in the A-pose of `train.skinner_pose_type`, keep everything in initial_skinner_<pose type>.pth.
+            # Needs the SMPL model (`smpl=` or smpl_pytorch); without it the rig stays synthetic.
+            smpl = kw.pop('smpl', None)
+            if smpl is None:
+                try:
+                    from .Deformer import getSMPL
+                    smpl = getSMPL(dataset.gender)
+                except ImportError:
+                    smpl = None
+            if smpl is not None:
+                from ..engineer.core.beta_optimizer import smpl_beta_optimizer
+                from ..utils import smpl_tmp_Apose
+                from .Deformer import initialLBSkinner
+                init_pose = torch.from_numpy(smpl_tmp_Apose(pose_type)).view(1, 24, 3).to(device)
+                if getattr(dataset, 'gt_joints2d', None) is not None:
+                    betas, extra_trans = smpl_beta_optimizer(dataset.gender, init_pose, dataset, device, smpl=smpl)
+                    extra_trans = extra_trans.detach().cpu()
+                else:
+                    betas, extra_trans = dataset.shape.detach().clone(), None
+                dataset.shape = betas.detach().cpu()
+                skinner, body_vs, body_fs = initialLBSkinner(dataset.gender, dataset.shape.to(device), init_pose,
+                                                             kw.pop('skin_resolution', (128 + 1, 224 + 1, 64 + 1)), bmins, bmaxs,
+                                                             extra_trans, smpl=smpl)
+                data = {'ws': skinner.ws.contiguous().cpu(), 'bmins': skinner.b_min.cpu(), 'bmaxs': skinner.b_max.cpu(),
+                        'Js': skinner.Js.cpu(), 'parents': skinner.parents, 'init_pose': skinner.init_pose.cpu(),
+                        'tmpBodyVs': body_vs.detach().cpu(), 'tmpBodyFs': body_fs.cpu(), 'betas': dataset.shape,
+                        'extra_trans': extra_trans, 'bbox_center': skinner.bbox_center.cpu(),
+                        'bbox_extend': skinner.bbox_extend.cpu()}
+                if int(kw.get('rank', 0)) == 0:         # (run the first start-up on one process: the shape fit shuffles frames)
+                    os.makedirs(osp.dirname(skinner_file), exist_ok=True)
+                    torch.save(data, skinner_file)
+                kw['skinner_state'] = data
+    kw.pop('smpl', None)
+    kw.pop('skin_resolution', None)
     optNet = cls(conf, device, **kw)
     optNet.visualizer = visualizer
     sdf_initialized = -1

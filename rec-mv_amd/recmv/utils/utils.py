@@ -18,7 +18,7 @@ from ..FastMinv import Fast3x3Minv, Fast3x3Minv_backward
 
 __all__ = ["save_model", "load_model", "set_hierarchical_config", "FastDiff3x3MinvFunction", "quat2mat", "annealing_weights", "GMRobustError", "sample_points",
            "compute_Jacobian", "batch_compute_Jacobian", "compute_deformed_normals", "compute_cardinal_rays",
-           "compute_netRender_color", "scatter_mean", "write_ply", "read_ply"]
+           "compute_netRender_color", "scatter_mean", "write_ply", "read_ply", "smpl_tmp_Apose"]
 
 
 class FastDiff3x3MinvFunction(Function):
@@ -252,3 +252,14 @@ def read_ply(name):
     if not (rows['n'] == 3).all():
         raise ValueError(name + ': non-triangle face')
     return torch.from_numpy(v.copy()), torch.from_numpy(rows['idx'].astype(np.int64))
+
+
+def smpl_tmp_Apose(init_pose_type=0):
+    """utils/utils.py:68-99 — the canonical pose the skinning volume is baked in: legs spread by 10 / 7 / 15 / 15 degrees, arms
+    lowered by 45 / 55 / 55 / 0 degrees for `train.skinner_pose_type` 0..3 (axis-angle [24,3], float32)."""
+    assert init_pose_type in (0, 1, 2, 3)
+    legs, arms = {0: (10., 45.), 1: (7., 55.), 2: (15., 55.), 3: (15., 0.)}[init_pose_type]
+    pose = np.zeros((24, 3))
+    pose[1], pose[2] = [0, 0, legs / 180. * np.pi], [0, 0, -legs / 180. * np.pi]
+    pose[16], pose[17] = [0, 0, -arms / 180. * np.pi], [0, 0, arms / 180. * np.pi]
+    return pose.astype(np.float32)

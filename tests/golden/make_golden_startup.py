@@ -250,6 +250,67 @@ def sdf_prefit(out):
     out['prefit_vs'], out['prefit_ns'] = sc.prefit_points()
 
 
+def skinner_baking(out):
+    """model/Deformer.py `smooth_weights`, `compute_lbswField`, `initialLBSkinner` (on tests/startup_case.StandInSMPL),
+    utils/utils.py `smpl_tmp_Apose`."""
+    ref_loader.ref_module("model.network")
+    Dref = ref_loader.ref_module("model.Deformer")
+    U = ref_loader.ref_module("utils.utils")
+    g = torch.Generator().manual_seed(71)
+    w = torch.softmax(torch.randn(1, 24, 6, 7, 5, generator=g), dim=1)
+    out['bake_smooth_in'], out['bake_smooth_out'] = w.clone(), Dref.smooth_weights(w.clone(), 4)
+    verts = torch.randn(80, 3, generator=g) * torch.tensor([0.3, 0.5, 0.2])
+    ws = torch.softmax(2 * torch.randn(80, 24, generator=g), dim=1)
+    out['bake_verts'], out['bake_ws'] = verts, ws
+    out['bake_field'] = Dref.compute_lbswField([-0.5, -0.8, -0.3], torch.tensor([0.5, 0.8, 0.3]), (7, 9, 5), verts, ws,
+                                               align_corners=False, mean_neighbor=5, smooth_times=3)
+    for t in range(4):
+        out['apose_%d' % t] = torch.from_numpy(U.smpl_tmp_Apose(t))
+    Dref.getSMPL = lambda gender: sc.StandInSMPL(rodrigues=Dref.batch_rodrigues)
+    shape = 0.5 * torch.randn(10, generator=g)
+    pose = torch.from_numpy(U.smpl_tmp_Apose(0)).view(1, 24, 3)
+    sk, v, f = Dref.initialLBSkinner('female', shape, pose, (9, 13, 7), None, None, torch.tensor([[0.01, 0.02, -0.01]]))
+    out['bake_shape'] = shape
+    for name, t in (('ws', sk.ws), ('b_min', sk.b_min), ('b_max', sk.b_max), ('Js', sk.Js), ('init_pose', sk.init_pose),
+                    ('extend', sk.bbox_extend), ('center', sk.bbox_center), ('verts', v), ('faces', f.float())):
+        out['bake_sk_' + name] = t.detach().float()
+    # the baked skinner at work: posed points (reference forward), for the GPU test of the fused kernels on a single extent
+    pts = 0.3 * torch.randn(2, 60, 3, generator=g)
+    poses, trans = cs.poses_trans(2, seed=9)
+    out['bake_pts'], out['bake_poses'], out['bake_trans'] = pts, poses, trans
+    out['bake_posed'] = sk(pts, [poses, trans])
+
+
+def beta_fit(out):
+    """engineer/core/beta_optimizer.py `smpl_beta_optimizer` (:132-245) run for real: 150 Adam steps on the 2-D joints of the
+    capture, SMPL replaced by the stand-in on both sides."""
+    import os
+    ref_loader.ref_module("model.network")
+    Bo = ref_loader.ref_module("engineer.core.beta_optimizer")
+    Dref = ref_loader.ref_module("model.Deformer")
+    refds = ref_loader.ref_module("dataset.dataset")
+    from recmv.model import RectifiedPerspectiveCameras as OurCameras
+    Bo.torch = TorchOnCpu()
+    Bo.RectifiedPerspectiveCameras = OurCameras
+    Bo.getSMPL = lambda gender: sc.StandInSMPL(rodrigues=Dref.batch_rodrigues)
+    np.int, np.bool = int, bool
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as root, tempfile.TemporaryDirectory() as scratch:
+        sc.write_joint_capture(root)
+        torch.manual_seed(35)
+        ds = refds.SceneDataset(root, dict(sc.CONDS), cf.GARMENT_TYPE, fl_sampling=sc.FL_SAMPLING, curve_sampling=1)
+        os.chdir(scratch)                                    # the function writes ./debug/smpl_beta/
+        try:
+            random.seed(36)
+            torch.manual_seed(36)
+            betas, extra = Bo.smpl_beta_optimizer(ds.gender, None, ds, 'cpu')
+        finally:
+            os.chdir(cwd)
+        out['beta_start'] = ds.shape.clone()
+    out['beta_betas'], out['beta_extra'] = betas, extra
+    print("beta fit: |betas - start| max", float((betas - out['beta_start']).abs().max()), " extra_trans", extra.view(-1).tolist())
+
+
 def main():
     torch.set_num_threads(8)
     out = {}
@@ -261,6 +322,8 @@ def main():
         torch.Tensor.cuda = real_cuda
     registration(out)
     sdf_prefit(out)
+    skinner_baking(out)
+    beta_fit(out)
     save("startup", **out)
 
 

@@ -82,6 +82,59 @@ def prefit_probe(n=50):
     return torch.randn(n, 3, generator=torch.Generator().manual_seed(52)) * 0.5
 
 
+class StandInSMPL:
+    """What the start-up steps ask of the reference's SMPL object (smpl_pytorch.SMPL, un-vendored): a linear shape space on a
+    6890-vertex template turned by the root rotation, a joint regressor to the 19 'cocoplus' joints, per-vertex blend weights,
+    the kinematic tree, faces.  NOT a body model — both sides of a parity test are handed the same one."""
+
+    def __init__(self, seed=61, rodrigues=None):
+        import common_setup as cs
+        g = torch.Generator().manual_seed(seed)
+        d = torch.nn.functional.normalize(torch.randn(6890, 3, generator=g), dim=1)
+        self.template = d * torch.tensor([0.28, 0.75, 0.16]) * (0.8 + 0.2 * torch.rand(6890, 1, generator=g))
+        self.shapedirs = 0.01 * torch.randn(10, 6890 * 3, generator=g)
+        self.joint_regressor = torch.softmax(4 * torch.randn(6890, 19, generator=g), dim=0)
+        self.weight = torch.softmax(3 * torch.randn(6890, 24, generator=g), dim=1)
+        self.J_template = 0.3 * torch.randn(24, 3, generator=g)
+        self.J_dirs = 0.01 * torch.randn(10, 24 * 3, generator=g)
+        self.parents = cs.SMPL_PARENTS
+        self.faces = torch.randint(0, 6890, (200, 3), generator=g).numpy()
+        self.rodrigues = rodrigues
+
+    def to(self, device):
+        for k in ('template', 'shapedirs', 'joint_regressor', 'weight', 'J_template', 'J_dirs'):
+            setattr(self, k, getattr(self, k).to(device))
+        return self
+
+    def skeleton(self, betas, require_body=False):
+        return (self.J_template[None] + (betas @ self.J_dirs).view(-1, 24, 3)), None
+
+    def __call__(self, betas, poses, get_skin=False):
+        from recmv.model import batch_rodrigues
+        rod = self.rodrigues or batch_rodrigues
+        v = self.template[None] + (betas @ self.shapedirs).view(-1, 6890, 3)
+        R = rod(poses.reshape(-1, 24, 3)[:, 0])
+        return torch.matmul(v, R.transpose(1, 2)), None, None
+
+
+JOINTS = 17
+
+
+def write_joint_capture(root):
+    """`write_capture` with 17 COCO joints per frame in pixels (x, y, visible) — what `smpl_beta_optimizer` consumes (the base
+    fixture's 49-joint TCMR rows only exercise the reader)."""
+    import capture_fixture as cf
+    import joblib
+    import numpy as np
+    write_capture(root)
+    rng = np.random.RandomState(3)
+    joints = np.concatenate([rng.uniform(5, 35, (cf.FRAMES, JOINTS, 2)), (rng.rand(cf.FRAMES, JOINTS, 1) > 0.2).astype(np.float64)],
+                            -1).astype(np.float32)
+    joblib.dump([None, {'gt_joints2d': joints, 'frame_ids': np.arange(cf.FRAMES), 'pose': rng.randn(cf.FRAMES, 72).astype(np.float32),
+                        'betas': rng.randn(cf.FRAMES, 10).astype(np.float32)}], os.path.join(root, '%s_tcmr_output.pkl' % cf.GARMENT_TYPE))
+    return root
+
+
 # ----------------------------------------------------------------------------------------------- recmv side
 def line_meshes(g, device):
     from recmv.engineer.utils.matrix_transform import FeatureLineMesh
@@ -173,3 +226,41 @@ def run_prefit(g, device, rtol=5e-3, atol_rel=2e-3):
         with torch.no_grad():
             probe = net(prefit_probe().to(device), -1).cpu()
         torch.testing.assert_close(probe, g[tag + 'probe'], rtol=rtol, atol=atol_rel)
+
+
+def run_skinner_baking(g, device, rtol=2e-4):
+    """compute_lbswField / smooth_weights / initialLBSkinner on the stand-in model against the reference functions."""
+    from recmv.model import compute_lbswField, initialLBSkinner, smooth_weights
+    from recmv.utils import smpl_tmp_Apose
+    torch.testing.assert_close(smooth_weights(g['bake_smooth_in'].clone().to(device), 4).cpu(), g['bake_smooth_out'], rtol=1e-5, atol=1e-6)
+    field = compute_lbswField([-0.5, -0.8, -0.3], torch.tensor([0.5, 0.8, 0.3]).to(device), (7, 9, 5), g['bake_verts'].to(device),
+                              g['bake_ws'].to(device), align_corners=False, mean_neighbor=5, smooth_times=3)
+    torch.testing.assert_close(field.cpu(), g['bake_field'], rtol=rtol, atol=1e-6)
+    pose = torch.from_numpy(smpl_tmp_Apose(0)).float().view(1, 24, 3).to(device)
+    sk, verts, faces = initialLBSkinner('female', g['bake_shape'].to(device), pose, (9, 13, 7), None, None,
+                                        torch.tensor([[0.01, 0.02, -0.01]]), smpl=StandInSMPL())
+    for name, got in (('ws', sk.ws), ('b_min', sk.b_min), ('b_max', sk.b_max), ('Js', sk.Js), ('init_pose', sk.init_pose),
+                      ('extend', sk.bbox_extend), ('center', sk.bbox_center), ('verts', verts), ('faces', faces.float())):
+        torch.testing.assert_close(got.detach().cpu().float().reshape(g['bake_sk_' + name].shape), g['bake_sk_' + name],
+                                   rtol=rtol, atol=1e-6, msg=lambda m: name + ': ' + m)
+    return sk.to(device)
+
+
+def run_beta_fit(g, root, device, rtol=2e-3):
+    """smpl_beta_optimizer on the joint capture under `root` against the reference function's betas / translation."""
+    import random
+    import capture_fixture as cf
+    from recmv.dataset import SceneDataset
+    from recmv.engineer.core.beta_optimizer import smpl_beta_optimizer
+    torch.manual_seed(35)
+    ds = SceneDataset(root, dict(CONDS), cf.GARMENT_TYPE, fl_sampling=FL_SAMPLING, curve_sampling=1)
+    for t in ds.conds + [ds.poses, ds.trans] + list(ds.camera_params.values()):
+        t.data = t.data.to(device)
+    random.seed(36)
+    torch.manual_seed(36)
+    betas, extra = smpl_beta_optimizer(ds.gender, None, ds, device, smpl=StandInSMPL(), log=None)
+    worst = {}
+    for name, got, want in (('betas', betas, g['beta_betas']), ('extra_trans', extra, g['beta_extra'])):
+        worst[name] = float((got.cpu() - want).abs().max()) / float(want.abs().max())
+        torch.testing.assert_close(got.cpu(), want, rtol=rtol, atol=rtol * float(want.abs().max()), msg=lambda m: name + ': ' + m)
+    return worst

@@ -165,7 +165,8 @@ def test_a_stored_skinner_file_is_read_in_the_reference_layout(tmp_path):
     torch.manual_seed(3)
     ds, _ = getDatasetAndLoader(root, conds_lens, 3, True, 0, True, True, conf.get_config('train.opt_camera'), cf.GARMENT_TYPE,
                                 data_type='scene')
-    baked = cs.build_skinner(LBSkinner)                            # plays the skinner of the reference's first run
+    # plays the skinner of the reference's first run: ONE normalisation extent (a cube, model/Deformer.py:609), not one per axis
+    baked = LBSkinner(**dict(cs.skinner_args(), bbox_extend=torch.tensor(2.4)))
     geo = sc.geometry()
     betas = torch.linspace(-1, 1, 10)
     os.makedirs(os.path.join(root, 'result'))
@@ -193,6 +194,8 @@ def test_a_stored_skinner_file_is_read_in_the_reference_layout(tmp_path):
         baked.extra_trans.copy_(torch.tensor([[0.01, -0.02, 0.03]]))
         torch.testing.assert_close(sk(pts, [poses, trans]), baked(pts, [poses, trans]))
         assert not torch.equal(want, baked(pts, [poses, trans]))                   # (the stored extra translation is in effect)
+        grid = sk._lbs_grid()                                                      # what the fused HIP kernels are handed
+        assert list(grid.scale) == pytest.approx([2.0 / 2.4] * 3) and list(grid.center) == pytest.approx(baked.bbox_center.tolist())
         ignored, _ = getOptNet(ds, 'result', 3, None, None, res, 'cpu', conf, curves=False, use_initial_skinner=False,
                                skin_grid=(5, 9, 7))
         assert ignored.deformer.defs[1].ws.shape[2:] == (5, 9, 7)
@@ -290,5 +293,75 @@ def test_align_fl_turns_a_stored_registration_into_the_loops_curves(tmp_path):
         plain, _ = getOptNet(ds, 'result', 3, box[0], box[1], res, 'cpu', conf, curves=False, skin_grid=(5, 9, 7))
         plain.align_fl(os.path.join(root, 'missing.pth'), fl_templates=templates)
         assert plain.curves and plain.inter_free_curve().shape[1] == 200
+    finally:
+        cpu_port.uninstall()
+
+
+def test_skinner_baking_matches_the_reference():
+    """model/Deformer.py `smooth_weights` (:533-544), `compute_lbswField` (:546-591), `initialLBSkinner` (:594-626, on the
+    stand-in SMPL of tests/startup_case.py) and utils/utils.py `smpl_tmp_Apose` (:68-99); the baked skinner then poses points
+    like the reference's."""
+    import common_setup as cs
+    from oracle import cpu_port
+    from recmv.utils import smpl_tmp_Apose
+    g = load()
+    for t in range(4):
+        assert torch.equal(torch.from_numpy(smpl_tmp_Apose(t)), g['apose_%d' % t])
+    cpu_port.install()
+    try:
+        sk = sc.run_skinner_baking(g, "cpu")
+        assert sk.bbox_extend.dim() == 0                                    # one extent for the three axes
+        torch.testing.assert_close(sk(g['bake_pts'], [g['bake_poses'], g['bake_trans']]), g['bake_posed'], rtol=1e-4, atol=1e-6)
+    finally:
+        cpu_port.uninstall()
+
+
+def test_smpl_shape_fit_matches_the_reference(tmp_path):
+    """engineer/core/beta_optimizer.py `smpl_beta_optimizer` (:132-245) run for real (150 Adam steps against the capture's 2-D
+    joints) vs recmv's, the SMPL model replaced by the same stand-in on both sides."""
+    from oracle import cpu_port
+    cpu_port.install()
+    try:
+        worst = sc.run_beta_fit(load(), sc.write_joint_capture(str(tmp_path)), "cpu")
+        assert max(worst.values()) < 1e-4, worst
+    finally:
+        cpu_port.uninstall()
+
+
+def test_first_run_builds_and_stores_the_skinner_when_a_smpl_model_is_given(tmp_path):
+    """model/network.py:250-276 through getOptNet: no initial_skinner file + a SMPL model -> shape fit to the 2-D joints, skinner
+    baked in the A-pose, `initial_skinner_0.pth` written in the reference's layout; the next getOptNet reads it back (no model
+    needed) and gets the same skinner."""
+    import os
+    from oracle import cpu_port
+    from recmv.dataset import getDatasetAndLoader
+    from recmv.hocon import ConfigFactory
+    from recmv.model.network import getOptNet
+    conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    root = sc.write_joint_capture(str(tmp_path))
+    conds_lens = {'deformer': conf.get_int('mlp_deformer.condlen') * 3, 'renderer': conf.get_int('render_net.condlen')}
+    torch.manual_seed(3)
+    ds, _ = getDatasetAndLoader(root, conds_lens, 3, True, 0, True, True, conf.get_config('train.opt_camera'), cf.GARMENT_TYPE,
+                                data_type='scene')
+    shape0 = ds.shape.clone()
+    cpu_port.install()
+    try:
+        res = [(9, 11, 7), (17, 21, 13)]
+        first, _ = getOptNet(ds, 'result', 3, None, None, res, 'cpu', conf, curves=False, smpl=sc.StandInSMPL(),
+                             skin_resolution=(9, 13, 7))
+        path = os.path.join(root, 'result', 'initial_skinner_0.pth')
+        stored = torch.load(path, weights_only=False)
+        assert set(stored) == {'ws', 'bmins', 'bmaxs', 'Js', 'parents', 'init_pose', 'tmpBodyVs', 'tmpBodyFs', 'betas', 'extra_trans',
+                               'bbox_center', 'bbox_extend'}
+        assert stored['ws'].shape == (1, 24, 7, 13, 9) and stored['tmpBodyVs'].shape == (6890, 3) and stored['bbox_extend'].dim() == 0
+        assert not torch.equal(ds.shape, shape0) and torch.equal(ds.shape, stored['betas'])         # the fitted shape
+        assert stored['extra_trans'].shape == (1, 3) and float(stored['extra_trans'].abs().max()) > 0
+        sk = first.deformer.defs[1]
+        assert torch.equal(sk.ws.cpu(), stored['ws']) and torch.equal(first.tmpBodyVs.cpu(), stored['tmpBodyVs'])
+        again, _ = getOptNet(ds, 'result', 3, None, None, res, 'cpu', conf, curves=False)           # no model this time
+        sk2 = again.deformer.defs[1]
+        for name in ('ws', 'b_min', 'b_max', 'Js', 'init_pose', 'extra_trans', 'bbox_center', 'bbox_extend'):
+            assert torch.equal(getattr(sk, name), getattr(sk2, name)), name
+        assert torch.equal(first.engine.b_min, again.engine.b_min) and torch.equal(first.engine.b_max, again.engine.b_max)
     finally:
         cpu_port.uninstall()

@@ -34,3 +34,17 @@ def test_bench_line_contract(path):
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "iters/s" and 0 < c["value"] < d["value"]
     assert d["remesh"]["remesh_steps_in_timed_region"] >= 1                      # a re-mesh is always inside the timed steps
+
+
+def test_whole_step_matrix_rate_is_a_function_of_the_line():
+    """bench.whole_step_matrix_rate on the committed driver-command line: Σ MFMA FLOP of a step over the step time."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", PROFILES.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    line = json.loads((PROFILES / "r02_bench_line_v7_driver_command.json").read_text().strip().splitlines()[-1])
+    w = bench.whole_step_matrix_rate(line["roofline"], line["steps"], line["ms_per_step"])
+    assert 6.0 < w["matrix_tflop_per_step"] < 10.0 and 0.3 < w["frac_of_f32_mfma_peak"] < 0.6
+    assert w["achieved"] == round(w["matrix_tflop_per_step"] / line["ms_per_step"] * 1e3, 2) or abs(
+        w["achieved"] - w["matrix_tflop_per_step"] / line["ms_per_step"] * 1e3) < 0.05
+    print(w)

@@ -31,7 +31,7 @@ from ..engineer.utils.featureline_utils import check_feature_lines, obtain_featu
 from ..engineer.utils.polygons import uniformsample
 from ..utils.constant import ATR_PARSING, FL_INFOS
 
-__all__ = ["SceneDataset", "Init_Fl_SceneDataset", "People_Snapshot_SceneDataset", "Large_Pose_SceneDataset", "one_euro_smooth", "ClipSampler", "RandomSampler", "getDatasetAndLoader",
+__all__ = ["SceneDataset", "Synthe_SceneDataset", "Init_Fl_SceneDataset", "People_Snapshot_SceneDataset", "Large_Pose_SceneDataset", "one_euro_smooth", "ClipSampler", "RandomSampler", "getDatasetAndLoader",
            "read_image_bgr", "dct_space"]
 
 
@@ -379,6 +379,21 @@ class People_Snapshot_SceneDataset(SceneDataset):
         return idx, out
 
 
+class Synthe_SceneDataset(SceneDataset):
+    """Synthetic-outfit renders (:1004-1064): a capture whose every frame carries its feature lines (no `curve_sampling` thinning)
+    and that has no 2-D joints (its SMPL shape is known, no shape fit)."""
+
+    def _annotated(self, idx):
+        return True
+
+    def __getitem__(self, idx):
+        out = self._sample(idx)
+        if self.require_albedo:
+            alb = read_image_bgr(osp.join(self.root, 'albedos/%d.png' % idx)).astype(np.float32)
+            out['albedo'] = torch.from_numpy((alb / 255. - 0.5) * 2.).view(self.H, self.W, 3)
+        return idx, out
+
+
 class Init_Fl_SceneDataset(SceneDataset):
     """A capture restricted to the frames `sample_idx` (:894-1000): what `get_init_fl_datasets` hands to the start-up
     registration.  Feature lines come from `mask2fl/` when the capture has it, else `featurelines/`; a frame without an
@@ -551,9 +566,11 @@ def getDatasetAndLoader(root, conds_lens, batch_size, shuffle, num_workers, opt_
         dataset = SceneDataset(root, conds_lens, garment_type, curve_sampling=curve_sampling)
     elif data_type in with_a_pose:
         dataset = with_a_pose[data_type](root, conds_lens, garment_type, curve_sampling=curve_sampling, a_pose=a_pose)
-    elif data_type in ('snug', 'synthe'):
-        raise NotImplementedError("data type {}: its pre-processing is outside this package (recmv/dataset/dataset.py)".format(
-            data_type))
+    elif data_type == 'synthe':
+        dataset = Synthe_SceneDataset(root, conds_lens, garment_type, curve_sampling=curve_sampling)
+    elif data_type == 'snug':
+        raise NotImplementedError("data type snug: it animates a capture with CMU motion files of the SNUG repository "
+                                  "(../snug/assets, `load_motion`), which are outside this package (recmv/dataset/dataset.py)")
     else:
         raise NotImplementedError('data type {} is not implemented'.format(data_type))
     for tensor, learn in ((dataset.poses, opt_pose), (dataset.trans, opt_trans)):

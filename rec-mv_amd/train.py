@@ -189,10 +189,10 @@ def main(argv=None, large_pose=False):
     batch_size = config.get_int('train.coarse.point_render.batch_size')
     sample_pix_num = config.get_int('train.sample_pix_num')
 
-    # train.py:150-160: a capture directory (`--data` with imgs/ masks/ ... , `--data_type scene | people_snap | large_pose`) is read by
+    # train.py:150-160: a capture directory (`--data` with imgs/ masks/ ... , `--data_type scene | people_snap | large_pose | synthe`) is read by
     # recmv.dataset with the reference's conds_lens; without one the frames are synthetic
     capture = None
-    if args.data is not None and args.data_type in ('scene', 'people_snap', 'large_pose') and osp.isdir(osp.join(args.data, 'imgs')):
+    if args.data is not None and args.data_type in ('scene', 'people_snap', 'large_pose', 'synthe') and osp.isdir(osp.join(args.data, 'imgs')):
         from recmv.dataset import getDatasetAndLoader
         garment_type = args.garment_type or osp.basename(osp.normpath(args.data))
         conds_lens = {'deformer': config.get_int('mlp_deformer.condlen') * 3,      # body + two garments (train.py:107)

@@ -1,7 +1,7 @@
 """Golden vectors for the data path, from the REAL reference dataset classes (dataset/dataset.py) reading the synthetic capture
 of tests/capture_fixture.py:
 
-  dataset.npz   `SceneDataset`, `People_Snapshot_SceneDataset` and `Large_Pose_SceneDataset` (a_pose False / True): four samples each (image, mask,
+  dataset.npz   `SceneDataset`, `People_Snapshot_SceneDataset`, `Large_Pose_SceneDataset` (a_pose False / True) and `Synthe_SceneDataset`: four samples each (image, mask,
                 feature-line points and flags, normal map, garment regions, 2-D joints), the per-line projection weights
                 (`area_size_statistic`), which frames carry an annotation, temporal windows (`get_batchframe_data`), camera
                 tuple, per-frame tensors incl. the DCT-initialised codes (seeded), lengths; the samplers' index streams; the
@@ -66,6 +66,12 @@ def main():
             out.update(cf.collect(ds, kind, samples=(0, 1, len(ds) - 1)))
             out[kind + '_apose'] = torch.tensor([float(ds.a_pose_start), float(ds.a_pose_end)])
             out[kind + '_all_trans'], out[kind + '_all_poses'], out[kind + '_shape'] = ds.trans.clone(), ds.poses.clone(), ds.shape.clone()
+        torch.manual_seed(14)
+        syn = refds.Synthe_SceneDataset(root, dict(CONDS), cf.GARMENT_TYPE, fl_sampling=30, curve_sampling=2)
+        for idx in (1, 5):                                   # odd frames: a SceneDataset with curve_sampling=2 would blank their lines
+            i, smp = syn[idx]
+            out['synthe_s%d_fl_masks' % idx], out['synthe_s%d_fl_pts' % idx] = smp['fl_masks'].float(), smp['fl_pts'].float()
+            out['synthe_s%d_keys' % idx] = torch.tensor([float(k in smp) for k in ('gt_joints2d', 'normal', 'upper', 'bottom')])
         # the smoother on an axis-angle sequence with a sign flip of one joint (the branch that re-expresses the rotation)
         smooth = ref_loader.ref_module("engineer.utils.smooth_poses").smooth_poses
         g = torch.Generator().manual_seed(9)

@@ -100,6 +100,25 @@ def test_loader_factory_and_collation(capture):
         getDatasetAndLoader(capture, dict(CONDS), 3, True, 0, True, True, False, cf.GARMENT_TYPE, data_type='snug')
 
 
+def test_synthe_dataset_matches_the_reference(capture, golden):
+    """Synthe_SceneDataset (dataset/dataset.py:1004-1064): every frame keeps its feature lines whatever `curve_sampling` says
+    (a SceneDataset with curve_sampling=2 blanks the odd frames), and the samples carry no 2-D joints."""
+    from recmv.dataset import SceneDataset, Synthe_SceneDataset, getDatasetAndLoader
+    torch.manual_seed(14)
+    syn = Synthe_SceneDataset(capture, dict(CONDS), cf.GARMENT_TYPE, fl_sampling=30, curve_sampling=2)
+    for idx in (1, 5):
+        i, smp = syn[idx]
+        assert i == idx
+        assert torch.equal(smp['fl_masks'].float(), golden['synthe_s%d_fl_masks' % idx])
+        torch.testing.assert_close(smp['fl_pts'].float(), golden['synthe_s%d_fl_pts' % idx], rtol=1e-6, atol=1e-5)
+        assert [float(k in smp) for k in ('gt_joints2d', 'normal', 'upper', 'bottom')] == golden['synthe_s%d_keys' % idx].tolist()
+    torch.manual_seed(14)
+    plain = SceneDataset(capture, dict(CONDS), cf.GARMENT_TYPE, fl_sampling=30, curve_sampling=2)
+    assert not plain[1][1]['fl_masks'].any() and syn[1][1]['fl_masks'].any()
+    ds, _ = getDatasetAndLoader(capture, dict(CONDS), 3, True, 0, True, True, False, cf.GARMENT_TYPE, data_type='synthe')
+    assert isinstance(ds, Synthe_SceneDataset) and ds.poses.requires_grad
+
+
 def test_one_iteration_of_the_facade_on_a_capture_directory(capture):
     """train.py's sequence with a capture read by recmv.dataset instead of the synthetic frames: getOptNet(dataset, ...),
     a collated mini-batch of the DataLoader as `datas`, forward / backward / propagateTmpPsGrad / optimizer.step — the per-frame

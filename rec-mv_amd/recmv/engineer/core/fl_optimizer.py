@@ -126,7 +126,7 @@ def _fit(params, lr, epochs, loader, step_loss, log):
             loss.backward()
             opt.step()
             if log is not None:
-                log("{}/{}/{}: fl_loss: {}".format(epoch, batch_id, len(loader), float(loss)))
+                log("{}/{}/{}: fl_loss: {}".format(epoch, batch_id, len(loader), float(loss.detach())))
 
 
 def scale_rigid_optimizer(deform_lbs, fl_meshes, smpl_mesh, mask_render, dataset, data_dataloader, save_path, fl_infos,

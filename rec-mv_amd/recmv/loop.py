@@ -270,6 +270,8 @@ class HotLoop:
                                       rendlen=conf.get_int('render_net.condlen'))
             dataset.set_garment_silhouettes([_zero_level_radius(n, device) for n in self.garment_nets], seed=seed + 3)
         self.dataset = dataset                     # getOptNet hands over the caller's dataset (model/network.py:352)
+        if self.garment_type is None:              # (the reference's configs name the capture in train.garment_type)
+            self.garment_type = getattr(dataset, 'garment_type', None)
         self._datas = None                         # the mini-batch dict of forward(datas, ...), when a caller passes one
         # large-pose fitting (OptimGarmentNetwork_Large_Pose.py:122-137): the surfaces are frozen, only the deformation,
         # the per-frame tensors, the colour net and the camera move

@@ -21,7 +21,9 @@ garment assets with mesh tools that are outside this tier.  The
 `--init-points <npz>` (body / garment point clouds) and no `initial_sdf_idr_*.pth` under the save folder yet, the nets are
 fitted for `train.initial_iters` epochs (`initializeTmpSDF`, train.py:179-206) and the files written under the reference's
 names; a later run loads them (getOptNet).  Without the clouds the canonical surfaces start from the geometric
-initialisation, and the curves from rings on those surfaces.  Scalars go to wandb when it is installed, to
+initialisation.  `--fl-templates <npz>` (one ribbon mesh per feature line of the capture) registers the lines to the annotated
+frames and samples the loop's curves from them (`initializeFL`, `align_fl`); without it the curves are rings on the initial
+surfaces.  Scalars go to wandb when it is installed, to
 `<save-folder>/logs/<exp_name>.jsonl` otherwise.  `--data <capture> --data_type scene|people_snap|large_pose`
 reads a capture directory in the reference's layout through `recmv.dataset` (images, masks, garment regions, 2-D feature
 lines, SMPL poses, camera); without a capture the frames are synthetic (`recmv.loop.SyntheticFrames`; `--frames` sets
@@ -61,6 +63,9 @@ def build_parser(large_pose=False):
     parser.add_argument('--no-curves', action='store_true',
                         help='skip the feature-curve branch (project_2d_loss) the reference runs every iteration')
     parser.add_argument('--frames', type=int, default=64, help='number of synthetic frames')
+    parser.add_argument('--fl-templates', default=None, metavar='NPZ',
+                        help='template feature lines as ribbon meshes: <line>_verts [V,3], <line>_faces [F,3] per line of the '
+                             'capture (FL_INFOS); registered to the annotated frames before the loop (initializeFL / align_fl)')
     parser.add_argument('--init-points', default=None, metavar='NPZ',
                         help='oriented point clouds for the SDF pre-fit: body_vs, body_ns, <garment>_vs, <garment>_ns '
                              '(what the reference cuts out of its SMPL garment templates)')
@@ -79,6 +84,13 @@ class CaptureLoader:
     def set_epoch(self, epoch):
         self.epoch = epoch
         return self
+
+    # what the start-up registration reads off the reference's DataLoader (engineer/core/fl_optimizer.py:121)
+    sampler, num_workers = None, 0
+
+    @property
+    def batch_size(self):
+        return self.loop.batch_size
 
     def __len__(self):
         per_it = self.loop.batch_size * self.loop.world_size
@@ -110,6 +122,28 @@ def _scalars(loss, info):
         elif isinstance(v, (int, float)):
             out[k] = float(v)
     return out
+
+
+def load_fl_templates(path, names, device='cpu'):
+    """{line name: FeatureLineMesh} from an npz with `<line>_verts` / `<line>_faces` for every line in `names`."""
+    import numpy as np
+    import torch
+    from recmv.engineer.utils.matrix_transform import FeatureLineMesh
+    data = np.load(path)
+    missing = [n for n in names if n + '_verts' not in data or n + '_faces' not in data]
+    if missing:
+        raise KeyError('%s: no template for the feature line(s) %s' % (path, ', '.join(missing)))
+    return {n: FeatureLineMesh(torch.from_numpy(data[n + '_verts']).float().to(device),
+                               torch.from_numpy(data[n + '_faces']).long().to(device)) for n in names}
+
+
+def register_feature_lines(optNet, dataloader, templates, save_root):
+    """train.py:209 with what `initializeTmpSDF` does first (OptimGarmentNetwork.py:542): register the template lines to the
+    annotated frames (writes fl_init/init_trans_matrix.pth; a stored file is re-applied, not re-fitted) and turn them into the
+    loop's explicit curves."""
+    optNet.garment_fl_templates = templates
+    optNet.initializeFL(dataloader, 0, optNet.device, osp.join(save_root, 'initial_sdf.pth'))
+    optNet.align_fl(osp.join(save_root, 'fl_init', 'init_trans_matrix.pth'), fl_templates=templates)
 
 
 def prefit_sdf(optNet, nepochs, config, args, save_root, rank):
@@ -211,6 +245,10 @@ def main(argv=None, large_pose=False):
     dataloader = FrameLoader(optNet) if capture is None else CaptureLoader(capture, optNet)
     if sdf_initialized > 0:
         prefit_sdf(optNet, sdf_initialized, config, args, save_root, rank)
+    if args.fl_templates is not None and capture is not None and not args.no_curves:
+        from recmv.utils.constant import FL_INFOS
+        register_feature_lines(optNet, dataloader, load_fl_templates(args.fl_templates, FL_INFOS[optNet.garment_type], device),
+                               save_root)
     if rank == 0:                                 # train.py:86: wandb when it is there, a jsonl file under logs/ otherwise
         from recmv.engineer.visualizer import wandb_visualizer
         optNet.visualizer = wandb_visualizer(args.project_name, args.exp_name, resume=False, log_dir=osp.join(save_root, 'logs'))

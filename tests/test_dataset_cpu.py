@@ -185,6 +185,9 @@ def test_capture_loader_deals_an_epoch_over_ranks(capture):
             loop = types.SimpleNamespace(batch_size=2, world_size=2, rank=rank)
             ids = [int(i) for frame_ids, outs in train.CaptureLoader(ds, loop).set_epoch(epoch) for i in frame_ids]
             assert len(train.CaptureLoader(ds, loop)) == 3
+            cl = train.CaptureLoader(ds, loop)          # what the start-up registration reads off a DataLoader
+            assert (cl.batch_size, cl.sampler, cl.num_workers) == (2, None, 0)
+            assert len(ds.get_init_fl_datasets(cl.batch_size, cl.sampler, cl.num_workers)) == 6
             per_rank.append(ids)
         assert sorted(per_rank[0] + per_rank[1]) == list(range(cf.FRAMES)) and not set(per_rank[0]) & set(per_rank[1])
         seen[epoch] = per_rank

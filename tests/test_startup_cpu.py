@@ -365,3 +365,54 @@ def test_first_run_builds_and_stores_the_skinner_when_a_smpl_model_is_given(tmp_
         assert torch.equal(first.engine.b_min, again.engine.b_min) and torch.equal(first.engine.b_max, again.engine.b_max)
     finally:
         cpu_port.uninstall()
+
+
+def test_train_py_registers_feature_line_templates_from_a_file(tmp_path):
+    """train.py --fl-templates: the npz of ribbon meshes -> `initializeFL` (writes fl_init/init_trans_matrix.pth) -> `align_fl`
+    (the loop's curves come from the registered ribbons); a second start re-applies the stored registration."""
+    import os
+    from oracle import cpu_port
+    import train
+    from recmv.dataset import getDatasetAndLoader
+    from recmv.hocon import ConfigFactory
+    from recmv.model.network import getOptNet
+    g = load()
+    conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    root = sc.write_capture(str(tmp_path))
+    conds_lens = {'deformer': conf.get_int('mlp_deformer.condlen') * 3, 'renderer': conf.get_int('render_net.condlen')}
+    torch.manual_seed(3)
+    ds, _ = getDatasetAndLoader(root, conds_lens, 3, True, 0, True, True, conf.get_config('train.opt_camera'), cf.GARMENT_TYPE,
+                                data_type='scene')
+    meshes = sc.line_meshes(g, 'cpu')
+    np.savez(tmp_path / 'lines.npz', **{n + k: (m.verts_packed() if k == '_verts' else m.faces_packed()).numpy()
+                                        for n, m in meshes.items() for k in ('_verts', '_faces')})
+    with pytest.raises(KeyError):
+        train.load_fl_templates(str(tmp_path / 'lines.npz'), sc.LINE_NAMES + ['bottom_curve'])
+    templates = train.load_fl_templates(str(tmp_path / 'lines.npz'), sc.LINE_NAMES)
+    assert all(torch.equal(templates[n].verts_packed(), meshes[n].verts_packed()) for n in sc.LINE_NAMES)
+    save_root = os.path.join(root, 'result')
+    os.makedirs(save_root)
+    cpu_port.install()
+    try:
+        res, box = [(9, 11, 7), (17, 21, 13)], ((-0.9, -1.2, -0.6), (0.9, 1.2, 0.6))
+        optNet, _ = getOptNet(ds, 'result', 3, box[0], box[1], res, 'cpu', conf, curves=True, skin_grid=(5, 9, 7))
+        assert optNet.garment_type == cf.GARMENT_TYPE                       # from the dataset: the config does not name it
+        rings = optNet.inter_free_curve().detach().clone()
+        loop = __import__('types').SimpleNamespace(batch_size=4, world_size=1, rank=0)
+        import io
+        import contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            train.register_feature_lines(optNet, train.CaptureLoader(ds, loop), templates, save_root)
+        path = os.path.join(save_root, 'fl_init', 'init_trans_matrix.pth')
+        stored = torch.load(path)
+        assert set(stored) == {'rigid_R', 'rigid_T', 'rigid_scale'} and stored['rigid_scale'].shape == (6,)
+        curves = optNet.inter_free_curve().detach()
+        assert curves.shape[0] == 6 and curves.shape != rings.shape or not torch.equal(curves, rings)
+        again, _ = getOptNet(ds, 'result', 3, box[0], box[1], res, 'cpu', conf, curves=True, skin_grid=(5, 9, 7))
+        stamp = os.path.getmtime(path)
+        with contextlib.redirect_stdout(io.StringIO()):
+            train.register_feature_lines(again, train.CaptureLoader(ds, loop), templates, save_root)
+        assert os.path.getmtime(path) == stamp                              # re-applied, not re-fitted
+        torch.testing.assert_close(again.inter_free_curve().detach(), curves, rtol=1e-6, atol=1e-7)
+    finally:
+        cpu_port.uninstall()

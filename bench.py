@@ -356,7 +356,7 @@ def whole_step_matrix_rate(roofline, steps, ms_per_step):
     rate = per_step / (ms_per_step * 1e-3)
     return {"matrix_tflop_per_step": round(per_step / 1e12, 3), "of_which_in_launches_too_short_to_time": round(small / steps / 1e12, 3),
             "achieved": round(rate / 1e12, 2), "unit": "TFLOP/s", "frac_of_f32_mfma_peak": round(rate / (roofline["peak"] * 1e12), 4),
-            "note": "all MFMA launches of the timed region (every variant, both GEMM kernels) over the whole step time"}
+            "note": "all MFMA launches of the timed region on rank 0 (every variant, both GEMM kernels) over the whole step time"}
 
 
 def main():

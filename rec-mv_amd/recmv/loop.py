@@ -530,6 +530,7 @@ class HotLoop:
         from .utils.constant import FL_INFOS
         save_fl_path = os.path.join(os.path.dirname(save_mesh_name), 'fl_init')
         os.makedirs(save_fl_path, exist_ok=True)
+        self._ensure_body_template()
         return scale_rigid_optimizer(self.deformer.defs[1], self.garment_fl_templates, (self.tmpBodyVs, self.tmpBodyFs), None,
                                      self.dataset, dataloader, save_fl_path, FL_INFOS[self.garment_type], device=device)
 

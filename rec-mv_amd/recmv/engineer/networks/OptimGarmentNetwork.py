@@ -17,6 +17,21 @@ import torch
 from ...loop import HotLoop
 
 
+def flatten_info(meta, parents=''):
+    """`make_recursive_meta_func` of the reference (utils/common_utils.py:73-84): nested dicts become 'a/b' keys, the first three
+    entries of a list or tuple '000' .. '002'."""
+    out = {}
+    if isinstance(meta, dict):
+        for k, v in meta.items():
+            out.update(flatten_info(v, parents + str(k) + '/'))
+    elif isinstance(meta, (list, tuple)):
+        for i, v in enumerate(meta[:3]):
+            out.update(flatten_info(v, parents + "{:03d}".format(i) + '/'))
+    else:
+        return {parents[:-1]: meta}
+    return out
+
+
 class OptimGarmentNetwork(HotLoop):
     def __call__(self, *args, **kwargs):
         return self.forward(*args, **kwargs)
@@ -44,6 +59,24 @@ class OptimGarmentNetwork(HotLoop):
 
     def eval(self):
         return self
+
+    def draw_loss(self, steps, **kwargs):
+        """:3309-3316 — everything in `self.info` (per-garment losses, ray counts, curve terms) plus the caller's scalars to the
+        visualizer, flattened.  Reads the 0-d device tensors of `info` back (one sync): train.py calls it every tenth
+        iteration, the reference every iteration."""
+        if getattr(self, 'visualizer', None) is None:
+            return
+        info = dict(self.info)
+        info.update(kwargs)
+        scalars = {}
+        for k, v in flatten_info(info).items():
+            if torch.is_tensor(v):
+                if v.numel() != 1:
+                    continue
+                v = v.item()
+            if isinstance(v, (bool, int, float)):
+                scalars[k] = float(v)
+        self.visualizer.add_scalar(scalars, int(steps))
 
     def align_fl(self, fl_align_path=None, epoch=0, fl_templates=None, sample_num=200):
         """train.py:209, OptimGarmentNetwork.py:3485-3546.  With template feature lines (`fl_templates` or

@@ -112,18 +112,6 @@ class CaptureLoader:
         return iter(loader)
 
 
-def _scalars(loss, info):
-    """The 0-d entries of optNet.info (per-garment losses, ray counts) + the total, for the visualizer."""
-    import torch
-    out = {'loss': float(loss)}
-    for k, v in info.items():
-        if isinstance(v, torch.Tensor) and v.numel() == 1:
-            out[k] = float(v)
-        elif isinstance(v, (int, float)):
-            out[k] = float(v)
-    return out
-
-
 def load_fl_templates(path, names, device='cpu'):
     """{line name: FeatureLineMesh} from an npz with `<line>_verts` / `<line>_faces` for every line in `names`."""
     import numpy as np
@@ -321,8 +309,8 @@ def main(argv=None, large_pose=False):
                     msg += ' | %s: eik %.4f pc_sdf %.5f' % (name, float(info.get(name + '_grad_loss', 0.)),
                                                            float(info.get('pc_%s_loss_sdf' % name, 0.)))
                 print(msg + ' (%.0f ms)' % ((time.perf_counter() - t0) * 1e3), flush=True)
-                if optNet.visualizer is not None and done % 10 == 0:
-                    optNet.visualizer.add_scalar(_scalars(loss, info), int(optNet.opt_times))
+                if done % 10 == 0:                                   # train.py:330 (every iteration there)
+                    optNet.draw_loss(optNet.opt_times, total_loss=float(loss), learning_rate=lr, ratio=ratio)
             optNet.opt_times += 1.
             done += 1
             if 0 <= args.max_iters <= done:

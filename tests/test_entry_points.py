@@ -173,3 +173,23 @@ def test_visualizer_without_wandb_writes_scalars_to_a_file(tmp_path, monkeypatch
     wv.watch_model(torch.nn.Linear(2, 2))
     rows = [json.loads(l) for l in open(tmp_path / 'exp.jsonl')]
     assert rows == [{'loss': 1.5, 'rays': 7.0, 'step': 3}, {'loss': 1.25, 'step': 4}]
+
+
+def test_draw_loss_flattens_info_like_the_reference(tmp_path, monkeypatch):
+    """OptimGarmentNetwork.draw_loss (:3309-3316) + make_recursive_meta_func (utils/common_utils.py:73-84): nested dicts -> 'a/b',
+    the first three entries of a tuple -> '000'..'002', the caller's scalars merged in; non-scalar tensors are skipped."""
+    import json
+    import types
+    monkeypatch.setenv('WANDB_MODE', 'disabled')
+    from recmv.engineer.networks.OptimGarmentNetwork import OptimGarmentNetwork, flatten_info
+    from recmv.engineer.visualizer import wandb_visualizer
+    assert flatten_info({'a': {'b': 1, 'c': (4, 5, 6, 7)}, 'd': 2.5}) == {'a/b': 1, 'a/c/000': 4, 'a/c/001': 5, 'a/c/002': 6, 'd': 2.5}
+    fake = types.SimpleNamespace(visualizer=wandb_visualizer('proj', 'run', log_dir=str(tmp_path)),
+                                 info={'upper_grad_loss': torch.tensor(0.25), 'upper_rayInfo': (3072, 1024),
+                                       'fl_loss': {'total': torch.tensor(2.0)}, 'surface_pixels': torch.ones(3)})
+    OptimGarmentNetwork.draw_loss(fake, 12., total_loss=1.5, learning_rate=1e-3, ratio={'sdfRatio': 1., 'deformerRatio': 0.6})
+    row = json.loads(open(tmp_path / 'run.jsonl').read())
+    assert row == {'upper_grad_loss': 0.25, 'upper_rayInfo/000': 3072.0, 'upper_rayInfo/001': 1024.0, 'fl_loss/total': 2.0,
+                   'total_loss': 1.5, 'learning_rate': 1e-3, 'ratio/sdfRatio': 1.0, 'ratio/deformerRatio': 0.6, 'step': 12}
+    fake.visualizer = None
+    OptimGarmentNetwork.draw_loss(fake, 13.)                                   # no sink: nothing to do

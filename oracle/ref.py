@@ -5,8 +5,10 @@ not using it).  The product (rec-mv_amd/) never imports this module.
 
 `oracle/_ref/*.so` are built in the development container from the sources under /root/reference (read-only) and
 travel to the GPU box as built files; `available()` tells whether they are there.  Functions mirror the contracts of
-`MCGpu.mc_gpu` (MCGpu/MCGpu.cpp:20-56) and `FastMinv.Fast3x3Minv(_backward)` (FastMinv/M3x3Inv.cpp:12-59) on CPU
-tensors, plus `canonical()` = the canonical MC ordering of SURVEY.md §8a-E applied to a reference run.
+`MCGpu.mc_gpu` (MCGpu/MCGpu.cpp:20-56), `FastMinv.Fast3x3Minv(_backward)` (FastMinv/M3x3Inv.cpp:12-59),
+`GridSamplerMine.forward / backward / dbackward` (MCAcc/cuda/GridSamplerMineKernel.cu:917-1022) and
+`interp2x_boundary3d.forward / backward` (MCAcc/cuda/interp2x_boundary3d_kernel.cu:243-304) on CPU tensors, plus
+`canonical()` = the canonical MC ordering of SURVEY.md §8a-E applied to a reference run.
 """
 from __future__ import annotations
 
@@ -20,7 +22,8 @@ import torch
 _HERE = Path(__file__).resolve().parent
 _REF = _HERE / "_ref"
 REFERENCE = Path("/root/reference")
-_LIBS = {"mc_fma": "libref_mc_fma.so", "mc_nofma": "libref_mc_nofma.so", "minv": "libref_minv.so"}
+_LIBS = {"mc_fma": "libref_mc_fma.so", "mc_nofma": "libref_mc_nofma.so", "minv": "libref_minv.so",
+         "gs3d_fma": "libref_gs3d_fma.so", "gs3d_nofma": "libref_gs3d_nofma.so", "interp2x": "libref_interp2x.so"}
 _loaded = {}
 
 
@@ -131,3 +134,72 @@ def inv3x3_backward(grads: torch.Tensor, invs: torch.Tensor):
     fn = {torch.float32: "ref_M3x3Inv_backward_float", torch.float64: "ref_M3x3Inv_backward_double"}[grads.dtype]
     getattr(_lib("minv"), fn)(_p(grads), _p(invs), _p(outs), C.c_int(grads.shape[0]))
     return outs
+
+
+# ------------------------------------------------------------------------------------ 3-D grid sampler
+def _i32(values):
+    return (C.c_int * 5)(*[int(v) for v in values])
+
+
+def _desc(t):
+    return _p(t), _i32(t.shape), _i32(t.stride())
+
+
+def _gs3d(fma):
+    return _lib("gs3d_fma" if fma else "gs3d_nofma")
+
+
+def _suffix(t):
+    return {torch.float32: "float", torch.float64: "double"}[t.dtype]
+
+
+def gs3d_forward(input, grid, interp=0, pad=1, fma=True):
+    """The reference's grid_sampler_3d_kernel (GridSamplerMineKernel.cu:160-328) run serially; tensors keep their strides."""
+    out = torch.empty(input.shape[0], input.shape[1], grid.shape[1], grid.shape[2], grid.shape[3], dtype=input.dtype)
+    getattr(_gs3d(fma), "ref_gs3d_forward_" + _suffix(input))(*_desc(input), *_desc(grid), *_desc(out), C.c_int(interp), C.c_int(pad))
+    return out
+
+
+def gs3d_backward(input, grid, grad_output, interp=0, pad=1, fma=True, scramble=0):
+    """grid_sampler_3d_backward_kernel (:331-570): (grad_input zeros + scattered adds, grad_grid).  `scramble` != 0 visits the
+    output locations in a scrambled order — the order in which a GPU's atomicAdd reaches grad_input is arbitrary."""
+    gi, gg = torch.zeros_like(input), torch.empty(grid.shape, dtype=grid.dtype)
+    L = _gs3d(fma)
+    n = grid.shape[0] * grid.shape[1] * grid.shape[2] * grid.shape[3]
+    L.ref_gs3d_set_loop_stride(C.c_long(_coprime_stride(n, scramble) if scramble else 1))
+    getattr(L, "ref_gs3d_backward_" + _suffix(input))(*_desc(grad_output), *_desc(input), *_desc(grid), *_desc(gi), *_desc(gg),
+                                                     C.c_int(interp), C.c_int(pad))
+    L.ref_gs3d_set_loop_stride(C.c_long(1))
+    return gi, gg
+
+
+def gs3d_dbackward(ggI, ggG, input, grid, grad_output, interp=0, pad=1, fma=True):
+    """grid_sampler_3d_backward_backward_kernel (:573-914): (grad_input, grad_grid, grad_grad_output)."""
+    gi, gg = torch.zeros_like(input), torch.empty(grid.shape, dtype=grid.dtype)
+    ggo = torch.zeros_like(grad_output)
+    getattr(_gs3d(fma), "ref_gs3d_dbackward_" + _suffix(input))(*_desc(ggI), *_desc(ggG), *_desc(grad_output), *_desc(input),
+                                                              *_desc(grid), *_desc(gi), *_desc(gg), *_desc(ggo),
+                                                              C.c_int(interp), C.c_int(pad))
+    return gi, gg, ggo
+
+
+# ------------------------------------------------------------------------------------ 2x boundary upsampler
+def interp2x_forward(input, balance_value):
+    """interp2x_boundary3d_cuda_forward_kernel (interp2x_boundary3d_kernel.cu:10-151): [output, is_boundary]."""
+    input = input.contiguous()
+    B, Cc, d, h, w = input.shape
+    out = torch.empty(B, Cc, 2 * d - 1, 2 * h - 1, 2 * w - 1, dtype=input.dtype)
+    bnd = torch.zeros(out.shape, dtype=torch.bool)
+    getattr(_lib("interp2x"), "ref_interp2x_forward_" + _suffix(input))(_p(input), _i32(input.shape), _p(out), _p(bnd),
+                                                                      _i32(out.shape), C.c_float(balance_value))
+    return [out, bnd]
+
+
+def interp2x_backward(grad_output):
+    """interp2x_boundary3d_cuda_backward_kernel (:154-239)."""
+    grad_output = grad_output.contiguous()
+    B, Cc, D, H, W = grad_output.shape
+    gi = torch.empty(B, Cc, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, dtype=grad_output.dtype)
+    getattr(_lib("interp2x"), "ref_interp2x_backward_" + _suffix(grad_output))(_p(grad_output), _i32(grad_output.shape), _p(gi),
+                                                                             _i32(gi.shape))
+    return gi

@@ -1,0 +1,130 @@
+"""Golden vectors for the silhouette branch as a WHOLE, from the REAL reference method `OptimGarmentNetwork.mask_loss`
+(engineer/networks/OptimGarmentNetwork.py:841-981) on a stand-in `self`: deformation of both explicit garment meshes through the
+reference's CompositeDeformer, the reference's own `PointsRendererWithFrags_Split` (model/CameraMine.py:347-415) around the merged
+point cloud, the dilation of the ground-truth masks by the splat radius, `compute_garment_pc_loss` per garment (IoU + LBS
+consistency), the SGD step on the explicit vertices, the |SDF| terms of both garment nets — value, info, the moved vertices, and
+the gradients the branch leaves on the deformer, the per-frame codes and the poses for the main optimiser.
+
+What is stood in: pytorch3d's `PointsRasterizer` / `AlphaCompositor` (absent) by the C oracle's restatements with their backward
+(oracle/cpu_port — parity of those two against pytorch3d stays unpinned), `Meshes` / `Pointclouds` by plain
+holders, the camera by recmv's restatement (pinned by camera_ndc.npz); `find_surface_ps` and `curve_aware_loss` (pinned by their
+own fixtures) return nothing / zero.
+
+    python tests/golden/make_golden_mask_loss.py
+"""
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent))
+sys.path[:0] = [str(REPO / "rec-mv_amd"), str(REPO)]
+import ref_loader  # noqa: E402
+
+ref_loader.install()
+import common_setup as cs  # noqa: E402
+import mask_loss_case as mc  # noqa: E402
+from make_golden import save  # noqa: E402
+
+
+class Meshes:
+    def __init__(self, verts, faces):
+        self._verts, self._faces = list(verts), list(faces)
+
+    def verts_list(self):
+        return self._verts
+
+    def verts_padded(self):
+        return torch.stack(self._verts)
+
+
+class Pointclouds:
+    def __init__(self, points, features):
+        self.points, self.features = list(points), list(features)
+
+    def points_packed(self):
+        return torch.cat(self.points, 0)
+
+    def features_packed(self):
+        return torch.cat(self.features, 0)
+
+
+def main():
+    ref_loader.ref_module("model.network")
+    Nref = ref_loader.ref_module("model.network")
+    Dref = ref_loader.ref_module("model.Deformer")
+    Cref = ref_loader.ref_module("model.CameraMine")
+    OGN = ref_loader.ref_module("engineer.networks.OptimGarmentNetwork")
+    from oracle import cpu_port
+    from recmv.hocon import ConfigFactory
+    from recmv.model import RectifiedPerspectiveCameras as OurCameras
+    OGN.Meshes, OGN.Pointclouds = Meshes, Pointclouds
+    conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf")).get_config('loss_coarse')
+    st = mc.state()
+    cam = OurCameras(st['focal'], st['pp'], st['R'], st['T'], image_size=[(mc.W, mc.H)])
+
+    class Rasterizer:
+        raster_settings = types.SimpleNamespace(radius=mc.RADIUS, points_per_pixel=mc.K)
+
+        def __call__(self, clouds, **kwargs):
+            pts = clouds.points_packed()
+            n, v = len(clouds.points), clouds.points[0].shape[0]
+            ndc = cam.transform_points_ndc(pts.reshape(-1, 3)).contiguous()
+            first, num = torch.arange(n) * v, torch.full((n,), v)
+            return cpu_port._rasterize_points(ndc, first, num, (mc.H, mc.W), mc.RADIUS, mc.K, max_points_per_cloud=v)
+
+    class Compositor:
+        def __call__(self, idx, weights, features, **kwargs):
+            return cpu_port._AlphaCompositeCPU.apply(idx.permute(0, 2, 3, 1).to(torch.int32).contiguous(),
+                                                  weights.permute(0, 2, 3, 1).contiguous(), features.contiguous())
+
+    sdfs = mc.build_sdfs(Nref.getTmpSdf)
+    tr = cs.build_translator(Dref.MLPTranslator)
+    sk = cs.build_skinner(Dref.LBSkinner, Dref.batch_rodrigues)
+    comp = Dref.CompositeDeformer([tr, sk])
+    leaf = lambda t: t.detach().clone().requires_grad_(True)
+    leaves = dict(conds_u=leaf(st['conds_u']), conds_b=leaf(st['conds_b']), poses=leaf(st['poses']), trans=leaf(st['trans']))
+    verts = [leaf(st['verts_u']), leaf(st['verts_b'])]
+    fake = types.SimpleNamespace(conf=conf, info={}, garment_size=2, garment_names=['upper', 'bottom'], garment_vs=verts,
+                                 garment_fs=[st['faces_u'], st['faces_b']], garment_nets=sdfs, deformer=comp, body_vs=st['verts_u'],
+                                 sdfShrinkRadius=0.0)
+    fake.get_grad_parameters = lambda fids, dev: ([None, leaves['conds_u'], leaves['conds_b']], leaves['poses'], leaves['trans'], None)
+    fake.find_surface_ps = lambda meshes: None
+    fake.curve_aware_loss = lambda ratio: 0.
+    fake.compute_garment_pc_loss = types.MethodType(OGN.OptimGarmentNetwork.compute_garment_pc_loss, fake)
+    fake.pcRender = Cref.PointsRendererWithFrags_Split(Rasterizer(), Compositor())
+    fake.garment_optimizer = torch.optim.SGD(verts, lr=0.05, momentum=0.9)
+    for m in sdfs + [comp]:
+        for q in m.parameters():
+            q.grad = None
+    ratio = {"sdfRatio": 0.8, "deformerRatio": 0.7, "renderRatio": 1.0}
+    out = OGN.OptimGarmentNetwork.mask_loss(fake, mc.N, mc.H, mc.W, torch.arange(mc.N), ratio, [st['gt_u'], st['gt_b']], 'cpu')
+    def_meshes, masks, dilated, pc_sdf_loss, _ = out
+    print("pc_sdf_loss", float(pc_sdf_loss.detach()), {k: v for k, v in fake.info.items() if not isinstance(v, dict)}, fake.info['pc_loss'])
+    pc_sdf_loss.backward()
+    tp = dict(tr.named_parameters())
+    res = dict(pc_sdf_loss=pc_sdf_loss, new_verts_u=verts[0].detach(), new_verts_b=verts[1].detach(),
+               mask_u=masks[0].detach(), mask_b=masks[1].detach(), dilated_u=dilated[0], dilated_b=dilated[1],
+               def_u=def_meshes[0].verts_padded().detach(), def_b=def_meshes[1].verts_padded().detach(),
+               info_upper_mask=torch.tensor(fake.info['pc_loss']['upper_mask_loss']),
+               info_bottom_mask=torch.tensor(fake.info['pc_loss']['bottom_mask_loss']),
+               info_upper_sdf=torch.tensor(fake.info['pc_upper_loss_sdf']), info_bottom_sdf=torch.tensor(fake.info['pc_bottom_loss_sdf']))
+    for k in mc.TR_KEYS:
+        res['g_tr_' + k.replace('.', '_')] = tp[k].grad[:mc.ROWS]
+    for k, v in leaves.items():
+        res['g_' + k] = v.grad if v.grad is not None else torch.zeros_like(v)
+    for i, net in enumerate(sdfs):
+        sp = dict(net.named_parameters())
+        for k in mc.SDF_KEYS:
+            res['g_sdf%d_' % i + k.replace('.', '_')] = sp[k].grad[:mc.ROWS]
+    res.update({'in_' + k: v for k, v in st.items()})
+    save("mask_loss", **res)
+
+
+if __name__ == "__main__":
+    main()

@@ -326,3 +326,18 @@ def test_fl_proj_loss_batched_and_per_pair_routes_agree():
             assert (a is None or float(a.abs().max()) == 0.0) and (b is None or float(b.abs().max()) == 0.0)
         else:
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_mask_loss_matches_the_reference_method():
+    """OptimGarmentNetwork.mask_loss (:841-981) run for real as a whole (tests/golden/make_golden_mask_loss.py): both garments
+    deformed, the reference's PointsRendererWithFrags_Split around the merged cloud, dilated ground-truth masks, IoU + LBS
+    consistency per garment, the SGD step on the explicit vertices, the |SDF| terms — value, info, moved vertices, and the
+    gradients left for the main optimiser (tests/mask_loss_case.py)."""
+    from oracle import cpu_port
+    import mask_loss_case as mlc
+    cpu_port.install()
+    try:
+        worst = mlc.run(load("mask_loss"), "cpu")
+        assert max(worst.values()) < 1e-4, worst                  # (measured: <= 9e-6, the pose / translation gradients)
+    finally:
+        cpu_port.uninstall()

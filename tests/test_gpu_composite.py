@@ -43,3 +43,11 @@ def test_fl_visibility_on_gpu_matches_the_reference_method():
 
 def test_curve_aware_loss_on_gpu_matches_the_reference_method():
     cc.run_curve_aware(DEV)
+
+
+def test_mask_loss_on_gpu_matches_the_reference_method():
+    """OptimGarmentNetwork.mask_loss (:841-981) as a whole (tests/golden/make_golden_mask_loss.py) through the HIP point
+    rasteriser + compositor, the fused skinner and the MFMA layers: value, info, moved vertices, gradients."""
+    import mask_loss_case as mlc
+    worst = mlc.run(cc.load("mask_loss"), DEV, rtol=1e-3, rtol_grad=1e-2)
+    print("mask_loss on the GPU, largest relative deviations:", {k: "%.1e" % v for k, v in worst.items() if v > 1e-6})

@@ -341,3 +341,18 @@ def test_mask_loss_matches_the_reference_method():
         assert max(worst.values()) < 1e-4, worst                  # (measured: <= 9e-6, the pose / translation gradients)
     finally:
         cpu_port.uninstall()
+
+
+def test_project_2d_loss_matches_the_reference_method():
+    """OptimGarmentNetwork.project_2d_loss (:1772-1883) run for real as a whole (tests/golden/make_golden_project2d.py): the
+    reference's deform_feature_line, body / garment z-buffer visibility, compute_fl_proj_loss and curve SDF terms for two
+    garments and six curves, one AdamW step — per-garment losses, the total, the curve-parameter gradients and the stepped
+    parameters (tests/project2d_case.py)."""
+    from oracle import cpu_port
+    import project2d_case as p2c
+    cpu_port.install()
+    try:
+        worst = p2c.run(load("project2d"), "cpu")
+        assert max(worst.values()) < 1e-5, worst                  # (measured: <= 1.2e-7)
+    finally:
+        cpu_port.uninstall()

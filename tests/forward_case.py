@@ -1,0 +1,179 @@
+"""The whole-iteration case shared by tests/golden/make_golden_forward.py (the REFERENCE's OptimGarmentNetwork.forward +
+backward + propagateTmpPsGrad) and the tests (recmv's HotLoop): the state of tests/project2d_case.py (two explicit garment
+meshes, body, six curves, camera, 2-D feature lines) on a 40-frame sequence, plus images, normal maps, garment masks and
+per-frame colour codes."""
+import torch
+
+import project2d_case as pc
+
+N, H, W, F = pc.N, pc.H, pc.W, 40
+FRAME_IDS = [0, 17, 39]
+SAMPLE_PIX = 40
+RADIUS, K = 0.06, 50
+SEED = 123
+TR_KEYS = ["lin0.weight", "lin2.bias", "lin4.weight"]
+SDF_KEYS = ["lin0.weight_v", "lin4.weight_g", "lin8.bias", "lin8.weight_v"]
+RN_KEYS = ["lin0.weight_v", "lin4.bias"]
+ROWS = 24
+
+
+def state():
+    st = pc.state()
+    g = torch.Generator().manual_seed(141)
+    st['poses_all'] = 0.15 * torch.randn(F, 24, 3, generator=g)
+    st['trans_all'] = 0.02 * torch.randn(F, 3, generator=g)
+    st['cu_all'] = 0.1 * torch.randn(F, 128, generator=g)
+    st['cb_all'] = 0.1 * torch.randn(F, 128, generator=g)
+    st['rend_all'] = 0.1 * torch.randn(F, 256, generator=g)
+    st['img'] = torch.rand(N, H, W, 3, generator=g) * 2 - 1
+    st['normal'] = torch.nn.functional.normalize(torch.randn(N, H, W, 3, generator=g), dim=-1)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing='ij')
+    st['gt_u'] = torch.stack([(((yy - 22 - i) / 13) ** 2 + ((xx - 24 + i) / 12) ** 2 < 1).float() for i in range(N)])
+    st['gt_b'] = torch.stack([(((yy - 43 + i) / 12) ** 2 + ((xx - 23 - i) / 11) ** 2 < 1).float() for i in range(N)])
+    for k in ('conds_u', 'conds_b', 'poses', 'trans'):
+        del st[k]
+    return st
+
+
+# ----------------------------------------------------------------------------------------------- recmv side
+class CaseDataset:
+    """What HotLoop asks of a caller's dataset (recmv/model/network.py getOptNet), over the fixture's tensors."""
+
+    video_segmented_index = []
+
+    def __init__(self, st, device):
+        leaf = lambda t: t.detach().clone().to(device).requires_grad_(True)
+        self.F = self.frame_num = F
+        self.H, self.W = H, W
+        self.garment_type = 'female-3-casual'
+        self.poses, self.trans = leaf(st['poses_all']), leaf(st['trans_all'])
+        self.dcond = leaf(torch.cat([torch.zeros(F, 128), st['cu_all'].cpu(), st['cb_all'].cpu()], dim=1))
+        self.rend = leaf(st['rend_all'])
+        self.conds = [self.dcond, self.rend]
+        self.focal, self.pp, self.T = leaf(st['focal']), leaf(st['pp']), leaf(st['T'])
+        self.R = st['R'].to(device)
+        self.camera_params = {'focal_length': self.focal, 'princeple_points': self.pp, 'world2cam_coord_trans': self.T}
+        self.fl_weights = dict(pc.WEIGHTS)
+        self.shape = torch.zeros(10)
+
+    def __len__(self):
+        return F
+
+    def get_grad_parameters(self, fids, device):
+        return self.poses[fids], self.trans[fids], self.dcond[fids], self.rend[fids]
+
+    def get_camera_parameters(self, n, device):
+        return self.focal.expand(n, 2), self.pp.expand(n, 2), self.R.expand(n, 3, 3), self.T.expand(n, 3), H, W
+
+    def get_batchframe_data(self, name, fids, batchsize):
+        from recmv.dataset import SceneDataset
+        return SceneDataset.get_batchframe_data(self, name, fids, batchsize)
+
+    def learnable_weights(self):
+        return [self.poses, self.trans, self.dcond, self.rend, self.focal, self.pp, self.T]
+
+
+def run(g, device, rtol=1e-3, rtol_grad=1e-2):
+    """One whole iteration of recmv's loop — HotLoop.forward, backward, propagateTmpPsGrad — on the fixture's state against
+    what the reference's forward / backward / propagateTmpPsGrad produced; returns the largest relative deviations."""
+    from pathlib import Path
+    import numpy as np
+    import common_setup as cs
+    import mask_loss_case as mlc
+    from recmv import curves as fl
+    from recmv.hocon import ConfigFactory
+    from recmv.loop import HotLoop, dct_nullspace
+    from recmv.model import CompositeDeformer, LBSkinner, MLPTranslator, RenderingNetwork_view_norm, getTmpSdf
+    from recmv.model.network import getOptNet
+    repo = Path(__file__).resolve().parent.parent
+    conf = ConfigFactory.parse_file(str(repo / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    dev = torch.device(device)
+    st = {k[3:]: v.to(dev) for k, v in g.items() if k.startswith('in_')}
+    ds = CaseDataset(st, dev)
+    optNet, _ = getOptNet(ds, None, N, (-0.8, -1.1, -0.6), (0.8, 1.1, 0.6), [(9, 11, 7), (17, 21, 13)], device, conf, curves=False,
+                          skin_grid=(5, 9, 7))
+    leaf = lambda t: t.detach().clone().requires_grad_(True)
+    sdfs = [n.to(dev) for n in mlc.build_sdfs(getTmpSdf)]
+    tr = cs.build_translator(MLPTranslator).to(dev)
+    sk = cs.build_skinner(LBSkinner).to(dev)
+    rn = cs.build_render(RenderingNetwork_view_norm).to(dev)
+    optNet.garment_nets = torch.nn.ModuleList(sdfs)
+    optNet.deformer = CompositeDeformer([tr, sk])
+    optNet.netRender = rn
+    verts = [leaf(st['verts_u']), leaf(st['verts_b'])]
+    optNet.garment_vs, optNet.garment_fs = verts, [st['faces_u'].long(), st['faces_b'].long()]
+    optNet.body_vs, optNet.body_fs = st['body_v'], st['body_f'].long()
+    optNet.tmpBodyVs, optNet.tmpBodyFs = st['body_v'], st['body_f'].long()
+    optNet.garment_optimizer = torch.optim.SGD(verts, lr=0.05, momentum=0.9)
+    curve = fl.Intersect_Free_Curve(list(st['curves']), list(0.9 * st['curves']), pc.NAMES).to(dev)
+    with torch.no_grad():
+        curve.scale.copy_(st['scale'])
+        curve.nx_scale.copy_(st['nx_scale'])
+    optNet.inter_free_curve, optNet.fl_names, optNet.curves = curve, list(pc.NAMES), True
+    optNet.fl_extract = {'upper': pc.UPPER, 'bottom': pc.BOTTOM}
+    optNet.fl_optimizer = torch.optim.AdamW(curve.parameters(), lr=1e-4)
+    optNet.forward_time, optNet.remesh_intersect, optNet.pc_radius, optNet.sample_pix = 1, 30, RADIUS, SAMPLE_PIX
+    optNet.angThred = optNet._cameras().angThreshold(0.5)
+    optNet.dctnull = dct_nullspace(30, 10, dev)
+    optNet._datas = dict(img=st['img'], normal=st['normal'], fl_pts=st['gt'], fl_masks=st['fl_masks'], upper=st['gt_u'],
+                         bottom=st['gt_b'])
+    cs.TrimeshStandIn.rng = np.random.RandomState(SEED)
+
+    def sampler(verts_, faces_, n):
+        pts = cs.TrimeshStandIn(verts_.detach().cpu().numpy(), faces_.cpu().numpy()).sample(n)
+        return torch.from_numpy(pts).float().to(dev)
+
+    optNet.curve_aware_loss = lambda ratio: HotLoop.curve_aware_loss(optNet, ratio, sampler=sampler)
+    opt = optNet.rebuild_optimizer()
+    frame_ids = torch.tensor(FRAME_IDS, device=dev)
+    torch.manual_seed(SEED)
+    loss = HotLoop.forward(optNet, frame_ids, pc.RATIO, global_optimizer=opt)
+    loss.backward()
+    optNet.propagateTmpPsGrad(frame_ids, pc.RATIO)
+    worst = {}
+
+    def close(name, got, want, rt):
+        want = want.to(torch.float32)
+        got = torch.as_tensor(got).detach().cpu().to(torch.float32).reshape(want.shape)
+        scale = max(float(want.abs().max()), 1e-12)
+        worst[name] = float((got - want).abs().max()) / scale
+        assert torch.allclose(got, want, rtol=rt, atol=rt * scale), (name, worst[name])
+
+    close('loss', loss, g['loss'], rtol)
+    info = optNet.info
+    ref_name = {'upper': 'short_sleeve_upper', 'bottom': 'long_pants'}
+    for mine, theirs in ref_name.items():
+        for key_mine, key_ref in (('%s_grad_loss', 'info_%s_grad_loss'), ('def_%s_loss', 'info_def_%s_loss'),
+                                  ('%s_color_loss', 'info_%s_color_loss'), ('%s_normal_loss', 'info_%s_normal_loss'),
+                                  ('pc_%s_loss_sdf', 'info_pc_%s_loss_sdf'), ('pc_%s_mask_loss', 'info_pc_loss__%s_mask_loss')):
+            close(key_mine % mine, info[key_mine % mine], g[key_ref % theirs], rtol)
+        assert tuple(int(v) for v in info['%s_invInfo' % mine]) == tuple(int(v) for v in g['info_%s_invInfo' % theirs]), mine
+        close('fl %s project loss' % mine, info['fl_loss']['%s_project loss' % mine], g['info_fl_loss__%s_project_loss' % theirs], rtol)
+    want_rays = [tuple(int(v) for v in g['info_%s_rayInfo' % n]) for n in ref_name.values()]     # (entering, converged) per garment
+    assert int(info['rays_total']) == sum(r[0] for r in want_rays), (info['rays_total'], want_rays)
+    assert [int(v) for v in info['rays_converged']] == [r[1] for r in want_rays], (info['rays_converged'], want_rays)
+    close('dct_loss', info['dct_loss'], g['info_dct_loss'], rtol)
+    close('curve-aware disc', info['pc_upper_bottom_circle_loss_sdf'], g['info_pc_upper_bottom_circle_loss_sdf'], rtol)
+    close('new_verts_u', verts[0], g['new_verts_u'], rtol)
+    close('new_verts_b', verts[1], g['new_verts_b'], rtol)
+    close('curve scale after its step', curve.scale, g['new_scale'], 1e-5)
+    close('curve nx_scale after its step', curve.nx_scale, g['new_nx'], 1e-4)
+    tp, rp = dict(tr.named_parameters()), dict(rn.named_parameters())
+    for k in TR_KEYS:
+        close('g_tr_' + k, tp[k].grad[:ROWS], g['g_tr_' + k.replace('.', '_')], rtol_grad)
+    for k in RN_KEYS:
+        close('g_rn_' + k, rp[k].grad[:ROWS], g['g_rn_' + k.replace('.', '_')], rtol_grad)
+    for i, net in enumerate(sdfs):
+        sp = dict(net.named_parameters())
+        for k in SDF_KEYS:
+            close('g_sdf%d_%s' % (i, k), sp[k].grad[:ROWS], g['g_sdf%d_' % i + k.replace('.', '_')], rtol_grad)
+    zero = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)
+    close('g_poses', zero(ds.poses), g['g_poses_all'], rtol_grad)
+    close('g_trans', zero(ds.trans), g['g_trans_all'], rtol_grad)
+    close('g_cond_upper', zero(ds.dcond)[:, 128:256], g['g_cu_all'], rtol_grad)
+    close('g_cond_bottom', zero(ds.dcond)[:, 256:], g['g_cb_all'], rtol_grad)
+    close('g_rendcond', zero(ds.rend), g['g_rend_all'], rtol_grad)
+    close('g_focal', zero(ds.focal), g['g_focal'], rtol_grad)
+    close('g_pp', zero(ds.pp), g['g_pp'], rtol_grad)
+    close('g_T', zero(ds.T), g['g_T'], rtol_grad)
+    return worst

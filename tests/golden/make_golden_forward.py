@@ -1,0 +1,204 @@
+"""Golden vectors for ONE WHOLE ITERATION, from the REAL reference: `OptimGarmentNetwork.forward` (engineer/networks/
+OptimGarmentNetwork.py:1885-1969) -> `loss.backward()` -> `propagateTmpPsGrad` (:2159-2313), every method underneath the
+reference's own (project_2d_loss, mask_loss, find_surface_ps, sample_train_ray, opt_garment_surface_ps, surface_render_loss,
+dct_poses_loss, curve_aware_loss, compute_*; utils.FindSurfacePs / OptimizeGarmentSurfacePs / compute_Jacobian / ...; the SDF,
+offset, skinning and colour networks): the loss, the info entries, the explicit vertices after the SGD step, the curve
+parameters after the AdamW step and the gradients the main optimiser would consume.
+
+What is stood in (as in the per-method generators): pytorch3d's mesh / point rasterisers and compositor by the C oracle's, `Meshes`
+/ `Pointclouds` by holders, `chamfer_distance` by the restatement of recmv.curves, the camera by recmv's restatement, trimesh's
+surface sampling by common_setup.TrimeshStandIn; no re-mesh inside (forward_time = 1: the explicit meshes are inputs).
+
+    python tests/golden/make_golden_forward.py
+"""
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent))
+sys.path[:0] = [str(REPO / "rec-mv_amd"), str(REPO)]
+import ref_loader  # noqa: E402
+
+ref_loader.install()
+import common_setup as cs  # noqa: E402
+import forward_case as fc  # noqa: E402
+import mask_loss_case as mlc  # noqa: E402
+import project2d_case as pc  # noqa: E402
+from make_golden import save  # noqa: E402
+
+
+class Meshes:
+    def __init__(self, verts, faces):
+        self.verts, self.faces = list(verts), list(faces)
+
+    def verts_list(self):
+        return self.verts
+
+    def verts_padded(self):
+        return torch.stack(self.verts)
+
+
+class Pointclouds:
+    def __init__(self, points, features):
+        self.points, self.features = list(points), list(features)
+
+    def points_packed(self):
+        return torch.cat(self.points, 0)
+
+    def features_packed(self):
+        return torch.cat(self.features, 0)
+
+
+def main():
+    Nref = ref_loader.ref_module("model.network")
+    Dref = ref_loader.ref_module("model.Deformer")
+    Rref = ref_loader.ref_module("model.RenderNet")
+    Cref = ref_loader.ref_module("model.CameraMine")
+    Uref = ref_loader.ref_module("utils.utils")
+    G = ref_loader.ref_module("engineer.utils.garment_structure")
+    DS = ref_loader.ref_module("dataset.dataset")
+    OGN = ref_loader.ref_module("engineer.networks.OptimGarmentNetwork")
+    from oracle import cpu_port, oracle as orc
+    from recmv import curves as ours
+    from recmv.hocon import ConfigFactory
+    from recmv.model import RectifiedPerspectiveCameras as OurCameras
+    OGN.Meshes, OGN.Pointclouds, OGN.RectifiedPerspectiveCameras = Meshes, Pointclouds, OurCameras
+    OGN.fl_proj_loss.__globals__["chamfer_distance"] = lambda a, b, point_reduction='sum': (ours.chamfer_distance_sum(a, b), None)
+    cs.TrimeshStandIn.rng = np.random.RandomState(fc.SEED)
+    OGN.trimesh = types.SimpleNamespace(Trimesh=cs.TrimeshStandIn)
+    conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf")).get_config('loss_coarse')
+    st = fc.state()
+    H, W, N = fc.H, fc.W, fc.N
+    frame_ids = torch.tensor(fc.FRAME_IDS)
+
+    class MaskRender:
+        rasterizer = types.SimpleNamespace(cameras=None)
+
+        def __call__(self, meshes):
+            cam = self.rasterizer.cameras
+            verts = torch.stack([v.detach() for v in meshes.verts])
+            faces = meshes.faces[0]
+            n, f = verts.shape[0], faces.shape[0]
+            ndc = cam.transform_points_ndc(verts.reshape(-1, 3)).view(n, -1, 3)
+            fv = ndc[:, faces.reshape(-1)].reshape(-1, 3, 3)
+            p2f, zbuf, bary, dists = orc.rasterize_meshes(fv, torch.arange(n) * f, torch.full((n,), f), (H, W))
+            return None, types.SimpleNamespace(zbuf=zbuf, pix_to_face=p2f, bary_coords=bary, dists=dists)
+
+    class PointRasterizer:
+        raster_settings = types.SimpleNamespace(radius=fc.RADIUS, points_per_pixel=fc.K)
+        cameras = None
+
+        def __call__(self, clouds, **kwargs):
+            pts = clouds.points_packed()
+            n, v = len(clouds.points), clouds.points[0].shape[0]
+            ndc = self.cameras.transform_points_ndc(pts.reshape(-1, 3)).contiguous()
+            return cpu_port._rasterize_points(ndc, torch.arange(n) * v, torch.full((n,), v), (H, W), fc.RADIUS, fc.K,
+                                              max_points_per_cloud=v)
+
+    class Compositor:
+        def __call__(self, idx, weights, features, **kwargs):
+            return cpu_port._AlphaCompositeCPU.apply(idx.permute(0, 2, 3, 1).to(torch.int32).contiguous(),
+                                                     weights.permute(0, 2, 3, 1).contiguous(), features.contiguous())
+
+    sdfs = mlc.build_sdfs(Nref.getTmpSdf)
+    # the explicit meshes of an iteration are extractions of their nets: put the blobs' vertices on the zero levels (Newton steps
+    # along the gradient), so that the rasterised surface points are starting points the root finder converges from
+    for key, net, radius in (('verts_u', sdfs[0], 0.5), ('verts_b', sdfs[1], 0.4)):
+        v = torch.nn.functional.normalize(st[key] - st[key].mean(0, keepdim=True), dim=1) * radius
+        for _ in range(6):
+            v = v.detach().requires_grad_(True)
+            f = net(v, pc.RATIO)
+            gr = torch.autograd.grad(f.sum(), v)[0]
+            v = (v - f * gr / (gr * gr).sum(1, keepdim=True)).detach()
+        st[key] = v
+    tr = cs.build_translator(Dref.MLPTranslator)
+    sk = cs.build_skinner(Dref.LBSkinner, Dref.batch_rodrigues)
+    comp = Dref.CompositeDeformer([tr, sk])
+    rn = cs.build_render(Rref.RenderingNetwork_view_norm)
+    ref = object.__new__(G.Intersect_Free_Curve)
+    torch.nn.Module.__init__(ref)
+    ref.cano2canosmpl = lambda lst, nm: [0.9 * c for c in lst]
+    ref.fl_names, ref.sample_num = list(pc.NAMES), pc.S
+    ref.initialize_parameters([c.clone() for c in st['curves']])
+    with torch.no_grad():
+        ref.scale.copy_(st['scale'])
+        ref.nx_scale.copy_(st['nx_scale'])
+    leaf = lambda t: t.detach().clone().requires_grad_(True)
+    leaves = dict(poses_all=leaf(st['poses_all']), trans_all=leaf(st['trans_all']), cu_all=leaf(st['cu_all']), cb_all=leaf(st['cb_all']),
+                  rend_all=leaf(st['rend_all']), focal=leaf(st['focal']), pp=leaf(st['pp']), T=leaf(st['T']))
+    verts = [leaf(st['verts_u']), leaf(st['verts_b'])]
+    ds_cls = [v for v in vars(DS).values() if isinstance(v, type) and getattr(v, "__module__", "") == DS.__name__
+              and "get_batchframe_data" in vars(v)][0]
+    dataset = types.SimpleNamespace(video_segmented_index=[], frame_num=fc.F, poses=leaves['poses_all'], trans=leaves['trans_all'],
+                                    fl_weights=dict(pc.WEIGHTS))
+    dataset.get_batchframe_data = lambda name, fids, bs: ds_cls.get_batchframe_data(dataset, name, fids, bs)
+    dataset.get_camera_parameters = lambda n, dev: (leaves['focal'].expand(n, 2), leaves['pp'].expand(n, 2), st['R'].expand(n, 3, 3),
+                                                    leaves['T'].expand(n, 3), H, W)
+    cam0 = OurCameras(st['focal'], st['pp'], st['R'], st['T'], image_size=[(W, H)])
+    names = ['short_sleeve_upper', 'long_pants']
+    fake = types.SimpleNamespace(conf=conf, info={}, garment_size=2, garment_names=names, garment_vs=verts, is_upper_bottom=False,
+                                 garment_fs=[st['faces_u'], st['faces_b']], garment_nets=sdfs, deformer=comp, netRender=rn,
+                                 sdfShrinkRadius=0.0, body_vs=st['body_v'], body_fs=st['body_f'], tmpBodyVs=st['body_v'],
+                                 tmpBodyFs=st['body_f'], inter_free_curve=ref, fl_names=list(pc.NAMES), maskRender=MaskRender(),
+                                 dataset=dataset, forward_time=1, remesh_intersect=30, remesh_time=0., root=None,
+                                 dctnull=Uref.DCTNullSpace(10, 30), angThred=cam0.angThreshold(0.5), garment_type='female-3-casual',
+                                 isfine=False)
+    fake.pcRender = Cref.PointsRendererWithFrags_Split(PointRasterizer(), Compositor())
+    fake.get_grad_parameters = lambda fids, dev: ([None, leaves['cu_all'][fids], leaves['cb_all'][fids]], leaves['poses_all'][fids],
+                                                  leaves['trans_all'][fids], leaves['rend_all'][fids])
+    for name in ('project_2d_loss', 'deform_feature_line', 'fl_visible_by_body_zbuff', 'compute_fl_proj_loss', 'mask_loss',
+                 'find_surface_ps', 'compute_garment_pc_loss', 'curve_aware_loss', 'sample_train_ray', 'opt_garment_surface_ps',
+                 'surface_render_loss', 'dct_poses_loss', 'save_debug'):
+        setattr(fake, name, types.MethodType(getattr(OGN.OptimGarmentNetwork, name), fake))
+    fake.garment_optimizer = torch.optim.SGD(verts, lr=0.05, momentum=0.9)
+    fake.fl_optimizer = torch.optim.AdamW(ref.parameters(), lr=1e-4)
+    shared = [q for m in sdfs + [comp, rn] for q in m.parameters()] + list(leaves.values())
+    opt = torch.optim.Adam(shared, lr=1e-3)
+    datas = dict(img=st['img'], mask=((st['gt_u'] + st['gt_b']) > 0).float(), fl_pts=st['gt'], fl_masks=st['fl_masks'],
+                 upper=st['gt_u'], bottom=st['gt_b'], body=torch.zeros_like(st['gt_u']), normal=st['normal'])
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self                    # curve_aware_loss uploads its samples with .cuda() (:809)
+    try:
+        torch.manual_seed(fc.SEED)
+        loss = OGN.OptimGarmentNetwork.forward(fake, datas, fc.SAMPLE_PIX, pc.RATIO, frame_ids, None, global_optimizer=opt)
+        loss.backward()
+        OGN.OptimGarmentNetwork.propagateTmpPsGrad(fake, frame_ids, pc.RATIO)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    flat = {}
+    for k, v in fake.info.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[k + '/' + kk] = vv
+        else:
+            flat[k] = v
+    print("loss %.6f" % float(loss.detach()))
+    print({k: (tuple(v) if isinstance(v, tuple) else round(float(v), 6)) for k, v in flat.items()})
+    res = dict(loss=loss.detach(), new_verts_u=verts[0].detach(), new_verts_b=verts[1].detach(), new_scale=ref.scale.detach(),
+               new_nx=ref.nx_scale.detach())
+    for k, v in flat.items():
+        key = 'info_' + k.replace('/', '__').replace(' ', '_')
+        res[key] = torch.tensor([float(x) for x in v]) if isinstance(v, tuple) else torch.tensor(float(v))
+    tp, rp = dict(tr.named_parameters()), dict(rn.named_parameters())
+    for k in fc.TR_KEYS:
+        res['g_tr_' + k.replace('.', '_')] = tp[k].grad[:fc.ROWS]
+    for k in fc.RN_KEYS:
+        res['g_rn_' + k.replace('.', '_')] = rp[k].grad[:fc.ROWS]
+    for i, net in enumerate(sdfs):
+        sp = dict(net.named_parameters())
+        for k in fc.SDF_KEYS:
+            res['g_sdf%d_' % i + k.replace('.', '_')] = sp[k].grad[:fc.ROWS]
+    for k, v in leaves.items():
+        res['g_' + k] = v.grad if v.grad is not None else torch.zeros_like(v)
+    res.update({'in_' + k: v for k, v in st.items()})
+    save("forward", **res)
+
+
+if __name__ == "__main__":
+    main()

@@ -73,9 +73,11 @@ class CaseDataset:
         return [self.poses, self.trans, self.dcond, self.rend, self.focal, self.pp, self.T]
 
 
-def run(g, device, rtol=1e-3, rtol_grad=1e-2):
+def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None):
     """One whole iteration of recmv's loop — HotLoop.forward, backward, propagateTmpPsGrad — on the fixture's state against
-    what the reference's forward / backward / propagateTmpPsGrad produced; returns the largest relative deviations."""
+    what the reference's forward / backward / propagateTmpPsGrad produced; returns the largest relative deviations.
+    `large_pose`: the large-pose stage on both sides (OptimGarmentNetwork_LargePose: SDF nets frozen, curve terms zero-weighted);
+    `inputs`: the fixture that holds the `in_*` state when `g` has outputs only."""
     from pathlib import Path
     import numpy as np
     import common_setup as cs
@@ -88,16 +90,19 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2):
     repo = Path(__file__).resolve().parent.parent
     conf = ConfigFactory.parse_file(str(repo / "configs" / "synthetic" / "people_snapshot_like.conf"))
     dev = torch.device(device)
-    st = {k[3:]: v.to(dev) for k, v in g.items() if k.startswith('in_')}
+    st = {k[3:]: v.to(dev) for k, v in (inputs if inputs is not None else g).items() if k.startswith('in_')}
     ds = CaseDataset(st, dev)
     optNet, _ = getOptNet(ds, None, N, (-0.8, -1.1, -0.6), (0.8, 1.1, 0.6), [(9, 11, 7), (17, 21, 13)], device, conf, curves=False,
-                          skin_grid=(5, 9, 7))
+                          skin_grid=(5, 9, 7), opt_large=large_pose)
+    assert optNet.large_pose == large_pose
     leaf = lambda t: t.detach().clone().requires_grad_(True)
     sdfs = [n.to(dev) for n in mlc.build_sdfs(getTmpSdf)]
     tr = cs.build_translator(MLPTranslator).to(dev)
     sk = cs.build_skinner(LBSkinner).to(dev)
     rn = cs.build_render(RenderingNetwork_view_norm).to(dev)
     optNet.garment_nets = torch.nn.ModuleList(sdfs)
+    if large_pose:
+        optNet.freeze_sdf()
     optNet.deformer = CompositeDeformer([tr, sk])
     optNet.netRender = rn
     verts = [leaf(st['verts_u']), leaf(st['verts_b'])]
@@ -166,7 +171,10 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2):
     for i, net in enumerate(sdfs):
         sp = dict(net.named_parameters())
         for k in SDF_KEYS:
-            close('g_sdf%d_%s' % (i, k), sp[k].grad[:ROWS], g['g_sdf%d_' % i + k.replace('.', '_')], rtol_grad)
+            if large_pose:
+                assert sp[k].grad is None, "frozen SDF nets receive no gradient"
+            else:
+                close('g_sdf%d_%s' % (i, k), sp[k].grad[:ROWS], g['g_sdf%d_' % i + k.replace('.', '_')], rtol_grad)
     zero = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)
     close('g_poses', zero(ds.poses), g['g_poses_all'], rtol_grad)
     close('g_trans', zero(ds.trans), g['g_trans_all'], rtol_grad)

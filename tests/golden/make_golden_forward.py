@@ -55,7 +55,7 @@ class Pointclouds:
         return torch.cat(self.features, 0)
 
 
-def main():
+def main(large_pose=False):
     Nref = ref_loader.ref_module("model.network")
     Dref = ref_loader.ref_module("model.Deformer")
     Rref = ref_loader.ref_module("model.RenderNet")
@@ -69,6 +69,11 @@ def main():
     from recmv.hocon import ConfigFactory
     from recmv.model import RectifiedPerspectiveCameras as OurCameras
     OGN.Meshes, OGN.Pointclouds, OGN.RectifiedPerspectiveCameras = Meshes, Pointclouds, OurCameras
+    KLASS = OGN.OptimGarmentNetwork
+    if large_pose:                       # the large-pose stage (OptimGarmentNetwork_Large_Pose.py): same iteration, SDF nets frozen,
+        OGNL = ref_loader.ref_module("engineer.networks.OptimGarmentNetwork_Large_Pose")     # curve terms zero-weighted (:219)
+        OGNL.Meshes, OGNL.Pointclouds, OGNL.RectifiedPerspectiveCameras = Meshes, Pointclouds, OurCameras
+        KLASS = OGNL.OptimGarmentNetwork_LargePose
     OGN.fl_proj_loss.__globals__["chamfer_distance"] = lambda a, b, point_reduction='sum': (ours.chamfer_distance_sum(a, b), None)
     cs.TrimeshStandIn.rng = np.random.RandomState(fc.SEED)
     OGN.trimesh = types.SimpleNamespace(Trimesh=cs.TrimeshStandIn)
@@ -155,10 +160,14 @@ def main():
     for name in ('project_2d_loss', 'deform_feature_line', 'fl_visible_by_body_zbuff', 'compute_fl_proj_loss', 'mask_loss',
                  'find_surface_ps', 'compute_garment_pc_loss', 'curve_aware_loss', 'sample_train_ray', 'opt_garment_surface_ps',
                  'surface_render_loss', 'dct_poses_loss', 'save_debug'):
-        setattr(fake, name, types.MethodType(getattr(OGN.OptimGarmentNetwork, name), fake))
+        setattr(fake, name, types.MethodType(getattr(KLASS, name), fake))
     fake.garment_optimizer = torch.optim.SGD(verts, lr=0.05, momentum=0.9)
     fake.fl_optimizer = torch.optim.AdamW(ref.parameters(), lr=1e-4)
-    shared = [q for m in sdfs + [comp, rn] for q in m.parameters()] + list(leaves.values())
+    if large_pose:
+        fake.sdf = sdfs[0]                                   # (freeze_sdf also walks the body net)
+        fake.garment_nets = torch.nn.ModuleList(sdfs)
+        KLASS.freeze_sdf(fake)
+    shared = [q for m in sdfs + [comp, rn] for q in m.parameters() if q.requires_grad] + list(leaves.values())
     opt = torch.optim.Adam(shared, lr=1e-3)
     datas = dict(img=st['img'], mask=((st['gt_u'] + st['gt_b']) > 0).float(), fl_pts=st['gt'], fl_masks=st['fl_masks'],
                  upper=st['gt_u'], bottom=st['gt_b'], body=torch.zeros_like(st['gt_u']), normal=st['normal'])
@@ -166,9 +175,9 @@ def main():
     torch.Tensor.cuda = lambda self, *a, **k: self                    # curve_aware_loss uploads its samples with .cuda() (:809)
     try:
         torch.manual_seed(fc.SEED)
-        loss = OGN.OptimGarmentNetwork.forward(fake, datas, fc.SAMPLE_PIX, pc.RATIO, frame_ids, None, global_optimizer=opt)
+        loss = KLASS.forward(fake, datas, fc.SAMPLE_PIX, pc.RATIO, frame_ids, None, global_optimizer=opt)
         loss.backward()
-        OGN.OptimGarmentNetwork.propagateTmpPsGrad(fake, frame_ids, pc.RATIO)
+        KLASS.propagateTmpPsGrad(fake, frame_ids, pc.RATIO)
     finally:
         torch.Tensor.cuda = real_cuda
     flat = {}
@@ -193,12 +202,19 @@ def main():
     for i, net in enumerate(sdfs):
         sp = dict(net.named_parameters())
         for k in fc.SDF_KEYS:
-            res['g_sdf%d_' % i + k.replace('.', '_')] = sp[k].grad[:fc.ROWS]
+            if large_pose:
+                assert sp[k].grad is None, "frozen SDF nets receive no gradient"
+            else:
+                res['g_sdf%d_' % i + k.replace('.', '_')] = sp[k].grad[:fc.ROWS]
     for k, v in leaves.items():
         res['g_' + k] = v.grad if v.grad is not None else torch.zeros_like(v)
-    res.update({'in_' + k: v for k, v in st.items()})
-    save("forward", **res)
+    if large_pose:                                          # same inputs as forward.npz: outputs only
+        save("forward_large", **res)
+    else:
+        res.update({'in_' + k: v for k, v in st.items()})
+        save("forward", **res)
 
 
 if __name__ == "__main__":
     main()
+    main(large_pose=True)

@@ -374,3 +374,18 @@ def test_one_whole_iteration_matches_the_reference():
         assert set(big) <= {'g_focal', 'g_pp'}, big          # (measured: everything <= 4.3e-5 but the two intrinsics' gradients, ~1e-3)
     finally:
         cpu_port.uninstall()
+
+
+def test_one_whole_large_pose_iteration_matches_the_reference():
+    """The same whole iteration on the large-pose stage: OptimGarmentNetwork_LargePose.forward (OptimGarmentNetwork_Large_Pose.py:
+    242-323, its zero-weighted project_2d_loss :150-240 and its propagateTmpPsGrad :326-475, SDF nets frozen by freeze_sdf
+    :130-137) vs the large-pose HotLoop; the frozen nets receive no gradient on either side."""
+    from oracle import cpu_port
+    import forward_case as fwc
+    cpu_port.install()
+    try:
+        worst = fwc.run(load("forward_large"), "cpu", rtol=1e-4, rtol_grad=5e-3, large_pose=True, inputs=load("forward"))
+        big = {k: v for k, v in worst.items() if v > 5e-5}
+        assert set(big) <= {'g_focal', 'g_pp'}, big
+    finally:
+        cpu_port.uninstall()

@@ -51,3 +51,31 @@ def test_mask_loss_on_gpu_matches_the_reference_method():
     import mask_loss_case as mlc
     worst = mlc.run(cc.load("mask_loss"), DEV, rtol=1e-3, rtol_grad=1e-2)
     print("mask_loss on the GPU, largest relative deviations:", {k: "%.1e" % v for k, v in worst.items() if v > 1e-6})
+
+
+# The whole-method drivers added after this round's GPU budget was spent (CPU-port parity: tests/test_golden_cpu.py).  They have
+# not met the device yet, so the driver's run skips them; RECMV_UNVALIDATED_GPU_TESTS=1 runs them (next round's first step).
+import os  # noqa: E402
+
+unvalidated = pytest.mark.skipif(os.environ.get("RECMV_UNVALIDATED_GPU_TESTS") != "1",
+                                 reason="not yet run on an MI355X (set RECMV_UNVALIDATED_GPU_TESTS=1)")
+
+
+@unvalidated
+def test_project_2d_loss_on_gpu_matches_the_reference_method():
+    import project2d_case as p2c
+    print(p2c.run(cc.load("project2d"), DEV, rtol=1e-3, rtol_grad=1e-2))
+
+
+@unvalidated
+def test_one_whole_iteration_on_gpu_matches_the_reference():
+    import forward_case as fwc
+    with cc.host_draws():
+        print(fwc.run(cc.load("forward"), DEV, rtol=1e-3, rtol_grad=2e-2))
+
+
+@unvalidated
+def test_one_whole_large_pose_iteration_on_gpu_matches_the_reference():
+    import forward_case as fwc
+    with cc.host_draws():
+        print(fwc.run(cc.load("forward_large"), DEV, rtol=1e-3, rtol_grad=2e-2, large_pose=True, inputs=cc.load("forward")))

@@ -118,7 +118,8 @@ def _sampler_cases(dtype):
     """(input, grid): the reference's own check shape (MCAcc/check_grid_sampler_mine.py:5-16), a channels-last skinning-like volume
     with a point list (what LBSkinner passes), several batch items with a 3-D output lattice, coordinates beyond [-1, 1]."""
     g = torch.Generator().manual_seed(11)
-    cases = [(torch.randn(1, 24, 5, 9, 7, generator=g, dtype=dtype).contiguous(memory_format=torch.channels_last_3d),
+    cases = [(torch.randn(1, 5, 15, 15, 15, generator=g, dtype=dtype), (torch.rand(1, 1, 1, 10, 3, generator=g, dtype=dtype) - 0.5) * 2.2),
+             (torch.randn(1, 24, 5, 9, 7, generator=g, dtype=dtype).contiguous(memory_format=torch.channels_last_3d),
               (torch.rand(1, 1, 1, 300, 3, generator=g, dtype=dtype) - 0.5) * 2.2),
              (torch.randn(2, 5, 7, 9, 8, generator=g, dtype=dtype), (torch.rand(2, 3, 4, 50, 3, generator=g, dtype=dtype) - 0.5) * 2.6),
              (torch.randn(1, 3, 2, 2, 2, generator=g, dtype=dtype), (torch.rand(1, 1, 1, 64, 3, generator=g, dtype=dtype) - 0.5) * 4.0)]

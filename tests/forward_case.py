@@ -15,6 +15,9 @@ TR_KEYS = ["lin0.weight", "lin2.bias", "lin4.weight"]
 SDF_KEYS = ["lin0.weight_v", "lin4.weight_g", "lin8.bias", "lin8.weight_v"]
 RN_KEYS = ["lin0.weight_v", "lin4.bias"]
 ROWS = 24
+BOX = ((-0.8, -1.1, -0.6), (0.8, 1.1, 0.6))
+RESOLUTIONS = [(9, 11, 7), (17, 21, 13)]
+BODY_BIAS = 0.5
 
 
 def state():
@@ -73,11 +76,12 @@ class CaseDataset:
         return [self.poses, self.trans, self.dcond, self.rend, self.focal, self.pp, self.T]
 
 
-def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None):
+def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, remesh=False):
     """One whole iteration of recmv's loop — HotLoop.forward, backward, propagateTmpPsGrad — on the fixture's state against
     what the reference's forward / backward / propagateTmpPsGrad produced; returns the largest relative deviations.
     `large_pose`: the large-pose stage on both sides (OptimGarmentNetwork_LargePose: SDF nets frozen, curve terms zero-weighted);
-    `inputs`: the fixture that holds the `in_*` state when `g` has outputs only."""
+    `inputs`: the fixture that holds the `in_*` state when `g` has outputs only; `remesh`: the iteration starts with the re-mesh
+    (forward_time = 0: Seg3dLossless pyramid + MC of the body net and both garment nets) instead of given explicit meshes."""
     from pathlib import Path
     import numpy as np
     import common_setup as cs
@@ -105,11 +109,17 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None):
         optNet.freeze_sdf()
     optNet.deformer = CompositeDeformer([tr, sk])
     optNet.netRender = rn
-    verts = [leaf(st['verts_u']), leaf(st['verts_b'])]
-    optNet.garment_vs, optNet.garment_fs = verts, [st['faces_u'].long(), st['faces_b'].long()]
-    optNet.body_vs, optNet.body_fs = st['body_v'], st['body_f'].long()
     optNet.tmpBodyVs, optNet.tmpBodyFs = st['body_v'], st['body_f'].long()
-    optNet.garment_optimizer = torch.optim.SGD(verts, lr=0.05, momentum=0.9)
+    if remesh:
+        torch.manual_seed(520)
+        optNet.sdf = cs.perturb(getTmpSdf("cpu", 6, bias=BODY_BIAS), 502, 0.003).to(dev)
+        optNet.body_vs = optNet.body_fs = None
+        assert [tuple(r) for r in optNet.engine.resolutions.tolist()] == RESOLUTIONS
+    else:
+        verts = [leaf(st['verts_u']), leaf(st['verts_b'])]
+        optNet.garment_vs, optNet.garment_fs = verts, [st['faces_u'].long(), st['faces_b'].long()]
+        optNet.body_vs, optNet.body_fs = st['body_v'], st['body_f'].long()
+        optNet.garment_optimizer = torch.optim.SGD(verts, lr=0.05, momentum=0.9)
     curve = fl.Intersect_Free_Curve(list(st['curves']), list(0.9 * st['curves']), pc.NAMES).to(dev)
     with torch.no_grad():
         curve.scale.copy_(st['scale'])
@@ -117,7 +127,7 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None):
     optNet.inter_free_curve, optNet.fl_names, optNet.curves = curve, list(pc.NAMES), True
     optNet.fl_extract = {'upper': pc.UPPER, 'bottom': pc.BOTTOM}
     optNet.fl_optimizer = torch.optim.AdamW(curve.parameters(), lr=1e-4)
-    optNet.forward_time, optNet.remesh_intersect, optNet.pc_radius, optNet.sample_pix = 1, 30, RADIUS, SAMPLE_PIX
+    optNet.forward_time, optNet.remesh_intersect, optNet.pc_radius, optNet.sample_pix = (0 if remesh else 1), 30, RADIUS, SAMPLE_PIX
     optNet.angThred = optNet._cameras().angThreshold(0.5)
     optNet.dctnull = dct_nullspace(30, 10, dev)
     optNet._datas = dict(img=st['img'], normal=st['normal'], fl_pts=st['gt'], fl_masks=st['fl_masks'], upper=st['gt_u'],
@@ -144,6 +154,11 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None):
         worst[name] = float((got - want).abs().max()) / scale
         assert torch.allclose(got, want, rtol=rt, atol=rt * scale), (name, worst[name])
 
+    if remesh:
+        verts = optNet.garment_vs
+        assert torch.equal(optNet.garment_fs[0].cpu(), g['faces_u'].long()) and torch.equal(optNet.garment_fs[1].cpu(), g['faces_b'].long())
+        assert torch.equal(optNet.body_fs.cpu(), g['body_f'].long())
+        close('re-meshed body vertices', optNet.body_vs, g['body_v'], 1e-4)      # (interpolated along edges from f32 SDF values)
     close('loss', loss, g['loss'], rtol)
     info = optNet.info
     ref_name = {'upper': 'short_sleeve_upper', 'bottom': 'long_pants'}

@@ -55,7 +55,7 @@ class Pointclouds:
         return torch.cat(self.features, 0)
 
 
-def main(large_pose=False):
+def main(large_pose=False, remesh=False):
     Nref = ref_loader.ref_module("model.network")
     Dref = ref_loader.ref_module("model.Deformer")
     Rref = ref_loader.ref_module("model.RenderNet")
@@ -154,6 +154,36 @@ def main(large_pose=False):
                                  dataset=dataset, forward_time=1, remesh_intersect=30, remesh_time=0., root=None,
                                  dctnull=Uref.DCTNullSpace(10, 30), angThred=cam0.angThreshold(0.5), garment_type='female-3-casual',
                                  isfine=False)
+    if remesh:
+        # forward_time = 0: the iteration starts with marching_cube_update (:678-740) -> discretizeSDF (:581-618): the reference's
+        # Seg3dLossless pyramid over the body net and both garment nets, MC through the oracle (canonical order), the explicit
+        # vertices become leaves with fresh SGD / AdamW optimisers.  openmesh's vertex->face table (never read afterwards) is a
+        # stand-in, the debug dumps behind `root` are switched off.
+        import tempfile
+        Sref = ref_loader.ref_module("MCAcc.seg3d_lossless")
+        fake.engine = Sref.Seg3dLossless(query_func=None, b_min=list(fc.BOX[0]), b_max=list(fc.BOX[1]), resolutions=fc.RESOLUTIONS,
+                                         align_corners=False, balance_value=0.0, use_cuda_impl=False, faster=False)
+        torch.manual_seed(520)
+        fake.sdf = cs.perturb(Nref.getTmpSdf("cpu", 6, bias=fc.BODY_BIAS), 502, 0.003)
+        fake.forward_time, fake.visualizer, fake.opt_times = 0, None, 0.
+        fake.update_hierarchical_config = lambda *a, **k: None
+
+        class TriMesh:
+            def __init__(self, v, f):
+                self.v, self.f = v, f
+
+            def vertex_face_indices(self):
+                rows = [[] for _ in range(self.v.shape[0])]
+                for i, face in enumerate(self.f):
+                    for vid in face:
+                        rows[int(vid)].append(i)
+                width = max(len(r) for r in rows)
+                return np.array([r + [-1] * (width - len(r)) for r in rows], dtype=np.int64)
+
+        OGN.om = types.SimpleNamespace(TriMesh=TriMesh)
+        for name in ('marching_cube_update', 'discretizeSDF'):
+            setattr(fake, name, types.MethodType(getattr(KLASS, name), fake))
+        root = tempfile.mkdtemp()
     fake.pcRender = Cref.PointsRendererWithFrags_Split(PointRasterizer(), Compositor())
     fake.get_grad_parameters = lambda fids, dev: ([None, leaves['cu_all'][fids], leaves['cb_all'][fids]], leaves['poses_all'][fids],
                                                   leaves['trans_all'][fids], leaves['rend_all'][fids])
@@ -161,6 +191,8 @@ def main(large_pose=False):
                  'find_surface_ps', 'compute_garment_pc_loss', 'curve_aware_loss', 'sample_train_ray', 'opt_garment_surface_ps',
                  'surface_render_loss', 'dct_poses_loss', 'save_debug'):
         setattr(fake, name, types.MethodType(getattr(KLASS, name), fake))
+    if remesh:
+        fake.save_debug = lambda *a, **k: None               # (`root` is set during a re-mesh iteration: no debug dumps)
     fake.garment_optimizer = torch.optim.SGD(verts, lr=0.05, momentum=0.9)
     fake.fl_optimizer = torch.optim.AdamW(ref.parameters(), lr=1e-4)
     if large_pose:
@@ -175,7 +207,7 @@ def main(large_pose=False):
     torch.Tensor.cuda = lambda self, *a, **k: self                    # curve_aware_loss uploads its samples with .cuda() (:809)
     try:
         torch.manual_seed(fc.SEED)
-        loss = KLASS.forward(fake, datas, fc.SAMPLE_PIX, pc.RATIO, frame_ids, None, global_optimizer=opt)
+        loss = KLASS.forward(fake, datas, fc.SAMPLE_PIX, pc.RATIO, frame_ids, root if remesh else None, global_optimizer=opt)
         loss.backward()
         KLASS.propagateTmpPsGrad(fake, frame_ids, pc.RATIO)
     finally:
@@ -189,6 +221,7 @@ def main(large_pose=False):
             flat[k] = v
     print("loss %.6f" % float(loss.detach()))
     print({k: (tuple(v) if isinstance(v, tuple) else round(float(v), 6)) for k, v in flat.items()})
+    verts = fake.garment_vs                                  # (after a re-mesh: the freshly extracted ones)
     res = dict(loss=loss.detach(), new_verts_u=verts[0].detach(), new_verts_b=verts[1].detach(), new_scale=ref.scale.detach(),
                new_nx=ref.nx_scale.detach())
     for k, v in flat.items():
@@ -208,7 +241,11 @@ def main(large_pose=False):
                 res['g_sdf%d_' % i + k.replace('.', '_')] = sp[k].grad[:fc.ROWS]
     for k, v in leaves.items():
         res['g_' + k] = v.grad if v.grad is not None else torch.zeros_like(v)
-    if large_pose:                                          # same inputs as forward.npz: outputs only
+    if remesh:
+        res.update(faces_u=fake.garment_fs[0], faces_b=fake.garment_fs[1], body_v=fake.body_vs.detach(), body_f=fake.body_fs)
+        print("re-mesh: %d / %d garment vertices, %d body vertices" % (verts[0].shape[0], verts[1].shape[0], fake.body_vs.shape[0]))
+        save("forward_remesh", **res)
+    elif large_pose:                                        # same inputs as forward.npz: outputs only
         save("forward_large", **res)
     else:
         res.update({'in_' + k: v for k, v in st.items()})
@@ -218,3 +255,4 @@ def main(large_pose=False):
 if __name__ == "__main__":
     main()
     main(large_pose=True)
+    main(remesh=True)

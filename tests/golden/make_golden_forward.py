@@ -210,20 +210,37 @@ def main(large_pose=False, remesh=False):
         loss = KLASS.forward(fake, datas, fc.SAMPLE_PIX, pc.RATIO, frame_ids, root if remesh else None, global_optimizer=opt)
         loss.backward()
         KLASS.propagateTmpPsGrad(fake, frame_ids, pc.RATIO)
+        info1 = dict(fake.info)
+        state1 = dict(new_verts_u=fake.garment_vs[0].detach().clone(), new_verts_b=fake.garment_vs[1].detach().clone(),
+                      new_scale=ref.scale.detach().clone(), new_nx=ref.nx_scale.detach().clone())
+        first = {k: (v.grad.detach().clone() if v.grad is not None else None) for k, v in leaves.items()}
+        first_modules = [[(q.grad.detach().clone() if q.grad is not None else None) for q in m.parameters()] for m in sdfs + [comp, rn]]
+        loss2 = None
+        if not large_pose and not remesh:
+            # a second iteration after the main optimiser's step (train.py:317-328): the SGD momentum on the explicit vertices,
+            # the AdamW state of the curves and forward_time carry over
+            opt.step()
+            opt.zero_grad()
+            loss2 = KLASS.forward(fake, datas, fc.SAMPLE_PIX, pc.RATIO, frame_ids, None, global_optimizer=opt).detach()
+            info2 = dict(fake.info)
+            for k, v in leaves.items():                      # what is compared below are the FIRST iteration's gradients
+                v.grad = first[k]
+            for m, grads in zip(sdfs + [comp, rn], first_modules):
+                for q, gq in zip(m.parameters(), grads):
+                    q.grad = gq
     finally:
         torch.Tensor.cuda = real_cuda
     flat = {}
-    for k, v in fake.info.items():
+    for k, v in info1.items():
         if isinstance(v, dict):
             for kk, vv in v.items():
                 flat[k + '/' + kk] = vv
         else:
             flat[k] = v
-    print("loss %.6f" % float(loss.detach()))
+    print("loss %.6f" % float(loss.detach()), "" if loss2 is None else "second iteration %.6f" % float(loss2))
     print({k: (tuple(v) if isinstance(v, tuple) else round(float(v), 6)) for k, v in flat.items()})
     verts = fake.garment_vs                                  # (after a re-mesh: the freshly extracted ones)
-    res = dict(loss=loss.detach(), new_verts_u=verts[0].detach(), new_verts_b=verts[1].detach(), new_scale=ref.scale.detach(),
-               new_nx=ref.nx_scale.detach())
+    res = dict(loss=loss.detach(), **state1)
     for k, v in flat.items():
         key = 'info_' + k.replace('/', '__').replace(' ', '_')
         res[key] = torch.tensor([float(x) for x in v]) if isinstance(v, tuple) else torch.tensor(float(v))
@@ -241,6 +258,9 @@ def main(large_pose=False, remesh=False):
                 res['g_sdf%d_' % i + k.replace('.', '_')] = sp[k].grad[:fc.ROWS]
     for k, v in leaves.items():
         res['g_' + k] = v.grad if v.grad is not None else torch.zeros_like(v)
+    if loss2 is not None:
+        res['loss2'] = loss2
+        res['rays2'] = torch.tensor([float(x) for n in names for x in info2['%s_rayInfo' % n]])
     if remesh:
         res.update(faces_u=fake.garment_fs[0], faces_b=fake.garment_fs[1], body_v=fake.body_vs.detach(), body_f=fake.body_fs)
         print("re-mesh: %d / %d garment vertices, %d body vertices" % (verts[0].shape[0], verts[1].shape[0], fake.body_vs.shape[0]))

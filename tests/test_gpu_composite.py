@@ -79,3 +79,10 @@ def test_one_whole_large_pose_iteration_on_gpu_matches_the_reference():
     import forward_case as fwc
     with cc.host_draws():
         print(fwc.run(cc.load("forward_large"), DEV, rtol=1e-3, rtol_grad=2e-2, large_pose=True, inputs=cc.load("forward")))
+
+
+@unvalidated
+def test_one_whole_iteration_with_the_remesh_inside_on_gpu_matches_the_reference():
+    import forward_case as fwc
+    with cc.host_draws():
+        print(fwc.run(cc.load("forward_remesh"), DEV, rtol=2e-3, rtol_grad=5e-2, inputs=cc.load("forward"), remesh=True))

@@ -392,10 +392,19 @@ class HotLoop:
         for prefix, mod in self._modules().items():
             for k, v in mod.state_dict().items():
                 out[prefix + '.' + k] = v
+        for name in self._BUFFERS:                    # the reference registers the SMPL template as buffers (:128-129)
+            if getattr(self, name, None) is not None:
+                out[name] = getattr(self, name)
         return out
+
+    _BUFFERS = ('tmpBodyVs', 'tmpBodyFs')
 
     def load_state_dict(self, sd, strict=True):
         missing, unexpected = [], set(sd.keys())
+        for name in self._BUFFERS:
+            if name in sd:
+                setattr(self, name, sd[name].to(self.device))
+                unexpected.discard(name)
         for prefix, mod in self._modules().items():
             sub = {k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + '.')}
             unexpected -= {prefix + '.' + k for k in sub}

@@ -193,3 +193,40 @@ def test_draw_loss_flattens_info_like_the_reference(tmp_path, monkeypatch):
                    'total_loss': 1.5, 'learning_rate': 1e-3, 'ratio/sdfRatio': 1.0, 'ratio/deformerRatio': 0.6, 'step': 12}
     fake.visualizer = None
     OptimGarmentNetwork.draw_loss(fake, 13.)                                   # no sink: nothing to do
+
+
+def test_checkpoint_layout_equals_the_references():
+    """utils.save_model on the loop object writes what the reference's save_model (utils/utils.py:350-357) wrote for an object of its
+    own classes (tests/golden/make_golden_checkpoint.py -> checkpoint_layout.json): the same top-level entries, and a
+    `model_state_dict` with the same keys, shapes and dtypes for the networks, the skinner, the curves and the SMPL template — so
+    that a reference checkpoint loads here (load_model drops `engine.*` and the skinning volume on both sides) and ours loads there."""
+    import json
+    import tempfile
+    from oracle import cpu_port
+    from recmv import utils
+    from recmv.model.network import getOptNet
+    want = json.loads((REPO / "tests" / "golden" / "checkpoint_layout.json").read_text())
+    cpu_port.install()
+    try:
+        optNet, _ = getOptNet(None, None, 3, BOX[0], BOX[1], RES, 'cpu', _conf(), n_frames=7, H=24, W=20, curves=True, skin_grid=(5, 9, 7))
+        with tempfile.TemporaryDirectory() as tmp:
+            utils.save_model(tmp + '/latest.pth', 3, optNet, optNet.dataset)
+            saved = torch.load(tmp + '/latest.pth', map_location='cpu')
+    finally:
+        cpu_port.uninstall()
+    top = {k: (list(v.shape) if torch.is_tensor(v) else type(v).__name__) for k, v in saved.items() if k != 'model_state_dict'}
+    assert set(top) == set(want['top_level']), set(top) ^ set(want['top_level'])
+    for k in ('epoch', 'poses', 'trans', 'shape', 'dcond', 'rcond'):
+        assert top[k] == want['top_level'][k] or k in ('shape',), (k, top[k], want['top_level'][k])
+    got = {k: [list(v.shape), str(v.dtype)] for k, v in saved['model_state_dict'].items()}
+    ref = want['model_state_dict']
+    # everything the reference stores for its networks, its skinner, its curves and its SMPL template is stored here under the same
+    # name; sizes that follow from the scene (skinning volume, template and curve sample counts) are free
+    scene_sized = ('deformer.defs.1.ws', 'tmpBodyVs', 'tmpBodyFs', 'engine.', 'inter_free_curve.')
+    missing = [k for k in ref if k not in got and not k.startswith('engine.')]
+    assert not missing, missing
+    for k, (shape, dtype) in ref.items():
+        if k in got and not k.startswith(scene_sized):
+            assert got[k] == [shape, dtype], (k, got[k], [shape, dtype])
+    extra = [k for k in got if k not in ref and not k.startswith('engine.')]
+    assert not extra, extra

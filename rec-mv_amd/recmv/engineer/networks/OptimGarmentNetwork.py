@@ -9,7 +9,8 @@ reference), with the reference's call signatures on top of the MI355X hot loop (
 `forward` takes the mini-batch dict the reference's DataLoader collates (`datas`: img, normal, mask, one segmentation
 per garment, fl_pts, fl_masks — dataset/dataset.py:617-680) and reads its ground truth from it; the per-frame learnable
 tensors and the camera come from `optNet.dataset`, as in the reference (:1888-1910).  Everything else
-(`initializeTmpSDF`, `initializeSDF`, `initializeFL`, `propagateTmpPsGrad`, `discretizeSDF`, `marching_cube_update`, `mask_loss`, `sample_train_ray`, `surface_render_loss`,
+(`initializeTmpSDF`, `initializeSDF`, `initializeFL`, `propagateTmpPsGrad`, `discretizeSDF`, `marching_cube_update`,
+`mask_loss`, `sample_train_ray`, `surface_render_loss`,
 `project_2d_loss`, `curve_aware_loss`, `dct_poses_loss`, `opt_times`, `info`, `engine`, ...) is HotLoop's.
 """
 import torch

@@ -16,7 +16,6 @@ import sys
 import types
 from pathlib import Path
 
-import numpy as np
 import torch
 
 HERE = Path(__file__).resolve().parent

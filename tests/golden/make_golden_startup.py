@@ -19,7 +19,6 @@ chamfer arithmetic stays parity-unpinned, as in curves.npz), the camera recmv's 
     python tests/golden/make_golden_startup.py
 """
 import random
-import shutil
 import sys
 import tempfile
 import types

@@ -76,12 +76,16 @@ class CaseDataset:
         return [self.poses, self.trans, self.dcond, self.rend, self.focal, self.pp, self.T]
 
 
-def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, remesh=False):
+def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, remesh=False, rtol_loss=None, rtol_cam=None):
     """One whole iteration of recmv's loop — HotLoop.forward, backward, propagateTmpPsGrad — on the fixture's state against
     what the reference's forward / backward / propagateTmpPsGrad produced; returns the largest relative deviations.
     `large_pose`: the large-pose stage on both sides (OptimGarmentNetwork_LargePose: SDF nets frozen, curve terms zero-weighted);
     `inputs`: the fixture that holds the `in_*` state when `g` has outputs only; `remesh`: the iteration starts with the re-mesh
-    (forward_time = 0: Seg3dLossless pyramid + MC of the body net and both garment nets) instead of given explicit meshes."""
+    (forward_time = 0: Seg3dLossless pyramid + MC of the body net and both garment nets) instead of given explicit meshes.
+    Tolerances (relative to the largest reference entry of each tensor): `rtol_loss` for the total loss (default `rtol`), `rtol`
+    for the per-term info values and the stepped vertices, `rtol_grad` for the gradients the main optimiser consumes, `rtol_cam`
+    (default `rtol_grad`) for the two camera-intrinsic gradients — sums of thousands of signed per-ray terms that cancel to a
+    few per cent of their magnitude."""
     from pathlib import Path
     import numpy as np
     import common_setup as cs
@@ -159,7 +163,7 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
         assert torch.equal(optNet.garment_fs[0].cpu(), g['faces_u'].long()) and torch.equal(optNet.garment_fs[1].cpu(), g['faces_b'].long())
         assert torch.equal(optNet.body_fs.cpu(), g['body_f'].long())
         close('re-meshed body vertices', optNet.body_vs, g['body_v'], 1e-4)      # (interpolated along edges from f32 SDF values)
-    close('loss', loss, g['loss'], rtol)
+    close('loss', loss, g['loss'], rtol if rtol_loss is None else rtol_loss)
     info = optNet.info
     ref_name = {'upper': 'short_sleeve_upper', 'bottom': 'long_pants'}
     for mine, theirs in ref_name.items():
@@ -196,8 +200,8 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
     close('g_cond_upper', zero(ds.dcond)[:, 128:256], g['g_cu_all'], rtol_grad)
     close('g_cond_bottom', zero(ds.dcond)[:, 256:], g['g_cb_all'], rtol_grad)
     close('g_rendcond', zero(ds.rend), g['g_rend_all'], rtol_grad)
-    close('g_focal', zero(ds.focal), g['g_focal'], rtol_grad)
-    close('g_pp', zero(ds.pp), g['g_pp'], rtol_grad)
+    close('g_focal', zero(ds.focal), g['g_focal'], rtol_grad if rtol_cam is None else rtol_cam)
+    close('g_pp', zero(ds.pp), g['g_pp'], rtol_grad if rtol_cam is None else rtol_cam)
     close('g_T', zero(ds.T), g['g_T'], rtol_grad)
     if 'loss2' in g:
         # a second iteration after the main optimiser's step: SGD momentum of the explicit vertices, AdamW state of the curves and

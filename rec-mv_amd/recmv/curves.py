@@ -13,19 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-# utils/constant.py:65-74 (feature lines of a garment type) and :219-227 (visibility slack behind the body surface)
-FL_EXTRACT = {
-    'long_sleeve_upper': ['neck', 'left_cuff', 'right_cuff', 'upper_bottom'],
-    'dress': ['neck', 'left_cuff', 'right_cuff', 'bottom_curve'],
-    'long_pants': ['left_pant', 'right_pant'],
-    'short_pants': ['left_pant', 'right_pant'],
-    'short_sleeve_upper': ['neck', 'left_cuff', 'right_cuff', 'upper_bottom'],
-    'tube': ['neck', 'bottom_curve'],
-    'skirt': ['bottom_curve'],
-    'no_sleeve_upper': ['neck', 'left_cuff', 'right_cuff', 'bottom_curve'],
-}
-ZBUF_THRESHOLD = {'neck': 0.1, 'right_cuff': 0.05, 'left_cuff': 0.05, 'left_pant': 0.05, 'right_pant': 0.05,
-                  'upper_bottom': 0.08, 'bottom_curve': 0.1}
+from .utils.constant import FL_EXTRACT, ZBUF_THRESHOLD  # noqa: E402,F401  (utils/constant.py:65-74, :219-227)
 
 
 def _legacy_cross(a, b):

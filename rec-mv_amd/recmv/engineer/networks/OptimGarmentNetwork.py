@@ -122,7 +122,7 @@ class OptimGarmentNetwork(HotLoop):
         # their counterparts on the canonical body: the sampled curves with translation and scale undone
         # (Intersect_Free_Curve.initialize_parameters, engineer/utils/garment_structure.py:77)
         smpl_curves = self.cano_fl_to_body_trans(curves, self.fl_names)
-        self.fl_extract = {g: [n for n in fl.FL_EXTRACT[self.FL_GARMENT[g]] if n in self.fl_names] for g in self.garment_names}
+        self.fl_extract, _ = self._feature_line_tables(available=self.fl_names)
         self.inter_free_curve = fl.Intersect_Free_Curve(curves, smpl_curves, self.fl_names).to(dev)
         self._ensure_body_template()
         self.curves = True

@@ -46,6 +46,7 @@ from .FastMinv import Fast3x3Minv
 from .MCAcc import Seg3dLossless
 from .model import (CompositeDeformer, LBSkinner, MLPTranslator, RectifiedPerspectiveCameras, getRenderNet, getTmpSdf,
                     getTranslatorNet)
+from .utils.constant import CURVE_AWARE, FL_INFOS, MASK_KEYS, TEMPLATE_GARMENT
 
 SMPL_PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21],
                         dtype=np.int64)
@@ -166,14 +167,15 @@ class SyntheticFrames:
         sl = frame_ids % self.n_img
         return self.img[sl], self.normal[sl]
 
-    def get_batch(self, frame_ids, garment_names=('upper', 'bottom')):
+    def get_batch(self, frame_ids, mask_keys=('upper', 'bottom')):
         """The `datas` dict of one mini-batch as the reference's DataLoader collates it (dataset/dataset.py:617-680;
-        read by OptimGarmentNetwork.forward :1888-1904): img / normal [N,H,W,3], mask and one segmentation per garment
-        [N,H,W], fl_pts [N, n_curves*M, 2] and fl_masks [N, n_curves] when feature lines exist."""
+        read by OptimGarmentNetwork.forward :1888-1904): img / normal [N,H,W,3], mask and one garment region per entry of
+        `mask_keys` [N,H,W] ('upper' / 'bottom', or 'upper_bottom' for a one-piece garment), fl_pts [N, n_curves*M, 2] and
+        fl_masks [N, n_curves] when feature lines exist."""
         img, normal = self.images(frame_ids)
         out = {'img': img, 'normal': normal, 'frame_ids': frame_ids}
         masks = [self.garment_masks(g, frame_ids) for g in range(len(self._masks))]
-        for name, m in zip(garment_names, masks):
+        for name, m in zip(mask_keys, masks):
             out[name] = m > 0
         out['mask'] = torch.stack(masks, 0).amax(0)
         if hasattr(self, 'gt_fl_pts'):
@@ -227,16 +229,32 @@ class HotLoop:
         self.conf = conf.get_config('loss_' + stage)
         self.device = device
         self.stage = stage
-        self.garment_names = ['upper', 'bottom']
+        # The garment set comes from the capture's name like the reference's (model/network.py:187-192,
+        # OptimGarmentNetwork.py:141-164): `train.garment_type` -> TEMPLATE_GARMENT -> one SDF net, explicit mesh and deformer
+        # code per garment template, in that order; the config wins, a caller's dataset names the capture otherwise.
         self.garment_type = conf.get_string('train.garment_type') if 'train.garment_type' in conf else None
+        if self.garment_type is None:
+            self.garment_type = getattr(dataset, 'garment_type', None)
+        if self.garment_type not in TEMPLATE_GARMENT:
+            raise KeyError("train.garment_type = %r is not a capture of utils/constant.py TEMPLATE_GARMENT (%s)"
+                           % (self.garment_type, ', '.join(sorted(TEMPLATE_GARMENT))))
+        self.garment_names = list(TEMPLATE_GARMENT[self.garment_type])                     # :160
+        self.garment_size = len(self.garment_names)                                      # :164
+        # one-piece garments are supervised with the union region of the parsing (:152-156, :1894-1905)
+        self.is_upper_bottom = bool(conf.get_bool('train.is_upper_bottom')) if 'train.is_upper_bottom' in conf else False
+        self.mask_keys = list(MASK_KEYS[self.is_upper_bottom])
+        if self.garment_size > 2:
+            raise NotImplementedError('only support less or equal than 2 garment_type')    # :934
+        if self.garment_size > len(self.mask_keys):
+            raise ValueError("train.is_upper_bottom supervises ONE garment with the union region; %s has %d garments"
+                             % (self.garment_type, self.garment_size))
         self.isfine = False                                   # train.py:239,312 set it with the fine stage
-        self.garment_size = len(self.garment_names)
         torch.manual_seed(seed)
         mult = conf.get_int('sdf_net.multires')
         # body + one SDF net per garment (model/network.py:188-199); different radii so the meshes differ
         self.sdf = getTmpSdf(device, mult, bias=0.5)
         self.garment_nets = torch.nn.ModuleList([getTmpSdf(device, conf.get_int('garment_sdf_net.multires'), bias=b)
-                                                 for b in (0.55, 0.45)])
+                                                 for b in (0.55, 0.45)[:self.garment_size]])
         skinner = None
         if skinner_state is not None:
             # the reference's `initial_skinner_<pose type>.pth` (model/network.py:225-236): the baked skinning volume (or the
@@ -270,8 +288,6 @@ class HotLoop:
                                       rendlen=conf.get_int('render_net.condlen'))
             dataset.set_garment_silhouettes([_zero_level_radius(n, device) for n in self.garment_nets], seed=seed + 3)
         self.dataset = dataset                     # getOptNet hands over the caller's dataset (model/network.py:352)
-        if self.garment_type is None:              # (the reference's configs name the capture in train.garment_type)
-            self.garment_type = getattr(dataset, 'garment_type', None)
         self._datas = None                         # the mini-batch dict of forward(datas, ...), when a caller passes one
         # large-pose fitting (OptimGarmentNetwork_Large_Pose.py:122-137): the surfaces are frozen, only the deformation,
         # the per-frame tensors, the colour net and the camera move
@@ -367,7 +383,7 @@ class HotLoop:
     def _gt_garment_mask(self, g_i, frame_ids):
         d = self._datas
         if d is not None:
-            return d[self.garment_names[g_i]].to(self.device).float()                 # datas['upper'] / ['bottom'] :1896
+            return d[self.mask_keys[g_i]].to(self.device).float()         # datas['upper'] / ['bottom'] / ['upper_bottom'] :1894-1905
         return self.dataset.garment_masks(g_i, frame_ids)
 
     def _gt_feature_lines(self, frame_ids):
@@ -577,9 +593,8 @@ class HotLoop:
         log and log('Fitting_body_net!')
         fit(self.sdf, body_points, save_name)
         for g_name, points, net in zip(self.garment_names, garment_points, self.garment_nets):
-            template = self.FL_GARMENT.get(g_name, g_name)
-            log and log('Fitting_garment_net {}!'.format(template))
-            fit(net, points, save_name.replace("sdf", 'sdf_{}'.format(template)))
+            log and log('Fitting_garment_net {}!'.format(g_name))
+            fit(net, points, save_name.replace("sdf", 'sdf_{}'.format(g_name)))                  # :563-576
         if self.large_pose:
             self.freeze_sdf()
 
@@ -631,8 +646,6 @@ class HotLoop:
         return frags
 
     # ------------------------------------------------------------------------------------------ feature curves
-    FL_GARMENT = {'upper': 'short_sleeve_upper', 'bottom': 'long_pants'}      # female-3-casual, utils/constant.py:116
-
     def _ensure_body_template(self):
         """`tmpBodyVs` / `tmpBodyFs`: the SMPL template in canonical space the body z-buffer tests rasterise (6890 vertices in
         the reference).  A stored skinner file brings it along; otherwise a coarse extraction of the body SDF stands in."""
@@ -648,6 +661,19 @@ class HotLoop:
         self.tmpBodyVs, self.tmpBodyFs = MCGpu.mc_gpu(vol, step[0], step[1], step[2], float(ax[0][0]), float(ax[1][0]),
                                                       float(ax[2][0]), 0.0)
 
+    def _feature_line_tables(self, available=None):
+        """({garment: its feature lines}, [all lines in the order of the dataset's `fl_pts` / `fl_masks` columns]):
+        FL_EXTRACT per garment template (OptimGarmentNetwork.py:1568, :1620) and FL_INFOS of the capture (:161; the order
+        `deform_feature_line` splits the 2-D ground truth in, :1539-1561).  `available`: restrict to the lines a registration
+        actually produced."""
+        extract = {g: [n for n in fl.FL_EXTRACT[g] if available is None or n in available] for g in self.garment_names}
+        used = [n for g in self.garment_names for n in extract[g]]
+        infos = FL_INFOS.get(self.garment_type, [])
+        names = list(infos) if set(used) <= set(infos) else used        # ('dance' & co. list a garment name there: unusable)
+        if available is not None:
+            names = [n for n in names if n in available]
+        return extract, names
+
     def _init_curves(self, seed, samples=200, gt_samples=100):
         """Synthetic stand-in for `align_fl` + the dataset's 2-D feature lines (OptimGarmentNetwork.py:3380-3546,
         dataset/dataset.py:113-155): closed rings on the initial garment spheres as canonical curves, the same rings
@@ -656,8 +682,7 @@ class HotLoop:
         dev = self.device
         g = torch.Generator().manual_seed(seed)
         radii = [_zero_level_radius(n, dev) for n in self.garment_nets]
-        self.fl_extract = {name: fl.FL_EXTRACT[self.FL_GARMENT[name]] for name in self.garment_names}
-        self.fl_names = [n for name in self.garment_names for n in self.fl_extract[name]]
+        self.fl_extract, self.fl_names = self._feature_line_tables()
         t = torch.linspace(0, 2 * math.pi, samples + 1)[:-1]
         ring = {}
         for name, r in zip(self.garment_names, radii):
@@ -685,6 +710,9 @@ class HotLoop:
         # z-buffer test sees them ON the surface where it faces the camera and a body-thickness behind it elsewhere
         r_body = _zero_level_radius(self.sdf, dev)
         owner = {n: r for name, r in zip(self.garment_names, radii) for n in self.fl_extract[name]}
+        for n in self.fl_names:                    # (a line of the capture no garment of the set carries: on the first one)
+            if n not in ring:
+                ring[n], owner[n] = ring[self.fl_extract[self.garment_names[0]][0]].clone(), radii[0]
         smpl_list = [ring[n] * (r_body / owner[n]) for n in self.fl_names]
         self.inter_free_curve = fl.Intersect_Free_Curve(curves_list, smpl_list, self.fl_names).to(dev)
         self._ensure_body_template()
@@ -887,8 +915,7 @@ class HotLoop:
             pc_sdf_loss = pc_sdf_loss + sdf_loss * conf.get_float('pc_weight.weight')
         return pc_sdf_loss + self.curve_aware_loss(ratio)                                # :972
 
-    CURVE_AWARE = {'female_outfit1': 'bottom_curve', 'female_outfit3': 'bottom_curve',
-                   'anran_dance': 'bottom_curve'}                                          # utils/constant.py:228-232
+    CURVE_AWARE = CURVE_AWARE                                                              # utils/constant.py:228-232
     CURVE_AWARE_SAMPLES = 50000                                                            # :808, :833
 
     def curve_aware_loss(self, ratio, sampler=None):
@@ -1368,7 +1395,7 @@ class FrameLoader:
     def __iter__(self):
         for pos in range(len(self)):
             frame_ids = self.loop.frame_batch_at(self.epoch, pos)
-            yield frame_ids, self.dataset.get_batch(frame_ids, self.loop.garment_names)
+            yield frame_ids, self.dataset.get_batch(frame_ids, self.loop.mask_keys)
 
 
 def fan_mesh(curve_pts):

@@ -325,7 +325,7 @@ def getOptNet(dataset, save_folder, N, bmins, bmaxs, resolutions, device, conf, 
         if osp.isfile(sdf_file) and use_initial_sdf:
             optNet.sdf.load_state_dict(torch.load(sdf_file, map_location='cpu'))
             for name, net in zip(optNet.garment_names, optNet.garment_nets):
-                garment_file = sdf_file.replace('sdf', 'sdf_{}'.format(optNet.FL_GARMENT.get(name, name)))      # :213-216
+                garment_file = sdf_file.replace('sdf', 'sdf_{}'.format(name))      # :213-216
                 assert osp.isfile(garment_file), garment_file
                 net.load_state_dict(torch.load(garment_file, map_location='cpu'))
             mesh_file = osp.join(root, save_folder, stem + '.ply')

@@ -158,7 +158,7 @@ def prefit_sdf(optNet, nepochs, config, args, save_root, rank):
     if rank == 0:
         utils.write_ply(osp.join(save_root, stem + '.ply'), verts_list[0], faces_list[0])
         for name, v, f in zip(optNet.garment_names, verts_list[1:], faces_list[1:]):
-            utils.write_ply(osp.join(save_root, stem.replace('sdf', 'sdf_' + optNet.FL_GARMENT.get(name, name)) + '.ply'), v, f)
+            utils.write_ply(osp.join(save_root, stem.replace('sdf', 'sdf_' + name) + '.ply'), v, f)
 
 
 def stage_of_epoch(config, epoch):
@@ -216,8 +216,13 @@ def main(argv=None, large_pose=False):
     capture = None
     if args.data is not None and args.data_type in ('scene', 'people_snap', 'large_pose', 'synthe') and osp.isdir(osp.join(args.data, 'imgs')):
         from recmv.dataset import getDatasetAndLoader
-        garment_type = args.garment_type or osp.basename(osp.normpath(args.data))
-        conds_lens = {'deformer': config.get_int('mlp_deformer.condlen') * 3,      # body + two garments (train.py:107)
+        # the capture's name keys the garment set (train.py:107,115: `train.garment_type` of the config; --garment_type or the
+        # folder name stand in when a config leaves it out); one deformer code for the body + one per garment template
+        from recmv.utils.constant import TEMPLATE_GARMENT
+        garment_type = args.garment_type or (config.get_string('train.garment_type') if 'train.garment_type' in config
+                                             else osp.basename(osp.normpath(args.data)))
+        config.put('train.garment_type', garment_type)
+        conds_lens = {'deformer': config.get_int('mlp_deformer.condlen') * (1 + len(TEMPLATE_GARMENT[garment_type])),
                       'renderer': config.get_int('render_net.condlen')}
         capture, _ = getDatasetAndLoader(args.data, conds_lens, batch_size, True, 0, config.get_bool('train.opt_pose'),
                                          config.get_bool('train.opt_trans'), config.get_config('train.opt_camera'),

@@ -18,6 +18,7 @@ ROWS = 24
 BOX = ((-0.8, -1.1, -0.6), (0.8, 1.1, 0.6))
 RESOLUTIONS = [(9, 11, 7), (17, 21, 13)]
 BODY_BIAS = 0.5
+GARMENT_TYPE = 'male-1-casual'      # TEMPLATE_GARMENT: short_sleeve_upper + long_pants, the garment names the fixture was made with
 
 
 def state():
@@ -48,7 +49,7 @@ class CaseDataset:
         leaf = lambda t: t.detach().clone().to(device).requires_grad_(True)
         self.F = self.frame_num = F
         self.H, self.W = H, W
-        self.garment_type = 'female-3-casual'
+        self.garment_type = GARMENT_TYPE
         self.poses, self.trans = leaf(st['poses_all']), leaf(st['trans_all'])
         self.dcond = leaf(torch.cat([torch.zeros(F, 128), st['cu_all'].cpu(), st['cb_all'].cpu()], dim=1))
         self.rend = leaf(st['rend_all'])
@@ -97,6 +98,7 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
     from recmv.model.network import getOptNet
     repo = Path(__file__).resolve().parent.parent
     conf = ConfigFactory.parse_file(str(repo / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    conf.put('train.garment_type', GARMENT_TYPE)
     dev = torch.device(device)
     st = {k[3:]: v.to(dev) for k, v in (inputs if inputs is not None else g).items() if k.startswith('in_')}
     ds = CaseDataset(st, dev)
@@ -129,7 +131,9 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
         curve.scale.copy_(st['scale'])
         curve.nx_scale.copy_(st['nx_scale'])
     optNet.inter_free_curve, optNet.fl_names, optNet.curves = curve, list(pc.NAMES), True
-    optNet.fl_extract = {'upper': pc.UPPER, 'bottom': pc.BOTTOM}
+    assert optNet.garment_names == ['short_sleeve_upper', 'long_pants'] and optNet.mask_keys == ['upper', 'bottom']
+    optNet.fl_extract, names = optNet._feature_line_tables()
+    assert names == list(pc.NAMES) and optNet.fl_extract == {'short_sleeve_upper': pc.UPPER, 'long_pants': pc.BOTTOM}
     optNet.fl_optimizer = torch.optim.AdamW(curve.parameters(), lr=1e-4)
     optNet.forward_time, optNet.remesh_intersect, optNet.pc_radius, optNet.sample_pix = (0 if remesh else 1), 30, RADIUS, SAMPLE_PIX
     optNet.angThred = optNet._cameras().angThreshold(0.5)
@@ -165,7 +169,7 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
         close('re-meshed body vertices', optNet.body_vs, g['body_v'], 1e-4)      # (interpolated along edges from f32 SDF values)
     close('loss', loss, g['loss'], rtol if rtol_loss is None else rtol_loss)
     info = optNet.info
-    ref_name = {'upper': 'short_sleeve_upper', 'bottom': 'long_pants'}
+    ref_name = {n: n for n in optNet.garment_names}           # (the loop's info is keyed on the reference's garment names)
     for mine, theirs in ref_name.items():
         for key_mine, key_ref in (('%s_grad_loss', 'info_%s_grad_loss'), ('def_%s_loss', 'info_def_%s_loss'),
                                   ('%s_color_loss', 'info_%s_color_loss'), ('%s_normal_loss', 'info_%s_normal_loss'),

@@ -116,10 +116,10 @@ def test_prefit_files_carry_the_reference_names_and_are_loaded_back(tmp_path):
                                 data_type='scene')
     g = torch.Generator().manual_seed(8)
     clouds = {}
-    for name, r in (('body', 0.40), ('upper', 0.50), ('bottom', 0.45)):
+    for name, r in (('body', 0.40), ('long_sleeve_upper', 0.50), ('long_pants', 0.45)):   # TEMPLATE_GARMENT['female-3-casual']
         d = torch.nn.functional.normalize(torch.randn(240, 3, generator=g), dim=1)
         clouds[name + '_vs'], clouds[name + '_ns'] = (d * r).numpy(), d.numpy()
-    del clouds['bottom_ns']                                            # a cloud without normals: fitted without the normal term
+    del clouds['long_pants_ns']                                            # a cloud without normals: fitted without the normal term
     np.savez(tmp_path / 'clouds.npz', **clouds)
     save_root = os.path.join(root, 'result')
     os.makedirs(save_root)
@@ -133,7 +133,7 @@ def test_prefit_files_carry_the_reference_names_and_are_loaded_back(tmp_path):
         train.prefit_sdf(optNet, 2, conf, argparse.Namespace(init_points=None), save_root, 0)          # no clouds: untouched
         assert all(torch.equal(a, b) for a, b in zip(before, optNet.garment_nets[0].parameters()))
         train.prefit_sdf(optNet, 2, conf, argparse.Namespace(init_points=str(tmp_path / 'clouds.npz')), save_root, 0)
-        names = ['initial_sdf_idr_6_0', 'initial_sdf_short_sleeve_upper_idr_6_0', 'initial_sdf_long_pants_idr_6_0']
+        names = ['initial_sdf_idr_6_0', 'initial_sdf_long_sleeve_upper_idr_6_0', 'initial_sdf_long_pants_idr_6_0']
         for n in names:
             assert os.path.isfile(os.path.join(save_root, n + '.pth')) and os.path.isfile(os.path.join(save_root, n + '.ply')), n
         assert not all(torch.equal(a, b) for a, b in zip(before, optNet.garment_nets[0].parameters()))
@@ -272,8 +272,8 @@ def test_align_fl_turns_a_stored_registration_into_the_loops_curves(tmp_path):
             centre = templates[n].verts_packed().mean(0, keepdim=True)
             want = ((curves[i] - g['srig_T'][i]) - centre) / g['srig_scale'][i] + centre
             torch.testing.assert_close(body, want, rtol=1e-5, atol=1e-6)
-        assert set(optNet.fl_extract['upper']) == {'neck', 'left_cuff', 'right_cuff', 'upper_bottom'}
-        assert optNet.fl_extract['bottom'] == ['left_pant', 'right_pant']
+        assert set(optNet.fl_extract[optNet.garment_names[0]]) == {'neck', 'left_cuff', 'right_cuff', 'upper_bottom'}
+        assert optNet.fl_extract[optNet.garment_names[1]] == ['left_pant', 'right_pant']
         # one iteration of the loop on these curves (train.py's sequence)
         from recmv import utils
         optNet, _ = utils.set_hierarchical_config(conf, 'coarse', optNet, None, res)

@@ -39,25 +39,39 @@ def state():
     return st
 
 
+SINGLE_TYPE = 'leyang_jump'          # TEMPLATE_GARMENT: ['dress'], a one-piece garment (train.is_upper_bottom = True)
+SINGLE_LINES = ['neck', 'left_cuff', 'right_cuff', 'bottom_curve']        # FL_INFOS['leyang_jump'] = FL_EXTRACT['dress']
+SINGLE_WEIGHTS = {'neck': 1.0, 'left_cuff': 2.0, 'right_cuff': 0.5, 'bottom_curve': 1.5}
+
+
+def single_state():
+    """The one-garment case: the upper mesh / net / code of state(), its four lines (the waist ring as the hem)."""
+    st = state()
+    L, M = len(SINGLE_LINES), pc.M
+    st['curves'], st['scale'], st['nx_scale'] = st['curves'][:L], st['scale'][:L], st['nx_scale'][:L]
+    st['gt'], st['fl_masks'] = st['gt'][:, :L * M], st['fl_masks'][:, :L]
+    return st
+
+
 # ----------------------------------------------------------------------------------------------- recmv side
 class CaseDataset:
     """What HotLoop asks of a caller's dataset (recmv/model/network.py getOptNet), over the fixture's tensors."""
 
     video_segmented_index = []
 
-    def __init__(self, st, device):
+    def __init__(self, st, device, single=False):
         leaf = lambda t: t.detach().clone().to(device).requires_grad_(True)
         self.F = self.frame_num = F
         self.H, self.W = H, W
-        self.garment_type = GARMENT_TYPE
+        self.garment_type = SINGLE_TYPE if single else GARMENT_TYPE
         self.poses, self.trans = leaf(st['poses_all']), leaf(st['trans_all'])
-        self.dcond = leaf(torch.cat([torch.zeros(F, 128), st['cu_all'].cpu(), st['cb_all'].cpu()], dim=1))
+        self.dcond = leaf(torch.cat([torch.zeros(F, 128), st['cu_all'].cpu()] + ([] if single else [st['cb_all'].cpu()]), dim=1))
         self.rend = leaf(st['rend_all'])
         self.conds = [self.dcond, self.rend]
         self.focal, self.pp, self.T = leaf(st['focal']), leaf(st['pp']), leaf(st['T'])
         self.R = st['R'].to(device)
         self.camera_params = {'focal_length': self.focal, 'princeple_points': self.pp, 'world2cam_coord_trans': self.T}
-        self.fl_weights = dict(pc.WEIGHTS)
+        self.fl_weights = dict(SINGLE_WEIGHTS if single else pc.WEIGHTS)
         self.shape = torch.zeros(10)
 
     def __len__(self):
@@ -77,12 +91,13 @@ class CaseDataset:
         return [self.poses, self.trans, self.dcond, self.rend, self.focal, self.pp, self.T]
 
 
-def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, remesh=False, rtol_loss=None, rtol_cam=None):
+def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, remesh=False, rtol_loss=None, rtol_cam=None, single=False):
     """One whole iteration of recmv's loop — HotLoop.forward, backward, propagateTmpPsGrad — on the fixture's state against
     what the reference's forward / backward / propagateTmpPsGrad produced; returns the largest relative deviations.
     `large_pose`: the large-pose stage on both sides (OptimGarmentNetwork_LargePose: SDF nets frozen, curve terms zero-weighted);
     `inputs`: the fixture that holds the `in_*` state when `g` has outputs only; `remesh`: the iteration starts with the re-mesh
-    (forward_time = 0: Seg3dLossless pyramid + MC of the body net and both garment nets) instead of given explicit meshes.
+    (forward_time = 0: Seg3dLossless pyramid + MC of the body net and both garment nets) instead of given explicit meshes;
+    `single`: the one-piece-garment case (`leyang_jump` = ['dress'], train.is_upper_bottom: single_state()).
     Tolerances (relative to the largest reference entry of each tensor): `rtol_loss` for the total loss (default `rtol`), `rtol`
     for the per-term info values and the stepped vertices, `rtol_grad` for the gradients the main optimiser consumes, `rtol_cam`
     (default `rtol_grad`) for the two camera-intrinsic gradients — sums of thousands of signed per-ray terms that cancel to a
@@ -98,15 +113,16 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
     from recmv.model.network import getOptNet
     repo = Path(__file__).resolve().parent.parent
     conf = ConfigFactory.parse_file(str(repo / "configs" / "synthetic" / "people_snapshot_like.conf"))
-    conf.put('train.garment_type', GARMENT_TYPE)
+    conf.put('train.garment_type', SINGLE_TYPE if single else GARMENT_TYPE)
+    conf.put('train.is_upper_bottom', bool(single))
     dev = torch.device(device)
     st = {k[3:]: v.to(dev) for k, v in (inputs if inputs is not None else g).items() if k.startswith('in_')}
-    ds = CaseDataset(st, dev)
+    ds = CaseDataset(st, dev, single=single)
     optNet, _ = getOptNet(ds, None, N, (-0.8, -1.1, -0.6), (0.8, 1.1, 0.6), [(9, 11, 7), (17, 21, 13)], device, conf, curves=False,
                           skin_grid=(5, 9, 7), opt_large=large_pose)
     assert optNet.large_pose == large_pose
     leaf = lambda t: t.detach().clone().requires_grad_(True)
-    sdfs = [n.to(dev) for n in mlc.build_sdfs(getTmpSdf)]
+    sdfs = [n.to(dev) for n in mlc.build_sdfs(getTmpSdf)][:1 if single else 2]
     tr = cs.build_translator(MLPTranslator).to(dev)
     sk = cs.build_skinner(LBSkinner).to(dev)
     rn = cs.build_render(RenderingNetwork_view_norm).to(dev)
@@ -122,24 +138,31 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
         optNet.body_vs = optNet.body_fs = None
         assert [tuple(r) for r in optNet.engine.resolutions.tolist()] == RESOLUTIONS
     else:
-        verts = [leaf(st['verts_u']), leaf(st['verts_b'])]
-        optNet.garment_vs, optNet.garment_fs = verts, [st['faces_u'].long(), st['faces_b'].long()]
+        verts = [leaf(st['verts_u']), leaf(st['verts_b'])][:len(sdfs)]
+        optNet.garment_vs, optNet.garment_fs = verts, [st['faces_u'].long(), st['faces_b'].long()][:len(sdfs)]
         optNet.body_vs, optNet.body_fs = st['body_v'], st['body_f'].long()
         optNet.garment_optimizer = torch.optim.SGD(verts, lr=0.05, momentum=0.9)
-    curve = fl.Intersect_Free_Curve(list(st['curves']), list(0.9 * st['curves']), pc.NAMES).to(dev)
+    line_names = list(SINGLE_LINES if single else pc.NAMES)
+    curve = fl.Intersect_Free_Curve(list(st['curves']), list(0.9 * st['curves']), line_names).to(dev)
     with torch.no_grad():
         curve.scale.copy_(st['scale'])
         curve.nx_scale.copy_(st['nx_scale'])
-    optNet.inter_free_curve, optNet.fl_names, optNet.curves = curve, list(pc.NAMES), True
-    assert optNet.garment_names == ['short_sleeve_upper', 'long_pants'] and optNet.mask_keys == ['upper', 'bottom']
+    optNet.inter_free_curve, optNet.fl_names, optNet.curves = curve, line_names, True
     optNet.fl_extract, names = optNet._feature_line_tables()
-    assert names == list(pc.NAMES) and optNet.fl_extract == {'short_sleeve_upper': pc.UPPER, 'long_pants': pc.BOTTOM}
+    if single:
+        assert optNet.garment_names == ['dress'] and optNet.mask_keys == ['upper_bottom'] and optNet.is_upper_bottom
+        assert names == line_names and optNet.fl_extract == {'dress': line_names}
+    else:
+        assert optNet.garment_names == ['short_sleeve_upper', 'long_pants'] and optNet.mask_keys == ['upper', 'bottom']
+        assert names == list(pc.NAMES) and optNet.fl_extract == {'short_sleeve_upper': pc.UPPER, 'long_pants': pc.BOTTOM}
     optNet.fl_optimizer = torch.optim.AdamW(curve.parameters(), lr=1e-4)
     optNet.forward_time, optNet.remesh_intersect, optNet.pc_radius, optNet.sample_pix = (0 if remesh else 1), 30, RADIUS, SAMPLE_PIX
     optNet.angThred = optNet._cameras().angThreshold(0.5)
     optNet.dctnull = dct_nullspace(30, 10, dev)
     optNet._datas = dict(img=st['img'], normal=st['normal'], fl_pts=st['gt'], fl_masks=st['fl_masks'], upper=st['gt_u'],
                          bottom=st['gt_b'])
+    if single:
+        optNet._datas = dict(img=st['img'], normal=st['normal'], fl_pts=st['gt'], fl_masks=st['fl_masks'], upper_bottom=st['gt_u'])
     cs.TrimeshStandIn.rng = np.random.RandomState(SEED)
 
     def sampler(verts_, faces_, n):
@@ -181,9 +204,12 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
     assert int(info['rays_total']) == sum(r[0] for r in want_rays), (info['rays_total'], want_rays)
     assert [int(v) for v in info['rays_converged']] == [r[1] for r in want_rays], (info['rays_converged'], want_rays)
     close('dct_loss', info['dct_loss'], g['info_dct_loss'], rtol)
-    close('curve-aware disc', info['pc_upper_bottom_circle_loss_sdf'], g['info_pc_upper_bottom_circle_loss_sdf'], rtol)
+    if single:                           # no waist line, not a CURVE_AWARE capture: no disc term on either side (:794, :816)
+        assert not any('circle_loss' in k for k in info) and not any('circle_loss' in k for k in g)
+    else:
+        close('curve-aware disc', info['pc_upper_bottom_circle_loss_sdf'], g['info_pc_upper_bottom_circle_loss_sdf'], rtol)
+        close('new_verts_b', verts[1], g['new_verts_b'], rtol)
     close('new_verts_u', verts[0], g['new_verts_u'], rtol)
-    close('new_verts_b', verts[1], g['new_verts_b'], rtol)
     close('curve scale after its step', curve.scale, g['new_scale'], 1e-5)
     close('curve nx_scale after its step', curve.nx_scale, g['new_nx'], 1e-4)
     tp, rp = dict(tr.named_parameters()), dict(rn.named_parameters())
@@ -202,7 +228,9 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
     close('g_poses', zero(ds.poses), g['g_poses_all'], rtol_grad)
     close('g_trans', zero(ds.trans), g['g_trans_all'], rtol_grad)
     close('g_cond_upper', zero(ds.dcond)[:, 128:256], g['g_cu_all'], rtol_grad)
-    close('g_cond_bottom', zero(ds.dcond)[:, 256:], g['g_cb_all'], rtol_grad)
+    if not single:
+        close('g_cond_bottom', zero(ds.dcond)[:, 256:], g['g_cb_all'], rtol_grad)
+    assert float(zero(ds.dcond)[:, :128].abs().max()) == 0.0          # (the body's slot of the code is never used by the loop)
     close('g_rendcond', zero(ds.rend), g['g_rend_all'], rtol_grad)
     close('g_focal', zero(ds.focal), g['g_focal'], rtol_grad if rtol_cam is None else rtol_cam)
     close('g_pp', zero(ds.pp), g['g_pp'], rtol_grad if rtol_cam is None else rtol_cam)

@@ -55,7 +55,10 @@ class Pointclouds:
         return torch.cat(self.features, 0)
 
 
-def main(large_pose=False, remesh=False):
+def main(large_pose=False, remesh=False, single=False):
+    """`single`: ONE one-piece garment — capture `leyang_jump` = ['dress'] with `train.is_upper_bottom` (configs/female_large_pose/
+    leyang_jump*.conf): the union region `datas['upper_bottom']` supervises it (:1894-1905), the deformer code holds body + one
+    garment (:670-676), four feature lines (neck, cuffs, hem), no curve-aware disc."""
     Nref = ref_loader.ref_module("model.network")
     Dref = ref_loader.ref_module("model.Deformer")
     Rref = ref_loader.ref_module("model.RenderNet")
@@ -78,8 +81,9 @@ def main(large_pose=False, remesh=False):
     cs.TrimeshStandIn.rng = np.random.RandomState(fc.SEED)
     OGN.trimesh = types.SimpleNamespace(Trimesh=cs.TrimeshStandIn)
     conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf")).get_config('loss_coarse')
-    st = fc.state()
+    st = fc.single_state() if single else fc.state()
     H, W, N = fc.H, fc.W, fc.N
+    line_names = list(fc.SINGLE_LINES if single else pc.NAMES)
     frame_ids = torch.tensor(fc.FRAME_IDS)
 
     class MaskRender:
@@ -111,10 +115,10 @@ def main(large_pose=False, remesh=False):
             return cpu_port._AlphaCompositeCPU.apply(idx.permute(0, 2, 3, 1).to(torch.int32).contiguous(),
                                                      weights.permute(0, 2, 3, 1).contiguous(), features.contiguous())
 
-    sdfs = mlc.build_sdfs(Nref.getTmpSdf)
+    sdfs = mlc.build_sdfs(Nref.getTmpSdf)[:1 if single else 2]
     # the explicit meshes of an iteration are extractions of their nets: put the blobs' vertices on the zero levels (Newton steps
     # along the gradient), so that the rasterised surface points are starting points the root finder converges from
-    for key, net, radius in (('verts_u', sdfs[0], 0.5), ('verts_b', sdfs[1], 0.4)):
+    for key, net, radius in list(zip(('verts_u', 'verts_b'), sdfs, (0.5, 0.4))):
         v = torch.nn.functional.normalize(st[key] - st[key].mean(0, keepdim=True), dim=1) * radius
         for _ in range(6):
             v = v.detach().requires_grad_(True)
@@ -129,7 +133,7 @@ def main(large_pose=False, remesh=False):
     ref = object.__new__(G.Intersect_Free_Curve)
     torch.nn.Module.__init__(ref)
     ref.cano2canosmpl = lambda lst, nm: [0.9 * c for c in lst]
-    ref.fl_names, ref.sample_num = list(pc.NAMES), pc.S
+    ref.fl_names, ref.sample_num = line_names, pc.S
     ref.initialize_parameters([c.clone() for c in st['curves']])
     with torch.no_grad():
         ref.scale.copy_(st['scale'])
@@ -138,22 +142,31 @@ def main(large_pose=False, remesh=False):
     leaves = dict(poses_all=leaf(st['poses_all']), trans_all=leaf(st['trans_all']), cu_all=leaf(st['cu_all']), cb_all=leaf(st['cb_all']),
                   rend_all=leaf(st['rend_all']), focal=leaf(st['focal']), pp=leaf(st['pp']), T=leaf(st['T']))
     verts = [leaf(st['verts_u']), leaf(st['verts_b'])]
+    if single:
+        del leaves['cb_all']
+        verts = verts[:1]
     ds_cls = [v for v in vars(DS).values() if isinstance(v, type) and getattr(v, "__module__", "") == DS.__name__
               and "get_batchframe_data" in vars(v)][0]
     dataset = types.SimpleNamespace(video_segmented_index=[], frame_num=fc.F, poses=leaves['poses_all'], trans=leaves['trans_all'],
-                                    fl_weights=dict(pc.WEIGHTS))
+                                    fl_weights=dict(fc.SINGLE_WEIGHTS if single else pc.WEIGHTS))
     dataset.get_batchframe_data = lambda name, fids, bs: ds_cls.get_batchframe_data(dataset, name, fids, bs)
     dataset.get_camera_parameters = lambda n, dev: (leaves['focal'].expand(n, 2), leaves['pp'].expand(n, 2), st['R'].expand(n, 3, 3),
                                                     leaves['T'].expand(n, 3), H, W)
     cam0 = OurCameras(st['focal'], st['pp'], st['R'], st['T'], image_size=[(W, H)])
-    names = ['short_sleeve_upper', 'long_pants']
-    fake = types.SimpleNamespace(conf=conf, info={}, garment_size=2, garment_names=names, garment_vs=verts, is_upper_bottom=False,
-                                 garment_fs=[st['faces_u'], st['faces_b']], garment_nets=sdfs, deformer=comp, netRender=rn,
+    names = ['dress'] if single else ['short_sleeve_upper', 'long_pants']
+    fake = types.SimpleNamespace(conf=conf, info={}, garment_size=len(names), garment_names=names, garment_vs=verts,
+                                 is_upper_bottom=single, garment_fs=[st['faces_u'], st['faces_b']][:len(names)], garment_nets=sdfs,
+                                 deformer=comp, netRender=rn,
                                  sdfShrinkRadius=0.0, body_vs=st['body_v'], body_fs=st['body_f'], tmpBodyVs=st['body_v'],
-                                 tmpBodyFs=st['body_f'], inter_free_curve=ref, fl_names=list(pc.NAMES), maskRender=MaskRender(),
+                                 tmpBodyFs=st['body_f'], inter_free_curve=ref, fl_names=line_names, maskRender=MaskRender(),
                                  dataset=dataset, forward_time=1, remesh_intersect=30, remesh_time=0., root=None,
-                                 dctnull=Uref.DCTNullSpace(10, 30), angThred=cam0.angThreshold(0.5), garment_type='female-3-casual',
-                                 isfine=False)
+                                 dctnull=Uref.DCTNullSpace(10, 30), angThred=cam0.angThreshold(0.5),
+                                 garment_type='leyang_jump' if single else 'female-3-casual', isfine=False)
+    if single:                                             # the reference's own split of the per-frame deformer code (:668-675)
+        fake.get_grad_parameters = types.MethodType(KLASS.get_grad_parameters, fake)
+        dataset.get_grad_parameters = lambda fids, dev: (leaves['poses_all'][fids], leaves['trans_all'][fids],
+                                                         torch.cat([torch.zeros(fc.F, 128), leaves['cu_all']], dim=1)[fids],
+                                                         leaves['rend_all'][fids])
     if remesh:
         # forward_time = 0: the iteration starts with marching_cube_update (:678-740) -> discretizeSDF (:581-618): the reference's
         # Seg3dLossless pyramid over the body net and both garment nets, MC through the oracle (canonical order), the explicit
@@ -185,8 +198,9 @@ def main(large_pose=False, remesh=False):
             setattr(fake, name, types.MethodType(getattr(KLASS, name), fake))
         root = tempfile.mkdtemp()
     fake.pcRender = Cref.PointsRendererWithFrags_Split(PointRasterizer(), Compositor())
-    fake.get_grad_parameters = lambda fids, dev: ([None, leaves['cu_all'][fids], leaves['cb_all'][fids]], leaves['poses_all'][fids],
-                                                  leaves['trans_all'][fids], leaves['rend_all'][fids])
+    if not single:
+        fake.get_grad_parameters = lambda fids, dev: ([None, leaves['cu_all'][fids], leaves['cb_all'][fids]], leaves['poses_all'][fids],
+                                                      leaves['trans_all'][fids], leaves['rend_all'][fids])
     for name in ('project_2d_loss', 'deform_feature_line', 'fl_visible_by_body_zbuff', 'compute_fl_proj_loss', 'mask_loss',
                  'find_surface_ps', 'compute_garment_pc_loss', 'curve_aware_loss', 'sample_train_ray', 'opt_garment_surface_ps',
                  'surface_render_loss', 'dct_poses_loss', 'save_debug'):
@@ -203,6 +217,9 @@ def main(large_pose=False, remesh=False):
     opt = torch.optim.Adam(shared, lr=1e-3)
     datas = dict(img=st['img'], mask=((st['gt_u'] + st['gt_b']) > 0).float(), fl_pts=st['gt'], fl_masks=st['fl_masks'],
                  upper=st['gt_u'], bottom=st['gt_b'], body=torch.zeros_like(st['gt_u']), normal=st['normal'])
+    if single:                                             # (only the union region is read with is_upper_bottom, :1901-1904)
+        datas = dict(img=st['img'], mask=st['gt_u'], fl_pts=st['gt'], fl_masks=st['fl_masks'], upper_bottom=st['gt_u'],
+                     normal=st['normal'])
     real_cuda = torch.Tensor.cuda
     torch.Tensor.cuda = lambda self, *a, **k: self                    # curve_aware_loss uploads its samples with .cuda() (:809)
     try:
@@ -211,12 +228,14 @@ def main(large_pose=False, remesh=False):
         loss.backward()
         KLASS.propagateTmpPsGrad(fake, frame_ids, pc.RATIO)
         info1 = dict(fake.info)
-        state1 = dict(new_verts_u=fake.garment_vs[0].detach().clone(), new_verts_b=fake.garment_vs[1].detach().clone(),
-                      new_scale=ref.scale.detach().clone(), new_nx=ref.nx_scale.detach().clone())
+        state1 = dict(new_verts_u=fake.garment_vs[0].detach().clone(), new_scale=ref.scale.detach().clone(),
+                      new_nx=ref.nx_scale.detach().clone())
+        if not single:
+            state1['new_verts_b'] = fake.garment_vs[1].detach().clone()
         first = {k: (v.grad.detach().clone() if v.grad is not None else None) for k, v in leaves.items()}
         first_modules = [[(q.grad.detach().clone() if q.grad is not None else None) for q in m.parameters()] for m in sdfs + [comp, rn]]
         loss2 = None
-        if not large_pose and not remesh:
+        if not large_pose and not remesh and not single:
             # a second iteration after the main optimiser's step (train.py:317-328): the SGD momentum on the explicit vertices,
             # the AdamW state of the curves and forward_time carry over
             opt.step()
@@ -261,7 +280,11 @@ def main(large_pose=False, remesh=False):
     if loss2 is not None:
         res['loss2'] = loss2
         res['rays2'] = torch.tensor([float(x) for n in names for x in info2['%s_rayInfo' % n]])
-    if remesh:
+    if single:                                              # its own inputs (one mesh, four lines) in forward_single.npz
+        if not large_pose:
+            res.update({'in_' + k: v for k, v in st.items()})
+        save("forward_single_large" if large_pose else "forward_single", **res)
+    elif remesh:
         res.update(faces_u=fake.garment_fs[0], faces_b=fake.garment_fs[1], body_v=fake.body_vs.detach(), body_f=fake.body_fs)
         print("re-mesh: %d / %d garment vertices, %d body vertices" % (verts[0].shape[0], verts[1].shape[0], fake.body_vs.shape[0]))
         save("forward_remesh", **res)
@@ -276,3 +299,5 @@ if __name__ == "__main__":
     main()
     main(large_pose=True)
     main(remesh=True)
+    main(single=True)
+    main(single=True, large_pose=True)

@@ -230,3 +230,14 @@ def test_checkpoint_layout_equals_the_references():
             assert got[k] == [shape, dtype], (k, got[k], [shape, dtype])
     extra = [k for k in got if k not in ref and not k.startswith('engine.')]
     assert not extra, extra
+
+
+def test_name_tables_equal_the_reference_module():
+    """recmv/utils/constant.py against the tables of the reference's utils/constant.py (dumped from the imported reference module by
+    tests/golden/make_golden_constants.py): garment templates per capture, feature lines per capture / per garment (list ORDER
+    included — it is the column order of `fl_pts`), z-buffer slack, curve-aware captures, ATR regions, initial line scales."""
+    import json
+    from recmv.utils import constant
+    want = json.loads((REPO / "tests" / "golden" / "constant_tables.json").read_text())
+    for name, table in want.items():
+        assert getattr(constant, name) == table, name

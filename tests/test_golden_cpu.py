@@ -407,3 +407,23 @@ def test_one_whole_iteration_with_the_remesh_inside_matches_the_reference():
         assert set(big) <= {'g_focal', 'g_pp'} and max(big.values(), default=0.) < 5e-2, big
     finally:
         cpu_port.uninstall()
+
+
+def test_one_whole_single_garment_iteration_matches_the_reference():
+    """The whole iteration for a capture with ONE one-piece garment — `leyang_jump` = ['dress'] with train.is_upper_bottom
+    (utils/constant.py:105, configs/female_large_pose/leyang_jump*.conf:5): the reference's forward takes the union region
+    `datas['upper_bottom']` (:1901-1904), splits the deformer code in body + one garment (:670-676), deforms the dress's four lines
+    (FL_EXTRACT), adds no curve-aware disc; HotLoop builds the same loop from train.garment_type alone."""
+    from oracle import cpu_port
+    import forward_case as fwc
+    cpu_port.install()
+    try:
+        worst = fwc.run(load("forward_single"), "cpu", rtol=1e-4, rtol_grad=5e-3, single=True)
+        big = {k: v for k, v in worst.items() if v > 5e-5}
+        assert set(big) <= {'g_focal', 'g_pp'}, big
+        worst = fwc.run(load("forward_single_large"), "cpu", rtol=1e-4, rtol_grad=5e-3, single=True, large_pose=True,
+                        inputs=load("forward_single"))           # (OptimGarmentNetwork_Large_Pose.py:250-258, same switch)
+        big = {k: v for k, v in worst.items() if v > 5e-5}
+        assert set(big) <= {'g_focal', 'g_pp'}, big
+    finally:
+        cpu_port.uninstall()

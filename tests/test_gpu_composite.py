@@ -99,3 +99,16 @@ def test_one_whole_iteration_with_the_remesh_inside_on_gpu_matches_the_reference
         _report("whole iteration with the re-mesh inside, on the GPU",
                 fwc.run(cc.load("forward_remesh"), DEV, rtol=3e-4, rtol_loss=1e-4, rtol_grad=1e-3, rtol_cam=5e-2,
                         inputs=cc.load("forward"), remesh=True))
+
+
+def test_one_whole_single_garment_iteration_on_gpu_matches_the_reference():
+    """One one-piece garment (`leyang_jump` = ['dress'], train.is_upper_bottom: union region, body + one garment code), the
+    optimisation stage and the large-pose stage (OptimGarmentNetwork.py:1894-1905, OptimGarmentNetwork_Large_Pose.py:250-258)."""
+    import forward_case as fwc
+    with cc.host_draws():
+        _report("whole single-garment iteration on the GPU",
+                fwc.run(cc.load("forward_single"), DEV, rtol=3e-4, rtol_loss=1e-4, rtol_grad=1e-3, rtol_cam=5e-3, single=True))
+    with cc.host_draws():
+        _report("whole single-garment large-pose iteration on the GPU",
+                fwc.run(cc.load("forward_single_large"), DEV, rtol=3e-4, rtol_loss=1e-4, rtol_grad=1e-3, rtol_cam=5e-3, single=True,
+                        large_pose=True, inputs=cc.load("forward_single")))

@@ -25,6 +25,64 @@ def _tiny_loop(world=1, rank=0, seed=0, curves=False, lr=None):
                    bbox=((-0.9, -1.2, -0.6), (0.9, 1.2, 0.6)), world_size=world, rank=rank, seed=seed, curves=curves)
 
 
+REF_CONFS = {       # the reference's own config files, parsed in place where /root/reference is mounted (this container)
+    'anran': '/root/reference/configs/gap-female/config_anran_garment_10-5-1.conf',
+    'leyang_jump': '/root/reference/configs/female_large_pose/leyang_jump_large_pose.conf',
+    'female-3-casual': '/root/reference/configs/people_snapshot/female-3-casual.conf',
+}
+
+
+@pytest.mark.parametrize("capture,garments,lines,mask_keys,large_pose", [
+    ('female-3-casual', ['long_sleeve_upper', 'long_pants'],
+     ['neck', 'left_cuff', 'right_cuff', 'upper_bottom', 'left_pant', 'right_pant'], ['upper', 'bottom'], False),
+    ('anran', ['short_sleeve_upper', 'skirt'], ['neck', 'left_cuff', 'right_cuff', 'upper_bottom', 'bottom_curve'],
+     ['upper', 'bottom'], False),                                                     # BASELINE config C4
+    ('leyang_jump', ['dress'], ['neck', 'left_cuff', 'right_cuff', 'bottom_curve'], ['upper_bottom'], True),   # C5
+])
+def test_garment_set_follows_the_capture_name(capture, garments, lines, mask_keys, large_pose):
+    """`train.garment_type` -> TEMPLATE_GARMENT / FL_INFOS / FL_EXTRACT, `train.is_upper_bottom` -> the union region
+    (utils/constant.py:53-131; OptimGarmentNetwork.py:141-164, :670-676, :1894-1905): HotLoop builds one- and two-garment loops
+    under the reference's names and takes an iteration with the feature-curve branch on.  The reference's own config file of the
+    capture is the input where the reference tree is mounted (sizes cut down for the host); the synthetic config with the
+    capture's name and switch otherwise."""
+    from oracle import cpu_port
+    from recmv.hocon import ConfigFactory
+    from recmv.loop import HotLoop
+    ref_conf = REF_CONFS[capture]
+    if os.path.isfile(ref_conf):
+        conf = ConfigFactory.parse_file(ref_conf)
+        assert conf.get_string('train.garment_type') == capture
+    else:
+        conf = ConfigFactory.parse_file(CONF)
+        conf.put('train.garment_type', capture)
+        conf.put('train.is_upper_bottom', mask_keys == ['upper_bottom'])
+    conf.put('train.sample_pix_num', 32)
+    cpu_port.install()
+    try:
+        loop = HotLoop(conf, 'cpu', n_frames=12, H=64, W=64, resolutions=[(9, 11, 7), (17, 21, 13)], skin_grid=(5, 9, 7),
+                       bbox=((-0.9, -1.2, -0.6), (0.9, 1.2, 0.6)), curves=True, large_pose=large_pose)
+        assert loop.garment_names == garments and loop.garment_size == len(garments) == len(loop.garment_nets)
+        assert loop.fl_names == lines and loop.mask_keys == mask_keys
+        assert [n for g in garments for n in loop.fl_extract[g]] == lines
+        assert loop.dataset.d_cond.shape[1] == 128 * (1 + len(garments))                    # train.py:107
+        frame_ids = loop.frame_batch(0)
+        datas = loop.dataset.get_batch(frame_ids, loop.mask_keys)
+        assert set(mask_keys) <= set(datas) and not ({'upper', 'bottom', 'upper_bottom'} - set(mask_keys)) & set(datas)
+        assert datas['fl_masks'].shape == (frame_ids.numel(), len(lines))
+        l0, rays = loop.step(0)
+        assert torch.isfinite(l0) and rays > 0
+        for g in garments:
+            assert f'{g}_grad_loss' in loop.info and f'pc_{g}_loss_sdf' in loop.info and f'pc_{g}_mask_loss' in loop.info
+            assert f'{g}_project loss' in loop.info['fl_loss']
+        # the waist disc exists only where the capture has a waist line (:794); no CURVE_AWARE capture here
+        assert ('pc_upper_bottom_circle_loss_sdf' in loop.info) == ('upper_bottom' in lines)
+        if large_pose:
+            assert all(not p.requires_grad for net in loop.garment_nets for p in net.parameters())
+        assert set(loop.state_dict()) >= {'garment_nets.%d.lin0.bias' % i for i in range(len(garments))}
+    finally:
+        cpu_port.uninstall()
+
+
 def test_loop_two_steps_on_cpu_port():
     from oracle import cpu_port
     cpu_port.install()

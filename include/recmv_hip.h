@@ -72,6 +72,13 @@ int recmv_grid_sample3d_forward(const void* input, const recmv_tensor5* input_de
  * is a registered buffer, never a parameter (model/Deformer.py:240-243).  When non-NULL it must be
  * zero-filled by the caller (the reference zero-fills it itself: GridSamplerMineKernel.cu:955).
  * grad_grid: [N,Do,Ho,Wo,3] contiguous (the reference assumes this too: ...Kernel.cu:538-545). */
+/* Summation order of backward / double backward when only grad_grid (and grad_grad_output) are asked for on a channels-last f32
+ * volume: 0 (default) = record-coalesced lanes — G lanes per point, per-point sums finished by a lane butterfly: the reference's
+ * terms in a different order, within a few ulp of sum |terms| (north_star: gradients within an f32 tolerance); 1 = one lane per
+ * point with the channel loop in the reference's order (GridSamplerMineKernel.cu:333-914), bit-equal to the oracle.  Requests
+ * with grad_input or ggI, f64, or other layouts always take the exact kernels.  Returns the previous mode. */
+int recmv_set_sampler_mode(int mode);
+
 int recmv_grid_sample3d_backward(const void* input, const recmv_tensor5* input_desc,
                                  const void* grid, const recmv_tensor5* grid_desc,
                                  const void* grad_output, const recmv_tensor5* grad_output_desc,

@@ -78,3 +78,21 @@ def dbackward(grad_output_input, grad_output_grid, input, grid, grad_output, int
             interpolation_mode, padding_mode, L.dtype_code(input), L.stream_ptr(input.device)),
             "GridSamplerMine.dbackward")
     return grad_input, grad_grid, ggo
+
+
+class exact_order:
+    """`with GridSamplerMine.exact_order():` — backward / double backward sum their channels in the reference's order (one lane per
+    point, GridSamplerMineKernel.cu:333-914; bit-equal to the oracle) instead of the default record-coalesced lanes (same terms,
+    lane butterfly; within a few ulp of sum |terms|).  `recmv_set_sampler_mode` of the C ABI; RECMV_SAMPLER_EXACT=1 sets it for a
+    whole process."""
+
+    def __init__(self, exact=True):
+        self.mode = 1 if exact else 0
+
+    def __enter__(self):
+        self.prev = L.lib().recmv_set_sampler_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        L.lib().recmv_set_sampler_mode(self.prev)
+        return False

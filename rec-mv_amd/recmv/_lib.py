@@ -86,6 +86,7 @@ def _declare(lib):
         "recmv_gemm_nt_actgrad": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, f32, f32, f32, vp]),
         "recmv_gemm_nt_mulgrad": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, f32, f32, f32, vp]),
         "recmv_set_gemm_mode": (C.c_int, [i32]),
+        "recmv_set_sampler_mode": (C.c_int, [i32]),
         "recmv_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),
         "recmv_gemm_tn": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
         "recmv_posenc_forward": (C.c_int, [vp, i64, vp, i64, i64, i64, i32, vp, f32, vp]),
@@ -151,6 +152,8 @@ def lib():
                               f"{ABI_VERSION}: rebuild with `python rec-mv_amd/build.py --force`")
         if os.environ.get("RECMV_GEMM_MODE"):
             l.recmv_set_gemm_mode(int(os.environ["RECMV_GEMM_MODE"]))
+        if os.environ.get("RECMV_SAMPLER_EXACT"):
+            l.recmv_set_sampler_mode(int(os.environ["RECMV_SAMPLER_EXACT"]))
         _lib = l
     return _lib
 

@@ -90,6 +90,12 @@ def test_sampler_forward_backward_dbackward_vs_oracle(oracle, dtype, cl, C):
     assert torch.equal(out_g.cpu(), out_o), "forward is a fixed fma chain: bit-exact"
     go = torch.randn(out_o.shape, dtype=dtype, generator=torch.Generator().manual_seed(1))
     gi_o, gg_o = oracle.gs3d_backward(inp, grid, go)
+    with GridSamplerMine.exact_order():         # the reference's channel order (the default for grad_grid-only requests is not)
+        _sampler_exact_backward_checks(oracle, dtype, cl, inp, grid, go, gi_o, gg_o)
+
+
+def _sampler_exact_backward_checks(oracle, dtype, cl, inp, grid, go, gi_o, gg_o):
+    from recmv import GridSamplerMine
     gi_g, gg_g = GridSamplerMine.backward(gpu(inp), gpu(grid), gpu(go), 0, 1)
     assert torch.equal(gg_g.cpu(), gg_o), "grad_grid: bit-exact"
     tol = 1e-12 if dtype == torch.float64 else 2e-5                     # atomics: order differs
@@ -112,11 +118,55 @@ def test_sampler_forward_backward_dbackward_vs_oracle(oracle, dtype, cl, C):
     assert a2_g is None and torch.equal(b2_g.cpu(), b2_o) and torch.equal(c2_g.cpu(), c2_o)
 
 
+@pytest.mark.parametrize("C", [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 20])
+def test_sampler_backward_record_lanes_within_tolerance(oracle, C):
+    """The DEFAULT backward / double backward for grad_grid-only requests on a channels-last f32 volume (what the loop asks: the
+    skinning volume is a frozen buffer): G lanes per point x V channels per lane, per-point sums finished by a lane butterfly —
+    the reference's terms (GridSamplerMineKernel.cu:333-570, 575-914) in another order.  Bound: 2e-6 of the largest entry of each
+    tensor (north_star: gradients within an f32 tolerance); the exact-order kernels stay bit-equal to the oracle
+    (test_sampler_forward_backward_dbackward_vs_oracle).  Ragged last block, several batch items, points outside the volume, on
+    the far border, and non-finite coordinates (every corner skipped: zeros); C = 20 has no lane split and falls back."""
+    from recmv import GridSamplerMine
+    g = torch.Generator().manual_seed(100 + C)
+    N, P = 3, 4099 + 32 * 11 + 3
+    inp = torch.randn(N, C, 9, 13, 11, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    grid = (torch.rand(N, 1, 1, P, 3, generator=g) - 0.5) * 2.6
+    grid[0, 0, 0, 5] = torch.tensor([float('nan'), 0.1, 0.2])
+    grid[1, 0, 0, 7] = torch.tensor([0.3, float('inf'), -0.2])
+    grid[2, 0, 0, 9] = torch.tensor([1.0 - 1.0 / 11, 1.0 - 1.0 / 13, 1.0 - 1.0 / 9])     # exactly the last voxel centre
+    go = torch.randn(N, C, 1, 1, P, generator=g)
+    ggG = torch.randn(N, 1, 1, P, 3, generator=g)
+    _, gg_o = oracle.gs3d_backward(inp, grid, go)
+    _, b_o, c_o = oracle.gs3d_dbackward(None, ggG, inp, grid, go, need_grad_input=False)
+
+    def close(name, got, want):
+        scale = float(want.abs().max())
+        err = float((got.cpu() - want).abs().max()) / scale
+        assert err <= 2e-6, (name, C, err)
+        return err
+
+    _, gg = GridSamplerMine.backward(gpu(inp), gpu(grid), gpu(go), 0, 1, need_grad_input=False)
+    _, b, c = GridSamplerMine.dbackward(None, gpu(ggG), gpu(inp), gpu(grid), gpu(go), 0, 1, need_grad_input=False)
+    errs = [close('grad_grid', gg, gg_o), close('dbackward grad_grid', b, b_o), close('grad_grad_output', c, c_o)]
+    print("C=%d: largest deviations relative to the largest entry: %.1e %.1e %.1e" % (C, *errs))
+    for t in (gg, b, c):                                     # a NaN coordinate: the reference skips every corner -> zeros
+        assert torch.isfinite(t).all()
+    assert float(gg[0, 0, 0, 5].abs().max()) == 0.0 and float(c[0, :, 0, 0, 5].abs().max()) == 0.0     # (NaN; +inf clips to the border)
+    # run to run reproducible (a fixed butterfly, no atomics)
+    _, gg_again = GridSamplerMine.backward(gpu(inp), gpu(grid), gpu(go), 0, 1, need_grad_input=False)
+    assert torch.equal(gg, gg_again)
+    # a strided grad_output view and a single batch item
+    go_wide = torch.randn(1, C, 1, 1, 2 * P, generator=g)
+    _, gg1_o = oracle.gs3d_backward(inp[:1], grid[:1], go_wide[..., ::2].contiguous())
+    _, gg1 = GridSamplerMine.backward(gpu(inp[:1]), gpu(grid[:1]), gpu(go_wide)[..., ::2], 0, 1, need_grad_input=False)
+    close('grad_grid, strided grad_output', gg1, gg1_o)
+
+
 @pytest.mark.parametrize("C", [4, 8, 12, 16, 24, 32, 20])
 def test_sampler_forward_record_lanes_vs_oracle(oracle, C):
-    """The record-coalesced forward (lane -> point, channel group; C / 4 in {1, 2, 3, 4, 6, 8}; 4096 <= P <= 300000) and the
-    fall-back for other widths (C = 20): bit-exact, incl. a ragged last block, points outside the volume and several batch
-    items."""
+    """The record-coalesced forward (G lanes per point x V channels per lane, branch-free clamped gathers, for lists of >= 2048
+    points) and the fall-back for widths without a lane split (C = 20) or other grid shapes: bit-exact, incl. a ragged last block,
+    points outside the volume and several batch items."""
     from recmv import GridSamplerMine
     inp, grid = _sampler_case(torch.float32, C=C, dims=(9, 13, 11), P=4099 + 64 * 37 + 5, channels_last=True, seed=C, spread=2.6)
     assert torch.equal(GridSamplerMine.forward(gpu(inp), gpu(grid), 0, 1).cpu(), oracle.gs3d_forward(inp, grid))

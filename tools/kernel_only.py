@@ -103,6 +103,54 @@ def run(out_json):
     json.dump(cases, open(out_json, "w"))
 
 
+def run_sampler(out_json):
+    """Sampler only: forward, backward, double backward on surface-coherent points, the exact-order kernels against the
+    record-coalesced lane splits (recmv_set_sampler_mode 1 / 0 / 2 / 3 = one lane per point, 8 lanes x 3 channels, 4 x 6, 2 x 12)."""
+    import torch
+    from recmv import GridSamplerMine, _lib
+    dev = "cuda:0"
+    cases = []
+    sep = torch.zeros(257, device=dev)
+
+    def case(name, nbytes, fn):
+        torch.sort(sep)
+        fn()
+        torch.cuda.synchronize()
+        torch.sort(sep)
+        for _ in range(REPS):
+            fn()
+        torch.cuda.synchronize()
+        cases.append({"name": name, "alg_bytes": int(nbytes)})
+
+    C, D, H, W = 24, 65, 225, 129
+    vol = torch.softmax(2 * torch.randn(1, C, D, H, W, device=dev), dim=1).contiguous(memory_format=torch.channels_last_3d)
+    for P in (105038, 153600, 460800, 1 << 20, 1 << 22):
+        n = int(round(P ** 0.5))
+        u, v = torch.meshgrid(torch.linspace(-0.9, 0.9, n, device=dev), torch.linspace(-0.9, 0.9, n, device=dev), indexing="ij")
+        surf = torch.stack([u, v, 0.3 * torch.sin(3 * u) * torch.cos(2 * v)], -1).view(1, 1, 1, -1, 3).contiguous()
+        Pc = surf.shape[3]
+        go = torch.randn(1, C, 1, 1, Pc, device=dev)
+        gg = torch.randn(1, 1, 1, Pc, 3, device=dev)
+        for mode, tag in ((1, "exact order, 1 lane/point"), (2, "8 lanes x 3 ch"), (3, "4 lanes x 6 ch"), (4, "2 lanes x 12 ch"),
+                          (0, "default")):
+            _lib.lib().recmv_set_sampler_mode(mode)
+            case(f"sampler fwd [{tag}], surface-coherent P={Pc} (coords + output bytes)", Pc * (12 + 4 * C),
+                 lambda: GridSamplerMine.forward(vol, surf, 0, 1))
+            case(f"sampler bwd (grid only) [{tag}], surface-coherent P={Pc}", Pc * (12 + 4 * C + 12),
+                 lambda: GridSamplerMine.backward(vol, surf, go, 0, 1, need_grad_input=False))
+            case(f"sampler dbwd [{tag}], surface-coherent P={Pc}", Pc * (12 + 12 + 4 * C + 12 + 4 * C),
+                 lambda: GridSamplerMine.dbackward(None, gg, vol, surf, go, 0, 1, need_grad_input=False))
+        if P <= (1 << 20):
+            rnd = (torch.rand(1, 1, 1, P, 3, device=dev) - 0.5) * 2.2
+            gor = torch.randn(1, C, 1, 1, P, device=dev)
+            case(f"sampler fwd [default], uniformly random P={P} (+ touched records)", P * (12 + 4 * C) + min(4 * C * D * H * W, 32 * C * P),
+                 lambda: GridSamplerMine.forward(vol, rnd, 0, 1))
+            case(f"sampler bwd [default], uniformly random P={P} (+ touched records)", P * (24 + 4 * C) + min(4 * C * D * H * W, 32 * C * P),
+                 lambda: GridSamplerMine.backward(vol, rnd, gor, 0, 1, need_grad_input=False))
+        _lib.lib().recmv_set_sampler_mode(0)
+    json.dump(cases, open(out_json, "w"))
+
+
 def report(prof_dir, cases_json):
     cases = json.load(open(cases_json))
     db = glob.glob(prof_dir + "/**/*.db", recursive=True)[0]
@@ -141,5 +189,7 @@ def report(prof_dir, cases_json):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(sys.argv[2])
+    elif sys.argv[1] == "run_sampler":
+        run_sampler(sys.argv[2])
     else:
         report(sys.argv[2], sys.argv[3])

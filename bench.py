@@ -556,7 +556,7 @@ def main():
                                                           tuple(int(v) for v in loop.engine.resolutions[-1]),
                                                           loop.remesh_intersect, loop.remesh_intersect,
                                                           "ON (project_2d_loss + curve_aware_loss)" if args.curves else "OFF (--no-curves)"),
-                "parallelism": "frame-sharded dp%d, 1 RCCL all-reduce of shared grads / step" % world,
+                "parallelism": "frame-sharded dp%d, three-stream order on every rank; per step: all-reduce of the explicit-vertex gradients, of the curve gradients, and of the shared gradients in two asynchronous buckets" % world,
                 "per_rank_ms_per_step": per_rank_ms,
                 "shared_grad_allreduce_us": allreduce_us,
                 "shared_grad_bytes": int(sum(p.numel() for p in loop.shared_parameters()) * 4),

@@ -42,23 +42,38 @@ def init_distributed(backend: str | None = None):
 class GradAllReduce:
     """Average the .grad of a list of tensors over all ranks with one flattened all-reduce.
     Tensors without a gradient contribute zeros (a rank whose frames produced no valid rays must still take
-    part in the collective)."""
+    part in the collective).
+
+    `start(tensors)` packs the gradients on the CURRENT stream and issues the collective asynchronously (RCCL runs it on the
+    process group's own stream behind the current stream's work); `finish(handle)` makes the current stream wait for it and
+    unpacks.  `__call__` = start + finish.  The loop issues its three exchanges from three streams (explicit vertices: main,
+    curve parameters: curve stream, shared gradients: main, in two buckets around the implicit differentiation), so the staging
+    buffer is per (stream, size): two exchanges in flight never share one.  Every rank issues them in the same host order."""
 
     def __init__(self, world_size: int):
         self.world = world_size
-        self._flat = None
+        self._flat = {}
 
-    def __call__(self, tensors):
+    def _buffer(self, n, dev, dt):
+        key = (torch.cuda.current_stream(dev).cuda_stream if dev.type == 'cuda' else None, dev, dt)
+        pool = self._flat.setdefault(key, {})
+        for buf in pool.values():              # (buffers in flight are marked busy until finish())
+            if not buf[1] and buf[0].numel() >= n:
+                buf[1] = True
+                return buf
+        buf = [torch.empty(n, dtype=dt, device=dev), True]
+        pool[len(pool)] = buf
+        return buf
+
+    def start(self, tensors):
         if self.world <= 1:
-            return
+            return None
         tensors = [t for t in tensors if t.requires_grad]
         if not tensors:
-            return
+            return None
         n = sum(t.numel() for t in tensors)
-        dev, dt = tensors[0].device, tensors[0].dtype
-        if self._flat is None or self._flat.numel() < n or self._flat.device != dev:
-            self._flat = torch.empty(n, dtype=dt, device=dev)
-        flat = self._flat[:n]
+        buf = self._buffer(n, tensors[0].device, tensors[0].dtype)
+        flat = buf[0][:n]
         off = 0
         for t in tensors:
             k = t.numel()
@@ -67,7 +82,14 @@ class GradAllReduce:
             else:
                 flat[off:off + k].copy_(t.grad.reshape(-1))
             off += k
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        return (tensors, flat, work, buf)
+
+    def finish(self, handle):
+        if handle is None:
+            return
+        tensors, flat, work, buf = handle
+        work.wait()                             # (device tensors: the current stream waits, the host does not)
         flat.div_(self.world)
         off = 0
         for t in tensors:
@@ -77,6 +99,10 @@ class GradAllReduce:
             else:
                 t.grad.copy_(flat[off:off + k].view_as(t))
             off += k
+        buf[1] = False
+
+    def __call__(self, tensors):
+        self.finish(self.start(tensors))
 
 
 def broadcast_state(tensors, src=0):

@@ -408,12 +408,14 @@ class HotLoop:
         for prefix, mod in self._modules().items():
             for k, v in mod.state_dict().items():
                 out[prefix + '.' + k] = v
-        for name in self._BUFFERS:                    # the reference registers the SMPL template as buffers (:128-129)
+        for name in self._BUFFERS:
             if getattr(self, name, None) is not None:
                 out[name] = getattr(self, name)
         return out
 
-    _BUFFERS = ('tmpBodyVs', 'tmpBodyFs')
+    # buffers the reference registers on the optimisation object itself: the SMPL template (:128-129) and, once the pre-fit has run,
+    # the body mesh extracted from the pre-fitted SDF (`load_init_sdf_vertices`, :176-178) — both travel in `model_state_dict`
+    _BUFFERS = ('tmpBodyVs', 'tmpBodyFs', 'tmp_sdf_body_vs', 'tmp_sdf_face_vs')
 
     def load_state_dict(self, sd, strict=True):
         missing, unexpected = [], set(sd.keys())
@@ -471,6 +473,17 @@ class HotLoop:
     def shared_parameters(self):
         """Tensors whose gradients are all-reduced across frame-sharded ranks (list 1)."""
         return [p for group in self.optimizer.param_groups for p in group['params']]
+
+    def early_shared_parameters(self):
+        """The shared tensors propagateTmpPsGrad does not touch: the colour net and the per-frame colour codes."""
+        early = [p for p in self.netRender.parameters() if p.requires_grad]
+        rend = getattr(self.dataset, 'rendcond', None)
+        if rend is None and hasattr(self.dataset, 'conds'):
+            rend = self.dataset.conds[1]
+        if rend is not None and rend.requires_grad:
+            early.append(rend)
+        ids = {id(p) for p in self.shared_parameters()}
+        return [p for p in early if id(p) in ids]
 
     # ------------------------------------------------------------------------------------------ MC path
     def discretizeSDF(self, ratio, engine=None, balance_value=0.):
@@ -1008,7 +1021,7 @@ class HotLoop:
         the root finder's shared state (weight-normed weights + transposes, posed skeleton, chain descriptors).  With
         these and the deformed vertices the pipeline runs on side streams underneath the mask loss's large GEMMs instead
         of behind them; the root finder's result is the same (it reads the nets, it does not change them)."""
-        if torch.device(self.device).type != 'cuda' or self.world_size != 1 or os.environ.get('RECMV_SERIAL') == '1':
+        if torch.device(self.device).type != 'cuda' or os.environ.get('RECMV_SERIAL') == '1':
             self._early = None              # RECMV_SERIAL=1: the reference's order on one stream (A/B timing, determinism)
             return
         with torch.no_grad():
@@ -1185,7 +1198,12 @@ class HotLoop:
             self._prepare_rays_early(frame_ids, cameras_rays, ratio)
         opt = global_optimizer if global_optimizer is not None else self.optimizer
         cuda = torch.device(self.device).type == 'cuda'
-        if not (cuda and self.world_size == 1 and os.environ.get('RECMV_SERIAL') != '1'):
+        # The dependency-graph order below is the default on the device — for frame-sharded ranks too: every collective is issued
+        # from the stream whose branch needs it (vertices: main, curves: curve stream, shared gradients: main after the backward),
+        # in the same host order on every rank.  RECMV_OVERLAP_ORDER=1 runs that ORDER on the host as well (no streams there:
+        # tests/test_loop_cpu.py compares it with the serial order for world size 2).
+        overlap = os.environ.get('RECMV_SERIAL') != '1' and (cuda or os.environ.get('RECMV_OVERLAP_ORDER') == '1')
+        if not overlap:
             # ---- the reference's order, one phase after the other
             if self.curves:
                 with self._phase('curves'):
@@ -1215,33 +1233,39 @@ class HotLoop:
             # The mask loss's large GEMMs go to the main stream first; the two chains of small launches run beside them
             # on side streams; the final backward runs every node on the stream of its forward.  Same arithmetic, same
             # random draws in the same host order: bit-identical to the serial order (tools/determinism_probe.py).
-            main = torch.cuda.current_stream(self.device)
-            if getattr(self, '_surface_stream', None) is None:
-                self._surface_stream = torch.cuda.Stream(device=self.device)
-            if getattr(self, '_curve_stream', None) is None:
-                self._curve_stream = torch.cuda.Stream(device=self.device)
-            s_ray, s_curve = self._surface_stream, self._curve_stream
+            if cuda:
+                main = torch.cuda.current_stream(self.device)
+                if getattr(self, '_surface_stream', None) is None:
+                    self._surface_stream = torch.cuda.Stream(device=self.device)
+                if getattr(self, '_curve_stream', None) is None:
+                    self._curve_stream = torch.cuda.Stream(device=self.device)
+                s_ray, s_curve = self._surface_stream, self._curve_stream
+                on = torch.cuda.stream
+            else:                                            # the same order on the host: one queue, nothing to wait for
+                main = s_ray = s_curve = _NoStream()
+                on = lambda s_: contextlib.nullcontext()
             opt.zero_grad()              # (:1934) nothing of the curve branch lands on the shared gradients any more
             with self._phase('mask_loss'):
                 self.mask_loss(N, frame_ids, ratio, cameras, defer_sdf_terms=True)
-            with torch.cuda.stream(s_ray):
+            with on(s_ray):
                 with self._phase('sample_rays'):
                     samples = self.sample_train_ray(N, frame_ids, cameras_rays)            # waits for the deformation only
-            with torch.cuda.stream(s_ray), self._phase('root_find'):
+            with on(s_ray), self._phase('root_find'):
                 init_ps_list, checks = self.opt_garment_surface_ps(frame_ids, cameras_rays, ratio, samples)
             curve_done = None
             if self.curves:
-                with torch.cuda.stream(s_curve), self._phase('curves'):
+                with on(s_curve), self._phase('curves'):
                     s_curve.wait_event(self._surface_ready)
                     self.project_2d_loss(N, frame_ids, ratio, cameras)                       # :1932
-                    curve_done = torch.cuda.Event()
-                    curve_done.record()
+                    if cuda:
+                        curve_done = torch.cuda.Event()
+                        curve_done.record()
             with self._phase('pc_sdf'):
                 if curve_done is not None:
                     main.wait_event(curve_done)          # curve_aware_loss reads the curves after their AdamW step
                 total_loss = total_loss + self.pc_sdf_terms(ratio)
-            with torch.cuda.stream(s_ray), self._phase('render_loss_fwd'):
-                s_ray.wait_event(self._sgd_done)
+            with on(s_ray), self._phase('render_loss_fwd'):
+                s_ray.wait_event(getattr(self, '_sgd_done', None))
                 render_loss = self.surface_render_loss(N, cameras_rays, frame_ids, ratio, checks, init_ps_list, samples)
             main.wait_stream(s_ray)
             total_loss = total_loss + render_loss
@@ -1365,11 +1389,24 @@ class HotLoop:
         loss = HotLoop.forward(self, frame_ids, ratio)      # (the facade subclass overrides forward(datas, ...))
         with self._phase('backward'):
             loss.backward()
+        pending = []
+        if allreduce is not None and hasattr(allreduce, 'start'):
+            # the colour net and the per-frame colour codes are final after the backward (the implicit differentiation below adds to
+            # the SDF nets, the deformer, the deformation codes, poses / translations and the camera only, :2269-2313): their
+            # all-reduce travels while propagateTmpPsGrad runs
+            early = self.early_shared_parameters()
+            pending.append(allreduce.start(early))
         with self._phase('propagate'):
             self.propagateTmpPsGrad(frame_ids, ratio)
         with self._phase('allreduce+adam'):
             if allreduce is not None:
-                allreduce([p for p in self.shared_parameters()])
+                if pending:
+                    ids = {id(p) for p in early}
+                    pending.append(allreduce.start([p for p in self.shared_parameters() if id(p) not in ids]))
+                    for h in pending:
+                        allreduce.finish(h)
+                else:
+                    allreduce([p for p in self.shared_parameters()])
             self.optimizer.step()
         self.opt_times += 1.
         return loss.detach(), self.info['rays_total']
@@ -1396,6 +1433,16 @@ class FrameLoader:
         for pos in range(len(self)):
             frame_ids = self.loop.frame_batch_at(self.epoch, pos)
             yield frame_ids, self.dataset.get_batch(frame_ids, self.loop.mask_keys)
+
+
+class _NoStream:
+    """Stands in for a HIP stream where there is none (the dependency-graph order on the host)."""
+
+    def wait_event(self, ev):
+        pass
+
+    def wait_stream(self, other):
+        pass
 
 
 def fan_mesh(curve_pts):

@@ -93,22 +93,39 @@ class CaptureLoader:
         return self.loop.batch_size
 
     def __len__(self):
-        per_it = self.loop.batch_size * self.loop.world_size
-        return (len(self.dataset) + per_it - 1) // per_it
+        from recmv.loop import iters_per_epoch
+        return iters_per_epoch(len(self.dataset), self.loop.batch_size, self.loop.world_size)
+
+    def rank_batches(self, order, rank=None):
+        """This rank's frame indices per position of the epoch.  The permutation is cut into len(self) positions of
+        batch_size * world_size frames and every rank takes its round-robin share of EACH position (HotLoop.frame_batch_at), so
+        all ranks yield exactly len(self) batches — every iteration holds three collectives, a rank that ran one batch more or
+        less than its peers would hang them or pair them with the next epoch's.  The last position holds the remaining frames;
+        when those are fewer than the ranks the permutation wraps so that nobody is left without a frame."""
+        rank = self.loop.rank if rank is None else rank
+        world, bs = self.loop.world_size, self.loop.batch_size
+        per_it = bs * world
+        out = []
+        for pos in range(len(self)):
+            ids = order[pos * per_it:(pos + 1) * per_it]
+            if len(ids) < world:
+                ids = ids + order[:world - len(ids)]
+            out.append(ids[rank::world][:bs])
+        return out
 
     def __iter__(self):
         import random
 
         import torch
         from recmv.dataset import RandomSampler
+        py_state, state = random.getstate(), torch.random.get_rng_state()
         random.seed(1234 + self.epoch)
-        state = torch.random.get_rng_state()
         torch.manual_seed(1234 + self.epoch)
         order = list(iter(RandomSampler(self.dataset, 1, True)))
         torch.random.set_rng_state(state)
-        mine = order[self.loop.rank::self.loop.world_size]
-        loader = torch.utils.data.DataLoader(torch.utils.data.Subset(self.dataset, mine), self.loop.batch_size,
-                                             shuffle=False, num_workers=0)
+        random.setstate(py_state)                    # (the caller's Python generator is left where it was)
+        batches = self.rank_batches(order)
+        loader = torch.utils.data.DataLoader(self.dataset, batch_sampler=batches, num_workers=0)
         return iter(loader)
 
 
@@ -230,6 +247,12 @@ def main(argv=None, large_pose=False):
                                          a_pose=bool(getattr(args, 'a_pose', False)))
         for t in capture.conds + [capture.poses, capture.trans, capture.shape] + list(capture.camera_params.values()):
             t.data = t.data.to(device)            # the reference keeps these on the host and moves batches per call
+    # The start-up stage (first-run skinner bake, SDF pre-fit, feature-line registration) draws unsynchronised random numbers and
+    # leaves files other ranks would read half-written: rank 0 runs it FIRST, the other ranks wait at a barrier and then find the
+    # stored files (initial_skinner_*.pth, initial_sdf_*.pth, fl_init/init_trans_matrix.pth) like any later run does.
+    staged = world > 1 and capture is not None
+    if staged and rank != 0:
+        rdist.barrier()
     # train.py:170-171 (bmins / bmaxs None: the canonical box is sized from the initial surfaces)
     optNet, sdf_initialized = getOptNet(capture, args.save_folder, batch_size, None, None, resolutions['coarse'], device,
                                         config, opt_large=large_pose, n_frames=args.frames, H=512, W=512,
@@ -242,12 +265,15 @@ def main(argv=None, large_pose=False):
         from recmv.utils.constant import FL_INFOS
         register_feature_lines(optNet, dataloader, load_fl_templates(args.fl_templates, FL_INFOS[optNet.garment_type], device),
                                save_root)
+    if staged and rank == 0:
+        rdist.barrier()
     if rank == 0:                                 # train.py:86: wandb when it is there, a jsonl file under logs/ otherwise
         from recmv.engineer.visualizer import wandb_visualizer
         optNet.visualizer = wandb_visualizer(args.project_name, args.exp_name, resume=False, log_dir=osp.join(save_root, 'logs'))
     optNet, dataloader = utils.set_hierarchical_config(config, 'coarse', optNet, dataloader, resolutions['coarse'])
     rdist.broadcast_state([p for p in optNet.shared_parameters()] + list(optNet.sdf.parameters())
-                          + (list(optNet.inter_free_curve.parameters()) if optNet.curves else []))
+                          + (list(optNet.inter_free_curve.parameters()) + list(optNet.inter_free_curve.buffers())
+                             if optNet.curves else []))
     allreduce = rdist.GradAllReduce(world) if world > 1 else None
     optNet._allreduce = allreduce                 # the explicit-vertex and curve gradients are shared inside forward
     optNet.train()

@@ -192,6 +192,25 @@ def test_capture_loader_deals_an_epoch_over_ranks(capture):
         assert sorted(per_rank[0] + per_rank[1]) == list(range(cf.FRAMES)) and not set(per_rank[0]) & set(per_rank[1])
         seen[epoch] = per_rank
     assert seen[0] != seen[1]
+    # every rank yields the SAME number of batches whatever the frame count (each iteration holds three collectives): the advisor's
+    # case F = 649, 8 ranks, batch 3 dealt 28 / 27 iterations before; the Python generator of the caller is left alone
+    import random
+    for F, world, bs in ((649, 8, 3), (13, 2, 6), (5, 8, 3), (48, 8, 3)):
+        order = list(range(F))
+        counts, union = set(), []
+        for rank in range(world):
+            cl = train.CaptureLoader(list(range(F)), types.SimpleNamespace(batch_size=bs, world_size=world, rank=rank))
+            batches = cl.rank_batches(order)
+            assert all(1 <= len(b) <= bs for b in batches), (F, world, bs, rank)
+            counts.add(len(batches))
+            assert len(batches) == len(cl)
+            union += [i for b in batches for i in b]
+        assert len(counts) == 1 and set(union) == set(range(F)), (F, world, bs)
+        assert len(union) == F or F % (world * bs) < world            # (only a wrapped last position repeats frames)
+    random.seed(5)
+    want = random.Random(5).random()
+    list(train.CaptureLoader(ds, types.SimpleNamespace(batch_size=2, world_size=1, rank=0)))
+    assert random.random() == want
 
 
 @pytest.mark.parametrize("a_pose", [False, True])

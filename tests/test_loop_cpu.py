@@ -212,9 +212,9 @@ def test_frame_sharding_is_a_partition():
         cpu_port.uninstall()
 
 
-def _dp_worker(rank, world, port, out_dir):
+def _dp_worker(rank, world, port, out_dir, order="serial"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
+                      LOCAL_RANK=str(rank), RECMV_OVERLAP_ORDER="1" if order == "overlap" else "0")
     for p in (REPO / "rec-mv_amd", REPO):
         if str(p) not in sys.path:
             sys.path.insert(0, str(p))
@@ -227,6 +227,13 @@ def _dp_worker(rank, world, port, out_dir):
     rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters())
                           + list(loop.inter_free_curve.parameters()) + list(loop.inter_free_curve.buffers()))
     allreduce = rdist.GradAllReduce(w)
+    # the curve-aware disc draws its samples from a generator of its own: on the host the loop's other draws (ray subset, eikonal
+    # points) share ONE generator with it, and the two orders reach the disc at different positions of that stream (on the
+    # device the ray subset comes from the host generator and the rest from the device's, in the same order either way)
+    from recmv.loop import HotLoop, sample_fan_mesh
+    gen = torch.Generator().manual_seed(77)
+    loop.curve_aware_loss = lambda ratio: HotLoop.curve_aware_loss(
+        loop, ratio, sampler=lambda v, f, n: sample_fan_mesh(v, f, 4000, generator=gen))
     for it in range(2):
         loop.step(it, allreduce)
     flat = torch.cat([p.detach().reshape(-1) for p in loop.shared_parameters()])
@@ -247,6 +254,53 @@ def test_data_parallel_world2_gloo(tmp_path):
     assert torch.equal(a["params"], b["params"]), "shared parameters diverged across ranks"
     assert torch.equal(a["verts"], b["verts"]), "MC vertices diverged across ranks (needs deterministic MC order)"
     assert torch.equal(a["curves"], b["curves"]), "feature-curve parameters diverged across ranks"
+
+
+def test_overlapped_order_equals_serial_order_world2_gloo(tmp_path):
+    """The dependency-graph order of an iteration (mask loss -> ray pipeline -> curve branch -> |SDF| terms -> render loss; on the
+    device: three streams) with its three exchanges — explicit vertices, curve parameters, shared gradients in two asynchronous
+    buckets around the implicit differentiation — issued in that order on both ranks, against the reference's serial order: after
+    two optimiser steps the shared parameters, the explicit vertices and the curve parameters are bit-identical between the
+    orders and between the ranks."""
+    import torch.multiprocessing as mp
+    out = {}
+    for k, order in enumerate(("serial", "overlap")):
+        d = tmp_path / order
+        d.mkdir()
+        mp.spawn(_dp_worker, args=(2, 29500 + ((os.getpid() + 7 * (k + 1)) % 1000), str(d), order), nprocs=2, join=True)
+        out[order] = [torch.load(d / "rank0.pt"), torch.load(d / "rank1.pt")]
+        for key in ("params", "verts", "curves"):
+            assert torch.equal(out[order][0][key], out[order][1][key]), (order, key)
+    for key in ("params", "verts", "curves"):
+        assert torch.equal(out["serial"][0][key], out["overlap"][0][key]), key
+
+
+def test_grad_allreduce_start_finish_two_in_flight(tmp_path):
+    """Two exchanges in flight at once (start, start, finish, finish) use two staging buffers and leave the averages."""
+    import torch.multiprocessing as mp
+    mp.spawn(_two_in_flight_worker, args=(2, 29500 + ((os.getpid() + 31) % 1000)), nprocs=2, join=True)
+
+
+def _two_in_flight_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    for p in (REPO / "rec-mv_amd", REPO):
+        if str(p) not in sys.path:
+            sys.path.insert(0, str(p))
+    from recmv import dist as rdist
+    r, _, w = rdist.init_distributed("gloo")
+    a, b, c = (torch.nn.Parameter(torch.zeros(n)) for n in (5, 7, 3))
+    a.grad, b.grad = torch.full((5,), float(r)), torch.full((7,), 10.0 + r)        # c has no gradient on either rank
+    ar = rdist.GradAllReduce(w)
+    h1 = ar.start([a])
+    h2 = ar.start([b, c])
+    assert h1[1].data_ptr() != h2[1].data_ptr()
+    ar.finish(h1)
+    ar.finish(h2)
+    assert torch.equal(a.grad, torch.full((5,), 0.5)) and torch.equal(b.grad, torch.full((7,), 10.5)) and torch.equal(c.grad, torch.zeros(3))
+    ar([a])                                          # the buffers are free again
+    assert torch.equal(a.grad, torch.full((5,), 0.5)) and sum(len(p) for p in ar._flat.values()) == 2
+    rdist.barrier()
+    torch.distributed.destroy_process_group()
 
 
 def test_grad_allreduce_handles_missing_grads_single_process():

@@ -144,6 +144,13 @@ def test_prefit_files_carry_the_reference_names_and_are_loaded_back(tmp_path):
         v, f = read_ply(os.path.join(save_root, names[0] + '.ply'))
         assert torch.equal(again.tmp_sdf_body_vs, v) and torch.equal(again.tmp_sdf_face_vs, f.float())
         assert torch.equal(v, optNet.tmp_sdf_body_vs.cpu()) and int(f.max()) < v.shape[0] and f.shape[0] > 0
+        # ... and travels in the checkpoint like the reference's registered buffers (OptimGarmentNetwork.py:176-178)
+        sd = again.state_dict()
+        assert torch.equal(sd['tmp_sdf_body_vs'], v) and torch.equal(sd['tmp_sdf_face_vs'], f.float())
+        fresh, _ = getOptNet(ds, None, 3, box[0], box[1], res, 'cpu', conf, curves=False, skin_grid=(5, 9, 7))
+        assert getattr(fresh, 'tmp_sdf_body_vs', None) is None
+        fresh.load_state_dict(sd, strict=False)
+        assert torch.equal(fresh.tmp_sdf_body_vs, v)
     finally:
         cpu_port.uninstall()
 

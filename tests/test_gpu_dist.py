@@ -31,7 +31,8 @@ def _worker(rank, world, port, out_dir, backend="nccl", serial=False):
     conf = ConfigFactory.parse_file(CONF)
     conf.put('train.sample_pix_num', 256)
     loop = HotLoop(conf, dev, n_frames=12, H=160, W=128, resolutions=[(9, 13, 7), (17, 25, 13), (33, 49, 25), (65, 97, 49)],
-                   skin_grid=(17, 33, 17), world_size=w, rank=r, seed=r, curves=True)    # different seeds: broadcast aligns
+                   skin_grid=(17, 33, 17), world_size=w, rank=r, seed=r, curves=True,    # different seeds: broadcast aligns
+                   bbox=((-0.85, -1.2, -0.85), (0.85, 1.2, 0.85)))      # (the default box is sized from the rank's OWN initial nets)
     rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters())
                           + list(loop.inter_free_curve.parameters()) + list(loop.inter_free_curve.buffers()))
     allreduce = rdist.GradAllReduce(w)

@@ -21,8 +21,10 @@ per-step split and the rate at the reference's cadence).
 Extra objects on the line:
   roofline     — the dominant kernel (gemm_nt, the fused MFMA layer): algorithmic FLOPs of every launch in the
                  timed region / their HIP-event durations (events recorded on the stream each kernel is launched on)
-                 against the dense f32 MFMA peak (157.3 TFLOP/s); `traffic` = HBM bytes per launch from the committed
-                 rocprofv3 PMC passes over this same loop (profiles/r02_pmc_loop.json, FETCH_SIZE x2 per the guide).
+                 against the dense f32 MFMA peak (157.3 TFLOP/s); `traffic` = HBM bytes per launch from the newest committed
+                 rocprofv3 PMC passes over this same loop (profiles/r*_pmc_loop.json, FETCH_SIZE x2 per the guide;
+                 `traffic_source` names the file and the commit it measured — a constant, not a measurement of this run).
+  config2      — BASELINE configs[2] as its own measured leg: 257^3 pyramid, Seg3dLossless + MC every step.
   hbm_kernels  — the HBM-bound kernels at the loop's shapes, each timed with HIP events around a captured hipGraph of
                  identical launches (kernel time + the ~1.5 us dependent-launch gap; no Python between launches).
   remesh       — per-step GPU times from events recorded at the step boundaries of the timed region.
@@ -325,23 +327,72 @@ def hbm_kernel_block(loop, device):
 
 
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` in this loop, from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_loop.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of `bench.py`, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_loop.py produced it)."""
-    f = REPO / "profiles" / "r02_pmc_loop.json"
-    if not f.exists():
+    """HBM bytes per launch of `kernel_name` in this loop, from the newest committed rocprofv3 PMC passes over `bench.py` itself
+    (profiles/r*_pmc_loop.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950; tools/pmc_loop.py produced it and stamped the commit it measured).  Counters cannot be collected inside the timed
+    run (a PMC pass serialises the kernels), so the figure is a constant of the commit named in `traffic_source`, not of this run."""
+    files = sorted((REPO / "profiles").glob("r*_pmc_loop.json"))
+    if not files:
         return None
+    f = files[-1]
     try:
         table = json.loads(f.read_text())
     except ValueError:
         return None
+    stamp = "profiles/%s (%s)" % (f.name, table.get("measured_at", "round-2 passes of 13:13, before the batching / mulgrad / "
+                                                                 "gemm_tn changes; commit not recorded"))
     # bench names the variant by <T, FAST, AMUL>; the kernel's 4th template argument is the matrix mode (BF3)
     want = kernel_name.split(" ")[0].rstrip(">")
     mode = ", true>" if "bf16x6" in kernel_name else ", false>"
     for k, v in table.get("kernels", {}).items():
         if k.startswith(want) and (k.endswith(mode) or "<" not in k):
-            return v
+            return dict(v, traffic_source=stamp)
     return None
+
+
+def config2_leg(loop, it, allreduce, world, device, steps=6):
+    """BASELINE configs[2] as a measured workload of its own: the SAME iteration with the reference's `resolutions_higher` pyramid
+    (33^3 -> 257^3, train.py:73-79) and a re-mesh — Seg3dLossless for the body and both garment nets + marching cubes — at the
+    start of EVERY step (remesh_intersect = 1).  Every iteration then works on freshly extracted meshes (the state right after a
+    re-mesh, where nearly all rays converge).  One untimed step, then `steps` steps between barriers; max over ranks."""
+    import torch.distributed as tdist
+    from recmv import dist as rdist
+    from recmv.MCAcc import Seg3dLossless
+    from recmv.loop import RESOLUTIONS
+    old_engine, old_period = loop.engine, loop.remesh_intersect
+    loop.engine = Seg3dLossless(query_func=None, b_min=old_engine.b_min.view(-1).tolist(), b_max=old_engine.b_max.view(-1).tolist(),
+                                resolutions=RESOLUTIONS['higher256'], align_corners=False, balance_value=0.0, use_cuda_impl=True,
+                                faster=False).to(device)
+    loop.remesh_intersect = 1
+    n = 0
+    try:
+        loop.step(it + n, allreduce)
+        n += 1
+        rdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rays = conv = 0
+        for _ in range(steps):
+            _, r = loop.step(it + n, allreduce)
+            n += 1
+            rays += int(r)
+            conv += sum(loop.info.get('rays_converged', []))
+        torch.cuda.synchronize()
+        rdist.barrier()
+        dt = time.perf_counter() - t0
+        verts = [int(v.shape[0]) for v in loop.garment_vs]
+    finally:
+        loop.engine, loop.remesh_intersect = old_engine, old_period
+        loop.forward_time = 0                       # the next step of the caller re-meshes on its own pyramid again
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        dt = float(t[0])
+    return {"workload": "configs[2]: the same iteration with the 33^3 -> 257^3 pyramid and Seg3dLossless + marching cubes for the "
+                        "body and both garment nets at the start of EVERY step (remesh_intersect = 1)",
+            "steps": steps, "value": round(steps * world / dt, 4), "unit": "iters/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "mc_vertices": verts, "rays_per_iter": round(rays / steps, 1),
+            "rays_converged_fraction": round(conv / max(rays, 1), 4), "_steps_run": n}
 
 
 def whole_step_matrix_rate(roofline, steps, ms_per_step):
@@ -385,6 +436,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the MFMA kernel launches with HIP events (no roofline object)")
     ap.add_argument("--no-hbm-kernels", action="store_true", help="skip the hbm_kernels block")
+    ap.add_argument("--no-config2", action="store_true",
+                    help="skip the second workload leg (BASELINE configs[2]: 257^3 Seg3dLossless + marching cubes every step)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--state", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--conf", default=str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
@@ -439,6 +492,7 @@ def main():
     if getattr(loop, "phase_ms", None):
         loop.phase_ms = {}          # RECMV_TIMING=1: report the timed steps only
     rays = 0
+    rays_local = 0
     converged = 0
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     remesh_steps = []
@@ -452,6 +506,7 @@ def main():
         _, r = loop.step(it, allreduce)
         marks[k + 1].record()
         rays += int(r)
+        rays_local += int(r)
         converged += sum(loop.info.get('rays_converged', []))     # host ints the loop's own gate read back
         it += 1
         if it % 5 == 0:
@@ -504,6 +559,10 @@ def main():
             gs_serial = prof.end()
         finally:
             del os.environ["RECMV_SERIAL"]
+    leg2 = None
+    if not args.no_config2:
+        leg2 = config2_leg(loop, it, allreduce, world, device)
+        it += leg2.pop("_steps_run")
     per_rank_ms, allreduce_us = None, None
     if world > 1:
         mine = elapsed
@@ -547,6 +606,7 @@ def main():
                                            "accumulate; same parity tolerances as f32)"),
             "data": "synthetic",
             "rays_per_sec": round(rays / elapsed, 1),
+            "rays_converged_fraction": round(converged / max(rays_local, 1), 4),
             "config": {
                 "workload": "configs[1]: PeopleSnapshot female-3-casual-like, 512x512, frames_per_step=%d per GPU, "
                             "2 garments, sample_pix_num=%d, stage=%s pyramid %s, remesh every %d iters (at least one "
@@ -576,6 +636,7 @@ def main():
                                           args.gemm_mode + ")",
                                 "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": MFMA_F32_PEAK / 1e12,
                                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), "traffic": tr.get("traffic_bytes_per_launch") if tr else None,
+                                "traffic_source": tr.get("traffic_source") if tr else None,
                                 "traffic_detail": tr,
                                 "launches": g["launches"], "avg_launch_us": round(g["avg_us"], 2),
                                 "avg_launch_gflop": round(g["avg_flops"] / 1e9, 3),
@@ -613,6 +674,8 @@ def main():
                         "in %d steps, the reference's cadence is 1 in %d" % (len(with_r), args.steps, period)}
         if alt:
             line["alt_mode"] = alt
+        if leg2:
+            line["config2"] = leg2
         log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
         if getattr(loop, "phase_ms", None):
             log("phase ms (RECMV_TIMING=1, timed steps only): " + json.dumps({k: round(v, 1) for k, v in loop.phase_ms.items()}))
@@ -621,6 +684,10 @@ def main():
             log("MC extraction timing done")
         if not args.no_hbm_kernels:
             line["hbm_kernels"] = hbm_kernel_block(loop, device)
+            mc257 = [k for k in line["hbm_kernels"] if k["kernel"].startswith("marching cubes 257x257x257")]
+            if mc257 and "mc_only_roofline" in line:           # the wall figure above keeps mc_gpu's counter read-back
+                line["mc_only_roofline"]["kernel_only"] = {"us": mc257[0]["us"], "achieved": mc257[0]["achieved_gbs"],
+                                                           "frac": mc257[0]["frac"], "timing": mc257[0]["timing"]}
             log("HBM kernel block done")
         if world == 1 and not args.no_cpu_baseline:
             import tempfile

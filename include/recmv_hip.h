@@ -206,6 +206,15 @@ int recmv_gemm_nt_actgrad(const float* G, int64_t ldg, const float* Y, int64_t l
 int recmv_gemm_nt_mulgrad(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                           int64_t N, int64_t K, const float* Y, int64_t ldy, int act, float act_param, float y_scale,
                           float scale, void* stream);
+/* recmv_gemm_nt / recmv_gemm_nt_mulgrad over a row block that holds the rows of TWO nets of one shape (the two garments' SDF nets
+ * in the surface root finder, utils/FindSurfacePs.py:273-353: one launch per layer for both): rows [0, split_row) multiply by
+ * B (+ bias), rows [split_row, M) by B2 (+ bias2).  split_row must be a multiple of 128; B2 == NULL is the plain product. */
+int recmv_gemm_nt_seg(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* B2,
+                      const float* bias2, int64_t split_row, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
+                      float act_param, float out_scale, void* stream);
+int recmv_gemm_nt_mulgrad_seg(const float* A, int64_t lda, const float* B, const float* B2, int64_t split_row, int64_t ldb,
+                              float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const float* Y, int64_t ldy, int act,
+                              float act_param, float y_scale, float scale, void* stream);
 /* Matrix mode of recmv_gemm_nt (and everything built on it): 0 = f32-input MFMA, the default — bit-for-bit an f32
  * fma chain; 1 = "bf16x6": every f32 operand element is split into three bf16 pieces in registers and each tile step
  * issues the six bf16 MFMA products of weight >= 2^-18 with f32 accumulation (f32-level accuracy, up to 2.7x the f32
@@ -281,6 +290,12 @@ typedef struct recmv_mlp {
   const float* Wt[RECMV_MLP_MAX_LAYERS];
   const float* bias[RECMV_MLP_MAX_LAYERS];
   float pe_weights[32];
+  /* optional second net of the same shape (ABI v5): rows [split_row, P) of a call use W2 / Wt2 / bias2 — the rows of two garments'
+   * SDF nets evaluated as one block (recmv_gemm_nt_seg).  split_row = 0 or W2[0] == NULL: one net.  A multiple of 128. */
+  const float* W2[RECMV_MLP_MAX_LAYERS];
+  const float* Wt2[RECMV_MLP_MAX_LAYERS];
+  const float* bias2[RECMV_MLP_MAX_LAYERS];
+  int64_t split_row;
 } recmv_mlp;
 
 /* keep = 1 lays every layer's activation out separately (needed by recmv_mlp_vjp_input); keep = 0 ping-pongs. */

@@ -117,6 +117,11 @@ struct AMul {
   int64_t ldy;
   int act;
   float param, y_scale, a_scale;
+  // row-segmented weights (recmv_gemm_nt_seg): tiles whose first row is >= split multiply by B2 (+ bias2) instead of B (+ bias) —
+  // two nets of one shape over one concatenated row block in one launch; split is a multiple of every tile height (128)
+  const float* B2;
+  const float* bias2;
+  int split;
 };
 
 __device__ __forceinline__ float4 amul4(float4 a, float4 y, const AMul& m) {
@@ -233,6 +238,10 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
   const int64_t logical = xcd_remap(blockIdx.x, (int64_t)nbm * nbn);
   const int tile_m = (int)(logical / nbn), tile_n = (int)(logical % nbn);
   const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+  if (am.B2 && m0 >= am.split) {              // second weight set for the rows of the second net (see AMul)
+    B = am.B2;
+    bias = am.bias2;
+  }
 
   f32x16 acc[T][T];
 #pragma unroll
@@ -417,6 +426,10 @@ __global__ __launch_bounds__(kBlk, 2) void gemm_nt_b3_kernel(const float* __rest
   const int64_t logical = xcd_remap(blockIdx.x, (int64_t)nbm * nbn);
   const int tile_m = (int)(logical / nbn), tile_n = (int)(logical % nbn);
   const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+  if (am.B2 && m0 >= am.split) {              // second weight set for the rows of the second net (see AMul)
+    B = am.B2;
+    bias = am.bias2;
+  }
 
   f32x16 acc[T][T];
 #pragma unroll
@@ -656,6 +669,10 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_narrow_kernel(const float* __res
   const int64_t logical = xcd_remap(blockIdx.x, (int64_t)nbm * nbn);
   const int tile_m = (int)(logical / nbn), tile_n = (int)(logical % nbn);
   const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+  if (am.B2 && m0 >= am.split) {              // second weight set for the rows of the second net (see AMul)
+    B = am.B2;
+    bias = am.bias2;
+  }
 
   f32x16 acc;
 #pragma unroll
@@ -1146,7 +1163,7 @@ static int dispatch_nt(const float* A, int64_t lda, const float* B, int64_t ldb,
                        int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
                        const AMul& am, hipStream_t s) {
   const bool a_vec = aligned16(A) && lda % 4 == 0 && (!AMUL || (aligned16(am.Y) && am.ldy % 4 == 0));
-  const bool b_vec = aligned16(B) && ldb % 4 == 0;
+  const bool b_vec = aligned16(B) && ldb % 4 == 0 && (!am.B2 || aligned16(am.B2));
   const bool c_vec = aligned16(C) && ldc % 4 == 0;
   const bool fast = a_vec && b_vec && K % 4 == 0 && K > 0;
   // tile choice: 128x128 tiles unless they would leave the 256 CUs under-filled (< 2 workgroups per CU)
@@ -1227,6 +1244,37 @@ extern "C" int recmv_gemm_nt_mulgrad(const float* A, int64_t lda, const float* B
   RECMV_REQUIRE(M < (1ll << 31) - BM && N < (1ll << 31) - BN && K < (1ll << 31) - BK, "gemm_nt_mulgrad: size overflow");
   RECMV_REQUIRE(act >= RECMV_ACT_NONE && act <= RECMV_ACT_TANH, "gemm_nt_mulgrad: unknown activation %d", act);
   AMul em = {Y, ldy, act, act_param, y_scale, scale};
+  return dispatch_nt<false>(A, lda, B, ldb, nullptr, C, ldc, M, N, K, RECMV_ACT_NONE, 0.f, 1.f, em, (hipStream_t)stream);
+}
+
+// The same products over a row block that holds the rows of TWO nets of one shape: rows [0, split_row) use B / bias, rows
+// [split_row, M) use B2 / bias2 (split_row a multiple of 128, the largest tile height; B2 == NULL: the plain product).
+extern "C" int recmv_gemm_nt_seg(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+                                 const float* B2, const float* bias2, int64_t split_row, float* C, int64_t ldc, int64_t M,
+                                 int64_t N, int64_t K, int act, float act_param, float out_scale, void* stream) {
+  RECMV_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_nt_seg: negative size");
+  if (M == 0 || N == 0) return RECMV_OK;
+  RECMV_REQUIRE(A && B && C, "gemm_nt_seg: NULL pointer");
+  RECMV_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_nt_seg: leading dimension too small");
+  RECMV_REQUIRE(M < (1ll << 31) - BM && N < (1ll << 31) - BN && K < (1ll << 31) - BK, "gemm_nt_seg: size overflow");
+  RECMV_REQUIRE(act >= RECMV_ACT_NONE && act <= RECMV_ACT_TANH, "gemm_nt_seg: unknown activation %d", act);
+  RECMV_REQUIRE(!B2 || (split_row >= 0 && split_row % BM == 0), "gemm_nt_seg: split_row must be a multiple of %d", BM);
+  RECMV_REQUIRE(!B2 || !bias == !bias2, "gemm_nt_seg: both nets with or both without a bias");
+  AMul am = {nullptr, 0, RECMV_ACT_NONE, 0.f, 1.f, 1.f, B2, bias2, (int)(split_row < M ? split_row : M)};
+  return dispatch_nt<false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, am, (hipStream_t)stream);
+}
+
+extern "C" int recmv_gemm_nt_mulgrad_seg(const float* A, int64_t lda, const float* B, const float* B2, int64_t split_row,
+                                         int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const float* Y,
+                                         int64_t ldy, int act, float act_param, float y_scale, float scale, void* stream) {
+  RECMV_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_nt_mulgrad_seg: negative size");
+  if (M == 0 || N == 0) return RECMV_OK;
+  RECMV_REQUIRE(A && B && C && Y, "gemm_nt_mulgrad_seg: NULL pointer");
+  RECMV_REQUIRE(lda >= K && ldb >= K && ldc >= N && ldy >= N, "gemm_nt_mulgrad_seg: leading dimension too small");
+  RECMV_REQUIRE(M < (1ll << 31) - BM && N < (1ll << 31) - BN && K < (1ll << 31) - BK, "gemm_nt_mulgrad_seg: size overflow");
+  RECMV_REQUIRE(act >= RECMV_ACT_NONE && act <= RECMV_ACT_TANH, "gemm_nt_mulgrad_seg: unknown activation %d", act);
+  RECMV_REQUIRE(!B2 || (split_row >= 0 && split_row % BM == 0), "gemm_nt_mulgrad_seg: split_row must be a multiple of %d", BM);
+  AMul em = {Y, ldy, act, act_param, y_scale, scale, B2, nullptr, (int)(split_row < M ? split_row : M)};
   return dispatch_nt<false>(A, lda, B, ldb, nullptr, C, ldc, M, N, K, RECMV_ACT_NONE, 0.f, 1.f, em, (hipStream_t)stream);
 }
 

@@ -134,7 +134,17 @@ int check_desc(const recmv_mlp* m) {
     RECMV_REQUIRE(m->rows[l] == expect, "mlp: layer %d has %d rows, expected %d", l, m->rows[l], expect);
   }
   RECMV_REQUIRE(m->skip_layer < m->n_layers, "mlp: bad skip layer");
+  if (m->split_row > 0 && m->W2[0]) {
+    RECMV_REQUIRE(m->split_row % 128 == 0, "mlp: split_row %lld is not a multiple of 128", (long long)m->split_row);
+    for (int l = 0; l < m->n_layers; ++l)
+      RECMV_REQUIRE(m->W2[l] && (!m->bias[l] == !m->bias2[l]), "mlp: the second net's layer %d is incomplete", l);
+  }
   return RECMV_OK;
+}
+
+// rows [split, P) of this call belong to the second net (0: there is none)
+inline int64_t second_net_from(const recmv_mlp* m, int64_t P) {
+  return (m->split_row > 0 && m->W2[0] && m->split_row < P) ? m->split_row : 0;
 }
 
 }  // namespace
@@ -222,18 +232,21 @@ extern "C" int recmv_mlp_forward(const recmv_mlp* m, const float* x, const float
   }
   const float* h = in;
   int64_t ldh = L.ld_in;
+  const int64_t split = second_net_from(m, P);
   for (int l = 0; l < n; ++l) {
     const bool last = l == n - 1;
+    const float* W2 = split ? m->W2[l] : nullptr;
+    const float* b2 = split ? m->bias2[l] : nullptr;
     if (last) {
-      RECMV_TRY(recmv_gemm_nt(h, ldh, m->W[l], m->dims[l], m->bias[l], out, ldo, P, n_out, m->dims[l], RECMV_ACT_NONE,
-                              0.f, 1.f, stream));
+      RECMV_TRY(recmv_gemm_nt_seg(h, ldh, m->W[l], m->dims[l], m->bias[l], W2, b2, split, out, ldo, P, n_out, m->dims[l],
+                                  RECMV_ACT_NONE, 0.f, 1.f, stream));
       if (m->residual) RECMV_TRY(recmv_add_scaled_2d(out, ldo, x, 3, 1.f, out, ldo, P, 3, stream));
       break;
     }
     float* y = base + L.off_act[l] / 4;
     const bool skip_next = l + 1 == m->skip_layer;
-    RECMV_TRY(recmv_gemm_nt(h, ldh, m->W[l], m->dims[l], m->bias[l], y, L.ld_act, P, m->rows[l], m->dims[l],
-                            m->hidden_act, m->act_param, skip_next ? kInvSqrt2 : 1.f, stream));
+    RECMV_TRY(recmv_gemm_nt_seg(h, ldh, m->W[l], m->dims[l], m->bias[l], W2, b2, split, y, L.ld_act, P, m->rows[l], m->dims[l],
+                                m->hidden_act, m->act_param, skip_next ? kInvSqrt2 : 1.f, stream));
     if (skip_next)
       RECMV_TRY(recmv_posenc_forward(x, 3, y + m->rows[l], L.ld_act, d_pe, P, m->multires, m->pe_weights, kInvSqrt2,
                                      stream));
@@ -253,6 +266,9 @@ extern "C" int recmv_mlp_vjp_input(const recmv_mlp* m, const float* x, int64_t P
   RECMV_REQUIRE(n_out >= 1 && n_out <= m->rows[n - 1], "mlp_vjp_input: bad n_out");
   RECMV_REQUIRE(g_out || n_out == 1, "mlp_vjp_input: a NULL cotangent means ones and needs n_out == 1");
   for (int l = 0; l < n; ++l) RECMV_REQUIRE(m->Wt[l], "mlp_vjp_input: layer %d has no transposed weight", l);
+  const int64_t split = second_net_from(m, P);
+  if (split)
+    for (int l = 0; l < n; ++l) RECMV_REQUIRE(m->Wt2[l], "mlp_vjp_input: the second net's layer %d has no transposed weight", l);
   const Layout L = make_layout(m, P, 1);
   if (workspace_bytes < L.bytes) {
     set_error("mlp_vjp_input: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)L.bytes);
@@ -272,8 +288,8 @@ extern "C" int recmv_mlp_vjp_input(const recmv_mlp* m, const float* x, int64_t P
     ld = 0;
   } else {
     // [P,n_out] x [n_out, dims] : Wt[n-1] is [dims[n-1], rows[n-1]] row-major, use its first n_out columns
-    RECMV_TRY(recmv_gemm_nt(g_out, ldg, m->Wt[n - 1], m->rows[n - 1], nullptr, gbuf[cur], L.ld_act, P, m->dims[n - 1],
-                            n_out, RECMV_ACT_NONE, 0.f, 1.f, stream));
+    RECMV_TRY(recmv_gemm_nt_seg(g_out, ldg, m->Wt[n - 1], m->rows[n - 1], nullptr, split ? m->Wt2[n - 1] : nullptr, nullptr, split,
+                                gbuf[cur], L.ld_act, P, m->dims[n - 1], n_out, RECMV_ACT_NONE, 0.f, 1.f, stream));
     g = gbuf[cur];
     ld = L.ld_act;
     cur ^= 1;
@@ -283,6 +299,7 @@ extern "C" int recmv_mlp_vjp_input(const recmv_mlp* m, const float* x, int64_t P
     const float* y = base + L.off_act[l] / 4;
     const bool skip_next = l + 1 == m->skip_layer;
     float* gin = gbuf[cur];
+    RECMV_REQUIRE(!(split && ld == 0 && skip_next), "mlp_vjp_input: two nets with the skip connection on the last layer");
     if (skip_next) {
       // y = [act(z)/sqrt2 | gamma/sqrt2]: left part through the activation, right part to the encoding.  The
       // right part is parked FIRST (the product below overwrites the buffer it may live in two steps later).
@@ -300,19 +317,28 @@ extern "C" int recmv_mlp_vjp_input(const recmv_mlp* m, const float* x, int64_t P
     int64_t lddz = ld;
     if (!have_dz) {
       float* dz = base + L.off_g[2] / 4;
-      RECMV_TRY(recmv_act_grad_2d(g, ld, y, L.ld_act, dz, L.ld_act, P, m->rows[l], m->hidden_act, m->act_param,
-                                  skip_next ? kSqrt2 : 1.f, skip_next ? kInvSqrt2 : 1.f, stream));
+      if (split && ld == 0) {
+        // the broadcast cotangent row (row 0 of the last weight) differs between the two nets: one pass per row range
+        RECMV_TRY(recmv_act_grad_2d(g, 0, y, L.ld_act, dz, L.ld_act, split, m->rows[l], m->hidden_act, m->act_param,
+                                    skip_next ? kSqrt2 : 1.f, skip_next ? kInvSqrt2 : 1.f, stream));
+        RECMV_TRY(recmv_act_grad_2d(m->W2[n - 1], 0, y + split * L.ld_act, L.ld_act, dz + split * L.ld_act, L.ld_act, P - split,
+                                    m->rows[l], m->hidden_act, m->act_param, skip_next ? kSqrt2 : 1.f,
+                                    skip_next ? kInvSqrt2 : 1.f, stream));
+      } else {
+        RECMV_TRY(recmv_act_grad_2d(g, ld, y, L.ld_act, dz, L.ld_act, P, m->rows[l], m->hidden_act, m->act_param,
+                                    skip_next ? kSqrt2 : 1.f, skip_next ? kInvSqrt2 : 1.f, stream));
+      }
       dzp = dz;
       lddz = L.ld_act;
     }
     const bool fuse = l >= 1 && l != m->skip_layer;       // layer l-1's output is layer l's whole input
     if (fuse) {
-      RECMV_TRY(recmv_gemm_nt_mulgrad(dzp, lddz, m->Wt[l], m->rows[l], gin, L.ld_act, P, m->dims[l], m->rows[l],
-                                      base + L.off_act[l - 1] / 4, L.ld_act, m->hidden_act, m->act_param, 1.f, 1.f,
-                                      stream));
+      RECMV_TRY(recmv_gemm_nt_mulgrad_seg(dzp, lddz, m->Wt[l], split ? m->Wt2[l] : nullptr, split, m->rows[l], gin, L.ld_act, P,
+                                          m->dims[l], m->rows[l], base + L.off_act[l - 1] / 4, L.ld_act, m->hidden_act,
+                                          m->act_param, 1.f, 1.f, stream));
     } else {
-      RECMV_TRY(recmv_gemm_nt(dzp, lddz, m->Wt[l], m->rows[l], nullptr, gin, L.ld_act, P, m->dims[l], m->rows[l],
-                              RECMV_ACT_NONE, 0.f, 1.f, stream));
+      RECMV_TRY(recmv_gemm_nt_seg(dzp, lddz, m->Wt[l], m->rows[l], nullptr, split ? m->Wt2[l] : nullptr, nullptr, split, gin,
+                                  L.ld_act, P, m->dims[l], m->rows[l], RECMV_ACT_NONE, 0.f, 1.f, stream));
     }
     have_dz = fuse;
     cur ^= 1;

@@ -16,7 +16,7 @@ _PKG = Path(__file__).resolve().parent.parent          # rec-mv_amd/
 LIB_PATH = _PKG / "lib" / "librecmv_hip.so"
 
 RECMV_OK = 0
-ABI_VERSION = 4          # include/recmv_hip.h; bumped when a signature changes (v4: recmv_mc_run, capacities in recmv_mc_emit)
+ABI_VERSION = 5          # include/recmv_hip.h; bumped when a signature changes (v5: second weight set + split_row in recmv_mlp)
 F32, F64 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = 0, 1, 2, 3
 
@@ -34,7 +34,9 @@ class Mlp(C.Structure):
                 ("hidden_act", C.c_int32), ("residual", C.c_int32), ("act_param", C.c_float),
                 ("dims", C.c_int32 * (MLP_MAX_LAYERS + 1)), ("rows", C.c_int32 * MLP_MAX_LAYERS),
                 ("W", C.c_void_p * MLP_MAX_LAYERS), ("Wt", C.c_void_p * MLP_MAX_LAYERS),
-                ("bias", C.c_void_p * MLP_MAX_LAYERS), ("pe_weights", C.c_float * 32)]
+                ("bias", C.c_void_p * MLP_MAX_LAYERS), ("pe_weights", C.c_float * 32),
+                ("W2", C.c_void_p * MLP_MAX_LAYERS), ("Wt2", C.c_void_p * MLP_MAX_LAYERS),
+                ("bias2", C.c_void_p * MLP_MAX_LAYERS), ("split_row", C.c_int64)]
 
 
 class LbsGrid(C.Structure):
@@ -85,6 +87,8 @@ def _declare(lib):
         "recmv_gemm_nt": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, i32, f32, f32, vp]),
         "recmv_gemm_nt_actgrad": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, f32, f32, f32, vp]),
         "recmv_gemm_nt_mulgrad": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, i32, f32, f32, f32, vp]),
+        "recmv_gemm_nt_seg": (C.c_int, [vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, i64, i64, i64, i32, f32, f32, vp]),
+        "recmv_gemm_nt_mulgrad_seg": (C.c_int, [vp, i64, vp, vp, i64, i64, vp, i64, i64, i64, i64, vp, i64, i32, f32, f32, f32, vp]),
         "recmv_set_gemm_mode": (C.c_int, [i32]),
         "recmv_set_sampler_mode": (C.c_int, [i32]),
         "recmv_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),

@@ -18,7 +18,9 @@ class MlpChain:
     """A recmv_mlp descriptor over tensors that the caller keeps alive (weights are referenced, not copied)."""
 
     def __init__(self, weights, biases, weights_t, dims, rows, multires, cond_dim=0, skip_layer=-1,
-                 hidden_act=L.ACT_RELU, act_param=0.0, residual=False, pe_weights=None):
+                 hidden_act=L.ACT_RELU, act_param=0.0, residual=False, pe_weights=None, second=None):
+        """`second` = (weights, biases, weights_t) of a second net of the same shape: a call with `split_row` evaluates rows
+        [split_row, P) with it (the two garments' SDF nets over one block of rays — one launch per layer for both)."""
         n = len(weights)
         assert n <= L.MLP_MAX_LAYERS and len(dims) == n + 1 and len(rows) == n
         self.device = weights[0].device
@@ -40,6 +42,18 @@ class MlpChain:
             m.dims[l] = dims[l]
         for i in range(32):
             m.pe_weights[i] = float(pe_weights[i]) if (pe_weights is not None and i < len(pe_weights)) else 1.0
+        if second is not None:
+            W2, b2, Wt2 = second
+            self._keep += (list(W2), list(b2), list(Wt2) if Wt2 is not None else None)
+            for l in range(n):
+                assert W2[l].is_contiguous() and W2[l].dtype == torch.float32 and W2[l].shape == weights[l].shape, l
+                assert (b2[l] is None) == (biases[l] is None)
+                m.W2[l] = W2[l].data_ptr()
+                m.bias2[l] = b2[l].data_ptr() if b2[l] is not None else None
+                if Wt2 is not None:
+                    assert Wt2[l].is_contiguous() and Wt2[l].shape == (dims[l], rows[l])
+                    m.Wt2[l] = Wt2[l].data_ptr()
+        self.has_second = second is not None
         self.m = m
         self.n_layers = n
         self.rows_last = rows[-1]
@@ -55,10 +69,18 @@ class MlpChain:
             self._ws[slot] = ws
         return ws
 
-    def forward(self, x, cond=None, cond_index=None, n_out=None, keep=False, out=None, slot=None):
-        """x [P,3] -> [P, n_out] (the first n_out outputs of the last layer)."""
+    def _split(self, split_row, P):
+        if split_row is None or not self.has_second or split_row >= P:
+            self.m.split_row = 0
+        else:
+            assert split_row > 0 and split_row % 128 == 0, "the second net starts at a multiple of 128 rows"
+            self.m.split_row = int(split_row)
+
+    def forward(self, x, cond=None, cond_index=None, n_out=None, keep=False, out=None, slot=None, split_row=None):
+        """x [P,3] -> [P, n_out] (the first n_out outputs of the last layer); rows >= split_row through the second net."""
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 3 and x.is_contiguous()
         P = x.shape[0]
+        self._split(split_row, P)
         n_out = self.rows_last if n_out is None else n_out
         if out is None:
             out = torch.empty((P, n_out), dtype=torch.float32, device=x.device)
@@ -75,9 +97,10 @@ class MlpChain:
                                               int(keep), L.stream_ptr(x.device)), "mlp_forward")
         return out
 
-    def vjp_input(self, x, g_out=None, n_out=None, slot=None):
-        """J(x)^T g_out -> [P,3]; call after forward(keep=True) with the same x.  g_out None = ones (n_out 1)."""
+    def vjp_input(self, x, g_out=None, n_out=None, slot=None, split_row=None):
+        """J(x)^T g_out -> [P,3]; call after forward(keep=True) with the same x (and split_row).  g_out None = ones (n_out 1)."""
         P = x.shape[0]
+        self._split(split_row, P)
         n_out = (1 if g_out is None else g_out.shape[1]) if n_out is None else n_out
         gx = torch.empty((P, 3), dtype=torch.float32, device=x.device)
         ws = self._workspace(P, 1, slot)

@@ -286,7 +286,9 @@ def _translator_explicit(self, ps, conds, batch_inds, **kwargs):
     ch = _translator_chain(self, kwargs['ratio']['deformerRatio'])
     ps = ps.detach().contiguous()
     slot = kwargs.get('offset_type', None)
-    out = ch.forward(ps, cond=conds.detach(), cond_index=batch_inds.contiguous(), n_out=3, keep=True, slot=slot)
+    cond_index = kwargs.get('cond_index')            # (rows of several garments in one block: code row = frame + N * garment)
+    out = ch.forward(ps, cond=conds.detach(), cond_index=(batch_inds if cond_index is None else cond_index).contiguous(), n_out=3,
+                     keep=True, slot=slot)
     return out, (ch, ps, slot)
 
 

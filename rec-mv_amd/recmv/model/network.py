@@ -180,6 +180,26 @@ class ImplicitNetwork(nn.Module):
         return ch
 
     @torch.no_grad()
+    def pair_chain(self, other, ws):
+        """MlpChain that evaluates rows [0, split) with THIS net and rows [split, P) with `other` (same architecture, same
+        annealing weights) in one launch per layer — the two garments' SDF nets in the surface root finder.  Cached on both nets'
+        normalised weights."""
+        from ..chains import MlpChain
+        a, b = self.chain(ws, need_t=True), other.chain(ws, need_t=True)
+        assert list(self.dims) == list(other.dims) and self.skip_in == other.skip_in and self.multires == other.multires
+        hit = self.__dict__.get('_pair_cache')
+        if hit is not None and hit[0] is a and hit[1] is b:
+            return hit[2]
+        nl = self.num_layers - 1
+        wl = None if ws is None else tuple(float(w) for w in ws)
+        ch = MlpChain(a._keep[0], a._keep[1], a._keep[2], list(self.dims), [W.shape[0] for W in a._keep[0]], self.multires,
+                      cond_dim=0, skip_layer=(self.skip_in[0] if len(self.skip_in) else -1), hidden_act=ops.ACT_SOFTPLUS,
+                      act_param=100.0, residual=False, pe_weights=wl, second=(b._keep[0], b._keep[1], b._keep[2]))
+        assert len(a._keep[0]) == nl
+        self.__dict__['_pair_cache'] = (a, b, ch)
+        return ch
+
+    @torch.no_grad()
     def _forward_inference(self, input, ws, chunk=1 << 19):
         """No-grad path: posenc + one fused kernel per layer, the whole chain enqueued by one C call per chunk."""
         ch = self.chain(ws)

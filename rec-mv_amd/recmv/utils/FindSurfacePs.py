@@ -171,6 +171,89 @@ class _RootState:
         return self.p, self.unfinished == 0
 
 
+class _RootGroup(_RootState):
+    """The root-finding iteration of ALL garments as ONE block of rows on one stream.  The offset MLP and the skinner are shared by
+    the garments (a ray's per-frame deformation code is a row of the concatenated code table), the update is per ray, and the SDF
+    nets — the only per-garment weights — are evaluated by row-segmented products (rows [0, split) through the first garment's
+    net, the rest through the second's: recmv_gemm_nt_seg, csrc/mlp_chain.hip), so a step is the SAME ~55 launches for two
+    garments as for one, on twice the rows (64 x 64 tiles instead of 64 x 32 at ~3 k rays per garment).  The first garment's
+    rows are padded to a multiple of 128 (the tile height) with finished copies of its first ray.  Per-ray arithmetic is what
+    _RootState does: same points, same convergence flags; the iteration ends when no garment has an unfinished ray."""
+
+    def __init__(self, cam_pos, rays_list, initTmpPs_list, batch_inds_list, nets, ratio, deformer, defconds_list, smpl_conds,
+                 dthreshold, athreshold, w1, w2, times, stream):
+        dev = initTmpPs_list[0].device
+        self.stream = stream
+        self.args = (dthreshold, athreshold, w1, w2)
+        self.times, self.it, self.finished = times, 0, False
+        self.deformer, self.ratio, self.name = deformer, ratio, 'rootfind'
+        self.graph, self.use_graph = None, False
+        sizes = [int(p.shape[0]) for p in initTmpPs_list]
+        live = [g for g, n in enumerate(sizes) if n > 0]
+        assert len(initTmpPs_list) <= 2, 'only support less or equal than 2 garment_type'
+        self.sizes, self.offsets = sizes, [0] * len(sizes)
+        if len(live) == 2:
+            self.offsets[1] = -(-sizes[0] // 128) * 128
+        P = max((self.offsets[g] + sizes[g] for g in live), default=0)
+        self.split = self.offsets[1] if len(live) == 2 else None
+        n_frames = defconds_list[0].shape[0]
+        with torch.cuda.stream(stream):
+            self.p = torch.empty(P, 3, device=dev)
+            self.rays = torch.empty(P, 3, device=dev)
+            self.frame = torch.empty(P, dtype=torch.int64, device=dev)
+            self.cond_index = torch.empty(P, dtype=torch.int64, device=dev)
+            self.unfinished = torch.zeros(P, dtype=torch.uint8, device=dev)
+            for g in live:
+                o, n = self.offsets[g], sizes[g]
+                end = self.offsets[g + 1] if g + 1 < len(sizes) and (g + 1) in live else o + n
+                self.p[o:o + n] = initTmpPs_list[g].detach()
+                self.rays[o:o + n] = rays_list[g].detach()
+                self.frame[o:o + n] = batch_inds_list[g]
+                self.unfinished[o:o + n] = 1
+                if end > o + n:                               # padding: finished copies of the garment's first ray
+                    self.p[o + n:end] = initTmpPs_list[g][:1].detach()
+                    self.rays[o + n:end] = rays_list[g][:1].detach()
+                    self.frame[o + n:end] = batch_inds_list[g][:1]
+                self.cond_index[o:end] = self.frame[o:end] + g * n_frames
+            self.cam = cam_pos.detach().reshape(3).contiguous().float()
+            self.cond_table = torch.cat([c.detach() for c in defconds_list], dim=0).contiguous()
+            self.ints = torch.zeros(2 * (times + 2) + 1, dtype=torch.int32, device=dev)
+        self.conds = [self.cond_table, smpl_conds]
+        self.counters = self.ints[:times + 2]
+        self.marks = self.ints[times + 2:2 * (times + 2)]
+        self.state = self.ints[2 * (times + 2):]
+        self.host = torch.zeros(times + 2, dtype=torch.int32).pin_memory()
+        self.host_np = self.host.numpy()
+        if len(live) == 2:
+            ws = nets[0]._pe_weights(ratio)
+            self.sdf_chain = nets[0].pair_chain(nets[1], ws)
+        elif live:
+            net = nets[live[0]]
+            self.sdf_chain = net.chain(net._pe_weights(ratio), need_t=True)
+        if P == 0:
+            self.finished = True
+
+    def _enqueue(self):
+        from .. import chains
+        dthr, athr, w1, w2 = self.args
+        p = self.p
+        f = self.sdf_chain.forward(p, n_out=1, keep=True, split_row=self.split)
+        gf = self.sdf_chain.vjp_input(p, None, split_row=self.split)
+        _, loss2, angle, gd = self.deformer.ray_energy_and_vjp(p, self.conds, self.frame, self.cam, self.rays, ratio=self.ratio,
+                                                               offset_type=self.name, cond_index=self.cond_index)
+        chains.rootfind_step(p, f, gf, loss2, angle, gd, self.unfinished, self.counters, self.marks, self.state, dthr,
+                             athr, w1, w2, self.times)
+        self.host.copy_(self.marks, non_blocking=True)
+
+    def results(self):
+        outs, oks = [], []
+        for g, n in enumerate(self.sizes):
+            o = self.offsets[g]
+            outs.append(self.p[o:o + n].clone())
+            oks.append(self.unfinished[o:o + n] == 0)
+        return outs, oks
+
+
 @torch.no_grad()
 def prepare_root_finder(tmpSdf_nets, deformer, smpl_conds, ratio):
     """Everything the garments' root finders share (weight-normed weights and their transposes, posed skeleton, chain
@@ -195,6 +278,31 @@ def _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, 
     # the main stream still works through whatever was queued after them
     if after is None:
         prepare_root_finder(tmpSdf_nets[:len(initTmpPs_list)], deformer, smpl_conds, ratio)
+    if os.environ.get('RECMV_ROOT_GROUPED', '0') == '1' and len(initTmpPs_list) <= 2:
+        # all garments as one block of rows, one launch per layer for all of them (_RootGroup).  OFF by default: measured on the
+        # MI355X (tools/ab_rootfind.sh, profiles/r03_rootfind_grouped_ab.txt) the single chain of twice-as-large launches takes
+        # 23.0 ms per iteration against 18.9 ms for the two garments' chains running beside each other on two streams (the chain
+        # is bound by its ~1150 dependent launches of 15-25 us, which two streams overlap and one block does not), the iteration
+        # 122-125 ms against 116-121 ms.
+        st = streams[0]
+        if after is None:
+            st.wait_stream(main)
+        else:
+            for dep in after:
+                st.wait_stream(dep) if isinstance(dep, torch.cuda.Stream) else st.wait_event(dep)
+        group = _RootGroup(cam_pos, rays_list, initTmpPs_list, batch_inds_list, tmpSdf_nets, ratio, deformer, defconds_list,
+                           smpl_conds, dthreshold, athreshold, w1, w2, times, st)
+        while group.step():
+            pass
+        with torch.cuda.stream(st):
+            outs, oks = group.results()
+        main.wait_stream(st)
+        for t in outs + oks:
+            t.record_stream(main)
+        if os.environ.get('RECMV_ROOT_TRACE'):
+            torch.cuda.synchronize()
+            print('rootfind (grouped) %d steps; unfinished per step:' % group.it, group.steps_trace(), flush=True)
+        return outs, oks
     states = []
     for g, (initTmpPs, batch_inds, defconds, rays, name) in enumerate(
             zip(initTmpPs_list, batch_inds_list, defconds_list, rays_list, garment_names)):

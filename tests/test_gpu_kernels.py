@@ -380,6 +380,53 @@ def test_gemm_nt_vs_fp64(M, N, K):
     within(ops.gemm_nt(gpu(A), gpu(B), gpu(bias), ops.ACT_TANH), torch.tanh(ref))
 
 
+@pytest.mark.parametrize("M0,M1,N,K", [(128, 77, 512, 512), (3072, 2900, 512, 512), (3200, 3000, 473, 512), (2944, 3071, 512, 39),
+                                       (40960, 40000, 512, 512), (384, 5, 1, 512), (1280, 1200, 3, 512)])
+def test_gemm_nt_seg_equals_two_plain_products(M0, M1, N, K):
+    """recmv_gemm_nt_seg / recmv_gemm_nt_mulgrad_seg (rows [0, M0) x B^T, rows [M0, M0 + M1) x B2^T in ONE launch; M0 a multiple
+    of 128) against the two plain launches, softplus epilogue, no bias, and the activation-gradient epilogue alike.  The 64 x 64
+    and 128 x 128 tiles run one fma chain over k per output element, the 64 x 32 tile (fewest rows) sums two half-K chains: where
+    the combined launch and a plain one get the same kind of chain the comparison is bit for bit, otherwise within the f32 MFMA
+    bound of test_gemm_nt_vs_fp64 (both sides against fp64)."""
+    from recmv import _lib as L, ops
+    g = torch.Generator().manual_seed(M0 + N)
+    A = gpu(torch.randn(M0 + M1, K, generator=g))
+    B, B2 = gpu(torch.randn(N, K, generator=g) / np.sqrt(K)), gpu(torch.randn(N, K, generator=g) / np.sqrt(K))
+    b, b2 = gpu(torch.randn(N, generator=g)), gpu(torch.randn(N, generator=g))
+    Y = gpu(torch.rand(M0 + M1, N, generator=g))
+    lib, st = L.lib(), L.stream_ptr(A.device)
+    narrow = lambda M: -(-M // 64) * -(-N // 64) < 640 and -(-M // 128) * -(-N // 128) < 512      # dispatch_nt's tile choice
+    exact = {0: narrow(M0 + M1) == narrow(M0), 1: narrow(M0 + M1) == narrow(M1)}
+
+    def same(got, want, Ar, W, part, scale=1.0):
+        if exact[part]:
+            assert torch.equal(got, want), (part, float((got - want).abs().max()))
+        else:
+            bound = scale * (4e-7 * (Ar.abs().double() @ W.abs().double().t()) + 1e-6) * 2
+            assert ((got.double() - want.double()).abs() <= bound + 4e-7 * want.abs().double()).all(), part
+
+    def seg(bias, bias2, act, p, scale):
+        out = torch.empty(M0 + M1, N, device=DEV)
+        L.check(lib.recmv_gemm_nt_seg(L.ptr(A), K, L.ptr(B), K, L.ptr(bias), L.ptr(B2), L.ptr(bias2), M0, L.ptr(out), N, M0 + M1, N, K,
+                                      act, p, scale, st), "gemm_nt_seg")
+        return out
+
+    for bias, bias2, act, p, scale in ((b, b2, ops.ACT_SOFTPLUS, 100.0, 0.5), (None, None, ops.ACT_NONE, 0.0, 1.0)):
+        got = seg(bias, bias2, act, p, scale)
+        same(got[:M0], ops.gemm_nt(A[:M0], B, bias, act, p, scale), A[:M0], B, 0)
+        same(got[M0:], ops.gemm_nt(A[M0:], B2, bias2, act, p, scale), A[M0:], B2, 1)
+    out = torch.empty(M0 + M1, N, device=DEV)
+    L.check(lib.recmv_gemm_nt_mulgrad_seg(L.ptr(A), K, L.ptr(B), L.ptr(B2), M0, K, L.ptr(out), N, M0 + M1, N, K, L.ptr(Y), N,
+                                          ops.ACT_SOFTPLUS, 100.0, 1.0, 1.0, st), "mulgrad_seg")
+    for part, (rows, W) in enumerate(((slice(0, M0), B), (slice(M0, None), B2))):
+        ref = torch.empty(out[rows].shape, device=DEV)
+        L.check(lib.recmv_gemm_nt_mulgrad(L.ptr(A[rows]), K, L.ptr(W), K, L.ptr(ref), N, ref.shape[0], N, K, L.ptr(Y[rows]), N,
+                                          ops.ACT_SOFTPLUS, 100.0, 1.0, 1.0, st), "mulgrad")
+        same(out[rows], ref, A[rows], W, part)
+    # a split that is not a multiple of the tile height is refused
+    assert lib.recmv_gemm_nt_seg(L.ptr(A), K, L.ptr(B), K, None, L.ptr(B2), None, 100, L.ptr(out), N, M0 + M1, N, K, 0, 0.0, 1.0, st) != 0
+
+
 def test_gemm_nt_strided_views():
     from recmv import ops
     g = torch.Generator().manual_seed(0)

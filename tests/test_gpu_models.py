@@ -4,10 +4,13 @@ torch-CPU sgemm and softplus(beta=100) amplifies pre-activation error, so values
 rtol 2e-4 / atol 2e-5 and first/second-order gradients at rtol 2e-3 / atol 2e-4 (relative to the
 tensor's scale).
 """
+import os
 import sys
 from pathlib import Path
 
 import numpy as np
+
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -206,6 +209,67 @@ def test_root_finder(nets):
     assert both.sum() >= 10
     err = (out[both] - g["out"].to(DEV)[both]).norm(dim=1)
     assert err.max().item() < 2e-4, err.max().item()
+
+
+def test_root_finder_all_garments_in_one_block_equals_per_garment(nets):
+    """The root finder over BOTH garments' rays as one block of rows (row-segmented SDF weights, shared offset MLP / skinner with
+    a concatenated code table; utils/FindSurfacePs.py:273-353 loops over the garments) against one launch chain per garment.
+    One garment (or one garment with rays): the same launches, bit for bit.  Two garments: a block of twice the rows gets the
+    64 x 64 MFMA tile where ~3 k rows get the 64 x 32 one (two half-K chains per element), so the products differ in the last
+    bits and the 20-step iteration — chaotic at its 5e-5 / 0.02 deg stopping thresholds, see test_root_finder — is compared the
+    way the reference fixture is: the same rays converge up to threshold-straddlers, converged points agree to 2e-4 and satisfy
+    the stopping rule.  ONE step agrees to f32 rounding.  And the SDF pair chain against the two nets' own chains."""
+    import common_setup as cs
+    from recmv.model import getTmpSdf
+    from recmv.utils import OptimizeGarmentSurfacePs
+    g, gt, gl = load("rootfind"), load("translator"), load("lbs")
+    conds = gt["conds"].to(DEV)
+    poses, trans = gl["poses"].to(DEV), gl["trans"].to(DEV)
+    sdf2 = cs.perturb(getTmpSdf("cpu", 6, bias=0.55), 77, 0.01).to(DEV)
+    start, rays, binds = g["start"].to(DEV), g["rays"].to(DEV), g["binds"].to(DEV)
+    n = start.shape[0]
+    k = (2 * n) // 3
+    conds2 = (conds + 0.05 * torch.randn(conds.shape, generator=torch.Generator().manual_seed(3)).to(DEV)).contiguous()
+
+    def run(grouped, starts, rays_l, binds_l, nets_l, conds_l, times=20):
+        os.environ['RECMV_ROOT_GROUPED'] = '1' if grouped else '0'
+        try:
+            return OptimizeGarmentSurfacePs(g["cam_pos"].to(DEV), rays_l, [s.clone() for s in starts], binds_l, nets_l, RATIO,
+                                            nets["comp"], [conds_l, [poses, trans]], garment_names=["a", "b"][:len(starts)],
+                                            dthreshold=5.e-5, athreshold=0.02, w1=3.05, w2=1., times=times)
+        finally:
+            os.environ.pop('RECMV_ROOT_GROUPED', None)
+
+    same = {"second garment without rays": ([start, start[:0]], [rays, rays[:0]], [binds, binds[:0]], [nets["sdf"], sdf2], [conds, conds2]),
+            "first garment without rays": ([start[:0], start], [rays[:0], rays], [binds[:0], binds], [sdf2, nets["sdf"]], [conds2, conds]),
+            "one garment": ([start], [rays], [binds], [nets["sdf"]], [conds])}
+    for name, args in same.items():
+        (pa, oa), (pb, ob) = run(True, *args), run(False, *args)
+        for x, y in zip(pa + oa, pb + ob):
+            assert x.shape == y.shape and torch.equal(x, y), name
+    two = ([start, start[:k] * 0.97], [rays, rays[:k]], [binds, binds[:k]], [nets["sdf"], sdf2], [conds, conds2])
+    (pa, oa), (pb, ob) = run(True, *two, times=1), run(False, *two, times=1)
+    for x, y, s0 in zip(pa, pb, two[0]):
+        moved = (y - s0).norm(dim=1)
+        assert moved.max() > 1e-4 and ((x - y).norm(dim=1) <= 1e-3 * moved + 2e-6).all(), float((x - y).norm(dim=1).max())
+    (pa, oa), (pb, ob) = run(True, *two), run(False, *two)
+    assert int(oa[0].sum()) > 10, "fixture: the first garment has converging rays"
+    for x, y, ca, cb, net in zip(pa, pb, oa, ob, two[3]):
+        assert (ca == cb).float().mean().item() > 0.9
+        both = ca & cb
+        assert not bool(both.any()) or (x[both] - y[both]).norm(dim=1).max().item() < 2e-4
+        with torch.no_grad():
+            assert (net(x[ca], RATIO).view(-1).abs() < 5.e-5).all()
+    # the pair chain: value and input gradient of each net on its own rows (256 + 100 rows: the same tile on both sides)
+    ws = nets["sdf"]._pe_weights(RATIO)
+    pair = nets["sdf"].pair_chain(sdf2, ws)
+    x = torch.cat([start[:256], start[:100] * 0.9]).contiguous()
+    f = pair.forward(x, n_out=1, keep=True, split_row=256)
+    gx = pair.vjp_input(x, None, split_row=256)
+    for net, rows in ((nets["sdf"], slice(0, 256)), (sdf2, slice(256, None))):
+        ch = net.chain(ws, need_t=True)
+        xr = x[rows].contiguous()
+        assert torch.equal(f[rows], ch.forward(xr, n_out=1, keep=True)) and torch.equal(gx[rows], ch.vjp_input(xr, None))
 
 
 def test_seg3d_lossless_and_mc(nets):

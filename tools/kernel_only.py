@@ -151,6 +151,42 @@ def run_sampler(out_json):
     json.dump(cases, open(out_json, "w"))
 
 
+def run_mc(out_json):
+    """Marching cubes only: 257^3, 385^3 and the loop's coarse pyramid, through recmv_mc_run (no host round trip)."""
+    import ctypes as C
+    import torch
+    from recmv import _lib as L
+    from microbench import body_like_volume
+    dev = "cuda:0"
+    cases = []
+    sep = torch.zeros(257, device=dev)
+    lib = L.lib()
+    for n in (257, 385):
+        torch.sort(sep)
+        vol3 = body_like_volume(n)
+        ws = torch.empty(int(lib.recmv_mc_workspace_bytes(n, n, n)), dtype=torch.uint8, device=dev)
+        cnt = (C.c_int32 * 3)(0, 0, 0)
+        L.check(lib.recmv_mc_count(L.ptr(vol3), n, n, n, 0.0, L.ptr(ws), ws.numel(), C.cast(cnt, C.c_void_p), L.stream_ptr(vol3.device)), "mc")
+        V, F = int(cnt[0]), int(cnt[1])
+        vb = torch.empty(V, 3, device=dev)
+        fb = torch.empty(F, 3, dtype=torch.int64, device=dev)
+        cdev = torch.empty(3, dtype=torch.int32, device=dev)
+        step = 2.0 / (n - 1)
+
+        def fn():
+            L.check(lib.recmv_mc_run(L.ptr(vol3), n, n, n, 0.0, step, step, step, -1.0, -1.0, -1.0, L.ptr(ws), ws.numel(), L.ptr(vb), V,
+                                     L.ptr(fb), F, L.ptr(cdev), L.stream_ptr(vol3.device)), "mc_run")
+        torch.sort(sep)
+        fn()
+        torch.cuda.synchronize()
+        torch.sort(sep)
+        for _ in range(REPS):
+            fn()
+        torch.cuda.synchronize()
+        cases.append({"name": f"mc_run {n}^3 (V={V}, F={F}): volume + vertices + faces", "alg_bytes": 4 * n ** 3 + 12 * V + 24 * F})
+    json.dump(cases, open(out_json, "w"))
+
+
 def report(prof_dir, cases_json):
     cases = json.load(open(cases_json))
     db = glob.glob(prof_dir + "/**/*.db", recursive=True)[0]
@@ -191,5 +227,7 @@ if __name__ == "__main__":
         run(sys.argv[2])
     elif sys.argv[1] == "run_sampler":
         run_sampler(sys.argv[2])
+    elif sys.argv[1] == "run_mc":
+        run_mc(sys.argv[2])
     else:
         report(sys.argv[2], sys.argv[3])

@@ -6,7 +6,7 @@
       rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o run -- python $REPO/bench.py --steps 3 --warmup 1 \
           --settle-iters 40 --no-cpu-baseline --no-mc --no-alt-mode --no-hbm-kernels --no-kernel-events
     done
-    python tools/pmc_loop.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > profiles/r02_pmc_loop.json
+    python tools/pmc_loop.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE --measured-at "<commit sha>, <date>" > profiles/rNN_pmc_loop.json
 
 Per kernel name (template arguments kept, parameter list dropped): launches seen, mean FETCH_SIZE / WRITE_SIZE per
 launch in bytes (rocprofv3 reports KiB-like units; FETCH_SIZE doubled: on gfx950 a wide coalesced streaming read is
@@ -46,7 +46,13 @@ def collect(root):
 
 def main():
     acc = {}
-    for root in sys.argv[1:]:
+    argv = sys.argv[1:]
+    measured_at = None
+    if "--measured-at" in argv:
+        i = argv.index("--measured-at")
+        measured_at = argv[i + 1]
+        argv = argv[:i] + argv[i + 2:]
+    for root in argv:
         acc.update(collect(root))
     kernels = {}
     for (name, ctr), vals in acc.items():
@@ -60,7 +66,7 @@ def main():
         if "fetch_bytes_per_launch" in k and "write_bytes_per_launch" in k:
             k["traffic_bytes_per_launch"] = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
     top = dict(sorted(kernels.items(), key=lambda kv: -kv[1].get("traffic_bytes_per_launch", 0) * kv[1]["launches"])[:40])
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py (tools/pmc_loop.py); FETCH_SIZE x2 "
+    json.dump({"measured_at": measured_at, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py (tools/pmc_loop.py); FETCH_SIZE x2 "
                          "(gfx950 wide-read correction), WRITE_SIZE as reported", "kernels": top}, sys.stdout, indent=1)
 
 

@@ -33,50 +33,91 @@ __device__ __forceinline__ void put(T* __restrict__ out, uint8_t* __restrict__ b
   bnd[o] = differ ? 1 : 0;
 }
 
+// The two x-parities of a cell are adjacent in the output row: ONE 8-byte value store and ONE 2-byte flag store per (y, z)
+// parity instead of two of each (the rows of a (2n-1)-wide volume start at any 4-byte / 1-byte offset, so the types below
+// only claim that alignment; gfx950 global stores take it).  Half the store instructions and L2 write transactions.
 template <typename T>
+struct alignas(alignof(T)) Pair {
+  T a, b;
+};
+struct alignas(1) FlagPair {
+  uint8_t a, b;
+};
+template <typename T>
+__device__ __forceinline__ void put2(T* __restrict__ out, uint8_t* __restrict__ bnd, int64_t o, T s0, bool d0, T s1, T scale1,
+                                     bool d1) {
+  Pair<T> v;
+  v.a = s0;
+  v.b = s1 * scale1;
+  *reinterpret_cast<Pair<T>*>(out + o) = v;
+  FlagPair f;
+  f.a = d0 ? 1 : 0;
+  f.b = d1 ? 1 : 0;
+  *reinterpret_cast<FlagPair*>(bnd + o) = f;
+}
+
+// R consecutive cell rows (same z, y = u0 .. u0+R-1) per workgroup trip: their 2 (R+1) source rows are requested up front —
+// neighbouring cell rows share a source row, and a lane has 4 (R+1) loads in flight instead of 8 (one cell row per trip was bound
+// by the latency of its 8 loads: 26 us at 129^3 -> 257^3 whatever the store width, profiles/r03_kernel_only_interp_v1.txt).
+template <typename T, int R>
 __global__ __launch_bounds__(256) void interp2x_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
-                                                            uint8_t* __restrict__ bnd, int64_t rows,
+                                                            uint8_t* __restrict__ bnd, int64_t groups, int hg,
                                                             int d, int h, int w, float balance) {
   const int D = 2 * d - 1, H = 2 * h - 1, W = 2 * w - 1;
   const T bal = (T)balance;
-  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
-    const int u = (int)(row % h);
-    const int t = (int)((row / h) % d);
-    const int64_t b = row / ((int64_t)h * d);
-    const bool hy = u < h - 1, hz = t < d - 1;          // odd y / odd z outputs exist for this cell row
-    const int u1 = hy ? u + 1 : u, t1 = hz ? t + 1 : t;
+  for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int u0 = (int)(grp % hg) * R;                  // first cell row of the group
+    const int t = (int)((grp / hg) % d);
+    const int64_t b = grp / ((int64_t)hg * d);
+    const bool hz = t < d - 1;                           // odd z outputs exist for this cell layer
+    const int t1 = hz ? t + 1 : t;
     const T* src = in + b * (int64_t)d * h * w;
-    const T* r00 = src + ((int64_t)t * h + u) * w;       // (z-, y-)
-    const T* r01 = src + ((int64_t)t * h + u1) * w;      // (z-, y+)
-    const T* r10 = src + ((int64_t)t1 * h + u) * w;      // (z+, y-)
-    const T* r11 = src + ((int64_t)t1 * h + u1) * w;     // (z+, y+)
-    const int64_t o00 = ((b * D + 2 * t) * H + 2 * u) * (int64_t)W;     // output rows (z, y) of this cell row
-    const int64_t o01 = o00 + W, o10 = o00 + (int64_t)H * W, o11 = o10 + W;
+    const T* lo = src + (int64_t)t * h * w;              // source layer z-
+    const T* hi = src + (int64_t)t1 * h * w;             // source layer z+
     for (int v = threadIdx.x; v < w; v += blockDim.x) {
       const bool hx = v < w - 1;
       const int v1 = hx ? v + 1 : v;
-      const T c000 = r00[v], c001 = r00[v1], c010 = r01[v], c011 = r01[v1];
-      const T c100 = r10[v], c101 = r10[v1], c110 = r11[v], c111 = r11[v1];
-      const bool f = c000 > bal;
-      const bool g001 = (c001 > bal) != f, g010 = (c010 > bal) != f, g011 = (c011 > bal) != f;
-      const bool g100 = (c100 > bal) != f, g101 = (c101 > bal) != f, g110 = (c110 > bal) != f;
-      const bool g111 = (c111 > bal) != f;
-      const int x = 2 * v;
-      out[o00 + x] = c000;
-      bnd[o00 + x] = 0;
-      if (hx) put(out, bnd, o00 + x + 1, c000 + c001, (T)0.5, g001);
-      if (hy) {
-        put(out, bnd, o01 + x, c000 + c010, (T)0.5, g010);
-        if (hx) put(out, bnd, o01 + x + 1, ((c000 + c001) + c010) + c011, (T)0.25, g001 || g010 || g011);
+      T a[R + 1][2], c[R + 1][2];                        // [source row][x parity] of the two layers
+#pragma unroll
+      for (int r = 0; r <= R; ++r) {
+        const int y = min(u0 + r, h - 1);
+        a[r][0] = lo[(int64_t)y * w + v];
+        a[r][1] = lo[(int64_t)y * w + v1];
+        c[r][0] = hi[(int64_t)y * w + v];
+        c[r][1] = hi[(int64_t)y * w + v1];
       }
-      if (hz) {
-        put(out, bnd, o10 + x, c000 + c100, (T)0.5, g100);
-        if (hx) put(out, bnd, o10 + x + 1, ((c000 + c100) + c001) + c101, (T)0.25, g100 || g001 || g101);   // skip_y
-        if (hy) {
-          put(out, bnd, o11 + x, ((c000 + c100) + c010) + c110, (T)0.25, g100 || g010 || g110);           // skip_x
-          if (hx)
-            put(out, bnd, o11 + x + 1, ((((((c000 + c001) + c010) + c011) + c100) + c101) + c110) + c111, (T)0.125,
-                g001 || g010 || g011 || g100 || g101 || g110 || g111);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int u = u0 + r;
+        if (u >= h) break;
+        const bool hy = u < h - 1;                       // odd y outputs exist for this cell row
+        const T c000 = a[r][0], c001 = a[r][1], c010 = a[r + 1][0], c011 = a[r + 1][1];
+        const T c100 = c[r][0], c101 = c[r][1], c110 = c[r + 1][0], c111 = c[r + 1][1];
+        const int64_t o00 = ((b * D + 2 * t) * H + 2 * u) * (int64_t)W;     // output rows (z, y) of this cell row
+        const int64_t o01 = o00 + W, o10 = o00 + (int64_t)H * W, o11 = o10 + W;
+        const bool f = c000 > bal;
+        const bool g001 = (c001 > bal) != f, g010 = (c010 > bal) != f, g011 = (c011 > bal) != f;
+        const bool g100 = (c100 > bal) != f, g101 = (c101 > bal) != f, g110 = (c110 > bal) != f;
+        const bool g111 = (c111 > bal) != f;
+        const int x = 2 * v;
+        if (hx) {       // every cell but the last of a row: both x-parities, stored as pairs
+          put2(out, bnd, o00 + x, c000, false, c000 + c001, (T)0.5, g001);
+          if (hy) put2(out, bnd, o01 + x, (c000 + c010) * (T)0.5, g010, ((c000 + c001) + c010) + c011, (T)0.25, g001 || g010 || g011);
+          if (hz) {
+            put2(out, bnd, o10 + x, (c000 + c100) * (T)0.5, g100, ((c000 + c100) + c001) + c101, (T)0.25, g100 || g001 || g101);   // skip_y
+            if (hy)
+              put2(out, bnd, o11 + x, (((c000 + c100) + c010) + c110) * (T)0.25, g100 || g010 || g110,                       // skip_x
+                   ((((((c000 + c001) + c010) + c011) + c100) + c101) + c110) + c111, (T)0.125,
+                   g001 || g010 || g011 || g100 || g101 || g110 || g111);
+          }
+        } else {
+          out[o00 + x] = c000;
+          bnd[o00 + x] = 0;
+          if (hy) put(out, bnd, o01 + x, c000 + c010, (T)0.5, g010);
+          if (hz) {
+            put(out, bnd, o10 + x, c000 + c100, (T)0.5, g100);
+            if (hy) put(out, bnd, o11 + x, ((c000 + c100) + c010) + c110, (T)0.25, g100 || g010 || g110);   // skip_x
+          }
         }
       }
     }
@@ -143,16 +184,18 @@ extern "C" int recmv_interp2x_boundary3d_forward(const void* input, void* output
   if (bc == 0 || d == 0 || h == 0 || w == 0) return RECMV_OK;
   RECMV_REQUIRE(input && output && is_boundary, "interp2x_forward: NULL pointer");
   RECMV_REQUIRE(d < (1 << 30) && h < (1 << 30) && w < (1 << 30), "interp2x_forward: size too large");
-  const int64_t rows = bc * d * h;                       // rows of source cells
+  constexpr int R = 4;                                   // cell rows per workgroup trip
+  const int hg = (int)ceil_div(h, (int64_t)R);
+  const int64_t groups = bc * d * hg;
   hipStream_t s = (hipStream_t)stream;
   const int blk = (int)(w >= 256 ? 256 : ceil_div(w, kWave) * kWave);
-  const unsigned g = (unsigned)(rows < (1ll << 30) ? rows : (1ll << 30));
+  const unsigned g = (unsigned)(groups < (1ll << 30) ? groups : (1ll << 30));
   if (dtype == RECMV_F32)
-    hipLaunchKernelGGL(interp2x_fwd_kernel<float>, dim3(g), dim3(blk), 0, s, (const float*)input,
-                       (float*)output, is_boundary, rows, (int)d, (int)h, (int)w, balance_value);
+    hipLaunchKernelGGL((interp2x_fwd_kernel<float, R>), dim3(g), dim3(blk), 0, s, (const float*)input,
+                       (float*)output, is_boundary, groups, hg, (int)d, (int)h, (int)w, balance_value);
   else if (dtype == RECMV_F64)
-    hipLaunchKernelGGL(interp2x_fwd_kernel<double>, dim3(g), dim3(blk), 0, s, (const double*)input,
-                       (double*)output, is_boundary, rows, (int)d, (int)h, (int)w, balance_value);
+    hipLaunchKernelGGL((interp2x_fwd_kernel<double, R>), dim3(g), dim3(blk), 0, s, (const double*)input,
+                       (double*)output, is_boundary, groups, hg, (int)d, (int)h, (int)w, balance_value);
   else {
     set_error("interp2x_forward: dtype %d unsupported", dtype);
     return RECMV_ERR_UNSUPPORTED;

@@ -187,6 +187,26 @@ def run_mc(out_json):
     json.dump(cases, open(out_json, "w"))
 
 
+def run_interp(out_json):
+    """The 2x boundary upsampler only."""
+    import torch
+    from recmv import interp2x_boundary3d
+    dev = "cuda:0"
+    cases = []
+    sep = torch.zeros(257, device=dev)
+    for n in (65, 129, 193):
+        x = torch.randn(1, 1, n, n, n, device=dev)
+        torch.sort(sep)
+        interp2x_boundary3d.forward(x, 0.0)
+        torch.cuda.synchronize()
+        torch.sort(sep)
+        for _ in range(REPS):
+            interp2x_boundary3d.forward(x, 0.0)
+        torch.cuda.synchronize()
+        cases.append({"name": f"interp2x fwd {n}^3 -> {2 * n - 1}^3", "alg_bytes": 4 * n ** 3 + 5 * (2 * n - 1) ** 3})
+    json.dump(cases, open(out_json, "w"))
+
+
 def report(prof_dir, cases_json):
     cases = json.load(open(cases_json))
     db = glob.glob(prof_dir + "/**/*.db", recursive=True)[0]
@@ -229,5 +249,7 @@ if __name__ == "__main__":
         run_sampler(sys.argv[2])
     elif sys.argv[1] == "run_mc":
         run_mc(sys.argv[2])
+    elif sys.argv[1] == "run_interp":
+        run_interp(sys.argv[2])
     else:
         report(sys.argv[2], sys.argv[3])

@@ -811,6 +811,13 @@ class HotLoop:
         lines, tie the canonical curves to their garment's zero level, one AdamW step on the curve parameters.  The
         gradients this leaves on the shared networks are cleared by the optimiser's zero_grad that follows."""
         conf = self.conf
+        # fl_visible_method (:1573-1583): every shipped config says `zbuff`.  `surface` (fl_visible_by_surface_normal, :1312-1372)
+        # cannot run in the reference either since the feature lines became curves: deform_feature_line hands it
+        # `fl_meshes_dict[name] = None` (:1562) and it dereferences that.  Anything else raises there too (`raise NotImplemented`).
+        method = conf.get_string('fl_visible_method') if 'fl_visible_method' in conf else 'zbuff'
+        if method != 'zbuff':
+            raise NotImplementedError("fl_visible_method = %r: only 'zbuff' runs (in the reference as well: its 'surface' branch "
+                                      "reads curve MESHES that deform_feature_line no longer builds)" % method)
         d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
         smpl_conds = [poses, trans]
         self._shared_def_vs = self._deform_garments(N, frame_ids, ratio)
@@ -1173,6 +1180,17 @@ class HotLoop:
         self.info['dct_loss'] = dct_loss.detach()
         return dct_loss * self.conf.get_float('dct_weight')
 
+    @staticmethod
+    def _backward_early(loss):
+        """The |SDF| terms of the mask loss (:963-972) depend on nothing the ray pipeline produces: their backward runs as soon as
+        they exist (like the mask loss's own, :959) instead of inside the caller's `loss.backward()`, and the value travels on in
+        the returned loss detached.  The gradients are the same sums, accumulated as (mask loss) + (|SDF| terms) + (render loss +
+        pose prior) — the order is the same in the serial and in the three-stream schedule."""
+        if torch.is_tensor(loss) and loss.requires_grad:
+            loss.backward()
+            return loss.detach()
+        return loss
+
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, frame_ids, ratio, global_optimizer=None):
         """OptimGarmentNetwork.forward (:1885-1969) on the frames `frame_ids`; `global_optimizer` is the caller's Adam
@@ -1211,7 +1229,7 @@ class HotLoop:
             opt.zero_grad()                                                                # :1934
             with self._phase('mask_loss'):
                 def_vs, pc_sdf_loss = self.mask_loss(N, frame_ids, ratio, cameras)
-            total_loss = total_loss + pc_sdf_loss
+            total_loss = total_loss + self._backward_early(pc_sdf_loss)
             d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
             cameras = cameras_rays                                                         # rebuilt graph (:1036)
             with self._phase('sample_rays'):
@@ -1263,7 +1281,9 @@ class HotLoop:
             with self._phase('pc_sdf'):
                 if curve_done is not None:
                     main.wait_event(curve_done)          # curve_aware_loss reads the curves after their AdamW step
-                total_loss = total_loss + self.pc_sdf_terms(ratio)
+                # differentiated NOW: the host would otherwise sit in the render loss's first read-back (the converged-ray count)
+                # until the root finder has finished, with this backward — the SDF nets on ~170 k vertices — still unqueued
+                total_loss = total_loss + self._backward_early(self.pc_sdf_terms(ratio))
             with on(s_ray), self._phase('render_loss_fwd'):
                 s_ray.wait_event(getattr(self, '_sgd_done', None))
                 render_loss = self.surface_render_loss(N, cameras_rays, frame_ids, ratio, checks, init_ps_list, samples)
@@ -1388,7 +1408,8 @@ class HotLoop:
         self._allreduce = allreduce
         loss = HotLoop.forward(self, frame_ids, ratio)      # (the facade subclass overrides forward(datas, ...))
         with self._phase('backward'):
-            loss.backward()
+            if loss.requires_grad:                   # (the |SDF| terms were differentiated inside forward: _backward_early)
+                loss.backward()
         pending = []
         if allreduce is not None and hasattr(allreduce, 'start'):
             # the colour net and the per-frame colour codes are final after the backward (the implicit differentiation below adds to

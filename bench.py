@@ -559,10 +559,6 @@ def main():
             gs_serial = prof.end()
         finally:
             del os.environ["RECMV_SERIAL"]
-    leg2 = None
-    if not args.no_config2:
-        leg2 = config2_leg(loop, it, allreduce, world, device)
-        it += leg2.pop("_steps_run")
     per_rank_ms, allreduce_us = None, None
     if world > 1:
         mine = elapsed
@@ -674,8 +670,6 @@ def main():
                         "in %d steps, the reference's cadence is 1 in %d" % (len(with_r), args.steps, period)}
         if alt:
             line["alt_mode"] = alt
-        if leg2:
-            line["config2"] = leg2
         log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
         if getattr(loop, "phase_ms", None):
             log("phase ms (RECMV_TIMING=1, timed steps only): " + json.dumps({k: round(v, 1) for k, v in loop.phase_ms.items()}))
@@ -696,6 +690,14 @@ def main():
                 export_state(loop, state, loop.frame_batch(it), it)
                 line["cpu_baseline"] = cpu_baseline(args.conf, state)
             log("CPU baseline done")
+    # the second workload leg LAST: it re-meshes on its own pyramid, and everything above describes the main workload's meshes
+    leg2 = None
+    if not args.no_config2:
+        leg2 = config2_leg(loop, it, allreduce, world, device)
+        it += leg2.pop("_steps_run")
+    if rank == 0:
+        if leg2:
+            line["config2"] = leg2
         print(json.dumps(line), flush=True)
     rdist.barrier()
     if tdist.is_initialized():

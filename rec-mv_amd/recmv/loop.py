@@ -444,6 +444,16 @@ class HotLoop:
     @contextlib.contextmanager
     def _phase(self, name):
         """Wall time per phase of an iteration into self.phase_ms when RECMV_TIMING=1 (adds device syncs)."""
+        if os.environ.get('RECMV_HOST_TRACE') == '1' and torch.cuda.is_available():
+            # no synchronisation: host interval of the phase + HIP events on the stream the phase runs on (tools/phase_overlap.py)
+            rec = self.__dict__.setdefault('phase_trace', [])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            yield
+            e1.record()
+            rec.append((name, t0, time.perf_counter(), e0, e1))
+            return
         if os.environ.get('RECMV_TIMING', '0') != '1':
             yield
             return
@@ -923,9 +933,11 @@ class HotLoop:
             return [d.detach() for d in def_vs], None
         return [d.detach() for d in def_vs], self.pc_sdf_terms(ratio)
 
-    def pc_sdf_terms(self, ratio):
+    def pc_sdf_terms(self, ratio, before_curve_term=None):
         """The |SDF| terms at the end of mask_loss (:963-972): the moved explicit vertices and the curve-aware disc pull
-        their garment's zero level towards them."""
+        their garment's zero level towards them.  Both parts are differentiated where they are formed (_backward_early) and
+        return detached; `before_curve_term()` runs between them (the three-stream order waits for the curve branch THERE: the
+        vertices' part does not read the curves, so the main stream does not sit idle until the curve stream has caught up)."""
         conf = self.conf
         pc_sdf_loss = 0.
         for g_i, name in enumerate(self.garment_names):                                   # :966-970
@@ -933,7 +945,10 @@ class HotLoop:
             sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
             self.info['pc_{}_loss_sdf'.format(name)] = sdf_loss.detach()
             pc_sdf_loss = pc_sdf_loss + sdf_loss * conf.get_float('pc_weight.weight')
-        return pc_sdf_loss + self.curve_aware_loss(ratio)                                # :972
+        pc_sdf_loss = self._backward_early(pc_sdf_loss)
+        if before_curve_term is not None:
+            before_curve_term()
+        return pc_sdf_loss + self._backward_early(self.curve_aware_loss(ratio))            # :972
 
     CURVE_AWARE = CURVE_AWARE                                                              # utils/constant.py:228-232
     CURVE_AWARE_SAMPLES = 50000                                                            # :808, :833
@@ -1229,7 +1244,7 @@ class HotLoop:
             opt.zero_grad()                                                                # :1934
             with self._phase('mask_loss'):
                 def_vs, pc_sdf_loss = self.mask_loss(N, frame_ids, ratio, cameras)
-            total_loss = total_loss + self._backward_early(pc_sdf_loss)
+            total_loss = total_loss + pc_sdf_loss                  # (detached: differentiated inside, _backward_early)
             d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
             cameras = cameras_rays                                                         # rebuilt graph (:1036)
             with self._phase('sample_rays'):
@@ -1279,11 +1294,11 @@ class HotLoop:
                         curve_done = torch.cuda.Event()
                         curve_done.record()
             with self._phase('pc_sdf'):
-                if curve_done is not None:
-                    main.wait_event(curve_done)          # curve_aware_loss reads the curves after their AdamW step
-                # differentiated NOW: the host would otherwise sit in the render loss's first read-back (the converged-ray count)
-                # until the root finder has finished, with this backward — the SDF nets on ~170 k vertices — still unqueued
-                total_loss = total_loss + self._backward_early(self.pc_sdf_terms(ratio))
+                # differentiated NOW (inside, _backward_early): the host would otherwise sit in the render loss's first read-back
+                # (the converged-ray count) until the root finder has finished, with this backward — the SDF nets on ~170 k
+                # vertices — still unqueued.  curve_aware_loss reads the curves after their AdamW step: the wait sits in front of it
+                total_loss = total_loss + self.pc_sdf_terms(
+                    ratio, before_curve_term=(lambda: main.wait_event(curve_done)) if curve_done is not None else None)
             with on(s_ray), self._phase('render_loss_fwd'):
                 s_ray.wait_event(getattr(self, '_sgd_done', None))
                 render_loss = self.surface_render_loss(N, cameras_rays, frame_ids, ratio, checks, init_ps_list, samples)

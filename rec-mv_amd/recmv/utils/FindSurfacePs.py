@@ -271,7 +271,10 @@ def _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, 
     thousand rays that cannot fill 256 CUs; the garments are independent, so their trains overlap."""
     dev = initTmpPs_list[0].device
     main = torch.cuda.current_stream(dev)
-    streams = _streams(dev, len(initTmpPs_list))
+    # the first garment's chain runs on the caller's stream (the ray pipeline is one chain anyway: sampling -> root finder -> render
+    # loss), only the others get side streams: HIP spreads streams over 4 hardware queues, and a fifth stream shares one — with one
+    # side stream per garment the curve branch's stream sat behind a root finder's 38 ms of launches (tools/phase_overlap.py)
+    streams = [main] + _streams(dev, len(initTmpPs_list) - 1)
     # everything the garments share (weight-normed weights and their transposes, posed skeleton, chain descriptors) is
     # produced BEFORE the side streams fork: on the main stream right here, or — `after` given — earlier by the caller
     # (prepare_root_finder), in which case the side streams wait for the caller's events / streams only and start while
@@ -306,7 +309,9 @@ def _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, 
     states = []
     for g, (initTmpPs, batch_inds, defconds, rays, name) in enumerate(
             zip(initTmpPs_list, batch_inds_list, defconds_list, rays_list, garment_names)):
-        if after is None:
+        if streams[g] is main and after is None:
+            pass
+        elif after is None:
             streams[g].wait_stream(main)
         else:
             for dep in after:
@@ -332,12 +337,14 @@ def _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, 
             st.ev1.record(st.stream)
     outs, oks = [], []
     for st in states:
-        main.wait_stream(st.stream)
+        if st.stream is not main:
+            main.wait_stream(st.stream)
         with torch.cuda.stream(st.stream):
             p, ok = st.result()
-        main.wait_stream(st.stream)
-        p.record_stream(main)
-        ok.record_stream(main)
+        if st.stream is not main:
+            main.wait_stream(st.stream)
+            p.record_stream(main)
+            ok.record_stream(main)
         if os.environ.get('RECMV_ROOT_TRACE'):
             torch.cuda.synchronize()
             print('rootfind %d steps on its stream: %.2f ms; unfinished per step:' % (st.it, st.ev0.elapsed_time(st.ev1)),

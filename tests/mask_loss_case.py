@@ -79,11 +79,13 @@ def run(g, device, rtol=2e-4, rtol_grad=3e-3):
     fake._gt_garment_mask = lambda g_i, fids: (st['gt_u'], st['gt_b'])[g_i]
     for name in ('_deform_garments', 'compute_garment_pc_loss', 'pc_sdf_terms', 'curve_aware_loss'):
         setattr(fake, name, types.MethodType(getattr(HotLoop, name), fake))
+    fake._backward_early = HotLoop._backward_early
     fake.garment_optimizer = torch.optim.SGD(verts, lr=0.05, momentum=0.9)
     cams = RectifiedPerspectiveCameras(st['focal'], st['pp'], st['R'], st['T'], image_size=[(W, H)])
     ratio = {"sdfRatio": 0.8, "deformerRatio": 0.7, "renderRatio": 1.0}
     def_vs, pc_sdf = HotLoop.mask_loss(fake, N, torch.arange(N, device=dev), ratio, cams)
-    pc_sdf.backward()
+    assert not pc_sdf.requires_grad          # (the |SDF| terms are differentiated where they are formed: the reference's
+                                            #  `loss.backward()` on them has already happened, HotLoop._backward_early)
     worst = {}
 
     def close(name, got, want, rt):

@@ -16,7 +16,8 @@ from recmv.loop import HotLoop  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
-loop = HotLoop(conf, torch.device("cuda", 0), n_frames=64, H=512, W=512, curves=True)
+import os  # noqa: E402
+loop = HotLoop(conf, torch.device("cuda", 0), n_frames=64, H=512, W=512, curves=os.environ.get("RECMV_TRACE_NO_CURVES") != "1")
 for it in range(3):
     loop.step(it)
 torch.cuda.synchronize()

@@ -1083,103 +1083,142 @@ class HotLoop:
         self.row_inds = [None] * self.garment_size
         self.col_inds = [None] * self.garment_size
         surface_sample_points = 4096 // self.garment_size
-        total_loss = 0.
         d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
         dev = self.device
+        # The garments' terms are independent chains of small launches (jets on a few thousand points, the colour net, a tail of
+        # element-wise work) — forward AND backward, since autograd runs every node on the stream of its forward.  With
+        # RECMV_RENDER_STREAMS=1 the second garment's chain goes to the root finder's side stream (no new hardware queue), forked
+        # behind everything queued so far and joined before the sum (the host draws its random numbers in the same order either
+        # way, and every garment's terms are summed on their own first: the value does not depend on the schedule).  OFF by
+        # default: measured slower, 110-112 against 108 ms per iteration — the phase is paced by the host's read-backs (subset
+        # sizes, converged-ray counts), not by the device chain (tools/phase_overlap.py, profiles/r03_phase_overlap.txt).
+        side = None
+        if (torch.device(dev).type == 'cuda' and self.garment_size > 1 and os.environ.get('RECMV_SERIAL') != '1'
+                and os.environ.get('RECMV_RENDER_STREAMS', '0') == '1'):
+            from .utils.FindSurfacePs import _streams
+            base = torch.cuda.current_stream(dev)
+            side = _streams(torch.device(dev), self.garment_size - 1)
+            fork = torch.cuda.Event()
+            fork.record()
+        losses = []
         for g_i, (init_ps, sample) in enumerate(zip(init_ps_list, samples)):
-            batch_inds, row_inds, col_inds, _, rays = sample
-            name = self.garment_names[g_i]
-            net = self.garment_nets[g_i]
-            TmpVs = self.garment_vs[g_i]
-            V = TmpVs.shape[0]
+            ctx = contextlib.nullcontext()
+            if side is not None and g_i > 0:
+                side[g_i - 1].wait_event(fork)
+                ctx = torch.cuda.stream(side[g_i - 1])
+            with ctx:
+                losses.append(self._garment_render_terms(g_i, init_ps, sample, N, cameras, ratio, checks[g_i], gtCs, gtNs,
+                                                         surface_sample_points, d_cond_list, poses, trans, rendcond))
+        if side is not None:
+            for st in side:
+                base.wait_stream(st)
+        total_loss = 0.
+        for loss_g in losses:
+            total_loss = total_loss + loss_g
+        return total_loss
+
+    def _garment_render_terms(self, g_i, init_ps, sample, N, cameras, ratio, check, gtCs, gtNs, surface_sample_points,
+                              d_cond_list, poses, trans, rendcond):
+        """One garment's share of surface_render_loss (:1100-1217): eikonal term, deformation regulariser, and on the converged
+        rays the colour and the weighted normal term; leaves what propagateTmpPsGrad reads (TmpPs, rays, pixel indices)."""
+        conf, dev = self.conf, self.device
+        total_loss = 0.
+        batch_inds, row_inds, col_inds, _, rays = sample
+        name = self.garment_names[g_i]
+        net = self.garment_nets[g_i]
+        TmpVs = self.garment_vs[g_i]
+        V = TmpVs.shape[0]
+        sel = torch.rand(V, device=dev) < float(surface_sample_points) / float(V)
+        nonmnfld = utils.sample_points(torch.cat([init_ps, TmpVs[sel].detach()], dim=0), 1.8, 0.01)
+        nonmnfld.requires_grad_()
+        pred = net(nonmnfld, ratio, jet=True, features=False)
+        grad = net.gradient(nonmnfld, pred)
+        grad_loss = ((grad.norm(2, dim=-1) - 1) ** 2).mean()                           # eikonal :1118
+        self.info['{}_grad_loss'.format(name)] = grad_loss.detach()
+        total_loss = total_loss + grad_loss * conf.get_float('grad_weight')
+        d_cond = d_cond_list[g_i + 1]
+        if 'def_regu' in conf and conf.get_float('def_regu.weight') > 0.:               # :1135-1155
             sel = torch.rand(V, device=dev) < float(surface_sample_points) / float(V)
-            nonmnfld = utils.sample_points(torch.cat([init_ps, TmpVs[sel].detach()], dim=0), 1.8, 0.01)
-            nonmnfld.requires_grad_()
-            pred = net(nonmnfld, ratio, jet=True, features=False)
-            grad = net.gradient(nonmnfld, pred)
-            grad_loss = ((grad.norm(2, dim=-1) - 1) ** 2).mean()                           # eikonal :1118
-            self.info['{}_grad_loss'.format(name)] = grad_loss.detach()
-            total_loss = total_loss + grad_loss * conf.get_float('grad_weight')
-            d_cond = d_cond_list[g_i + 1]
-            if 'def_regu' in conf and conf.get_float('def_regu.weight') > 0.:               # :1135-1155
-                sel = torch.rand(V, device=dev) < float(surface_sample_points) / float(V)
-                pts = torch.cat([init_ps, TmpVs[sel].detach()], dim=0)
-                pts = torch.cat([pts, utils.sample_points(pts, 1.8, 0.01, 0)], dim=0).view(1, -1, 3).expand(N, -1, 3)
-                pts = pts.contiguous().requires_grad_()
-                defVs = self.deformer.defs[0](pts, d_cond, ratio=ratio, offset_type=name, jet=True)
-                Jacobs = utils.compute_Jacobian(pts, defVs, True, True)
-                s = torch.log(singular_values_3x3(Jacobs))
-                def_loss = utils.GMRobustError((s * s).sum(1), conf.get_float('def_regu.c'), True).mean()
-                self.info['def_{}_loss'.format(name)] = def_loss.detach()
-                total_loss = total_loss + def_loss * conf.get_float('def_regu.weight')
-            check = checks[g_i]
-            # the reference gates on rayInfo[1] > 0 via .item(); the gate is kept but read once per garment
-            n_valid = int(self._ray_valid[g_i])
-            self.info.setdefault('rays_converged', []).append(n_valid)
-            if n_valid > 0:
-                self.TmpPs[g_i] = init_ps[check]
-                self.TmpPs[g_i].requires_grad = True
-                self.rays[g_i] = rays[check]
-                self.batch_inds[g_i] = batch_inds[check]
-                self.col_inds[g_i] = col_inds[check]
-                self.row_inds[g_i] = row_inds[check]
-                p, b = self.TmpPs[g_i], self.batch_inds[g_i]
-                sdfs = net(p, ratio, jet=True)
-                rend_feat = net.rendcond
-                nx = net.gradient(p, sdfs)           # = autograd.grad(sdfs, p, ones, create_graph=True) (:1169-1172)
-                onx = nx.detach()
-                nx = nx / nx.norm(dim=1, keepdim=True)
-                defconds = [d_cond, [poses, trans]]
-                crays, defVs = utils.compute_cardinal_rays(self.deformer, p, self.rays[g_i], defconds, b, ratio,
-                                                           'train', offset_type=name)
-                grad_d_p = None                      # d(defVs)/dp, formed once for the two terms below that use it
-                if conf.get_float('color_weight') > 0.:
-                    colors = utils.compute_netRender_color(self.netRender, p, defVs, nx, crays, rend_feat,
-                                                           rendcond[b], ratio)
-                    color_loss = (gtCs[b, self.row_inds[g_i], self.col_inds[g_i], :] - colors).abs().sum(1)
-                    color_loss = utils.scatter_mean(color_loss, b, N).mean()
-                    self.info['{}_color_loss'.format(name)] = color_loss.detach()
-                    total_loss = total_loss + conf.get_float('color_weight') * color_loss
-                if 'normal_weight' in conf and conf.get_float('normal_weight') > 0. and gtNs is not None:  # :1191-1217
-                    if 'weighted_normal' in conf and conf.get_bool('weighted_normal'):
-                        # compute_deformed_normals(..., 'test') of the reference (:1196) evaluates the SDF gradient and
-                        # the deformer Jacobian at p once more without a graph; both are at hand already (the SDF jet
-                        # above, the deformer jet of compute_cardinal_rays): J^-T grad f, J grad f where J is singular
-                        if grad_d_p is None:
-                            grad_d_p = utils.compute_Jacobian(p, defVs, True, True)
-                        with torch.no_grad():
-                            Jd = grad_d_p.detach()
-                            Jd_inv, inv_ok = utils.FastDiff3x3MinvFunction.apply(Jd)
-                            cnx = torch.where(inv_ok.view(-1, 1), (Jd_inv.transpose(-2, -1) * onx.unsqueeze(-2)).sum(-1),
-                                              (Jd * onx.unsqueeze(-2)).sum(-1))
-                            cnx = cnx / cnx.norm(dim=1, keepdim=True)
-                        weights = torch.clamp((-self.rays[g_i] * cnx).sum(1).detach(), max=1., min=0.) ** 2
-                    else:
-                        weights = torch.ones(nx.shape[0], device=dev)
-                    gtn = gtNs[b, self.row_inds[g_i], self.col_inds[g_i], :]
-                    flip = torch.diag(torch.ones(3, device=dev) * torch.arange(-1., 2., device=dev).abs().mul(-2.).add(1.))
-                    # = diag(-1, 1, -1), formed on the device (a host list would be a blocking H2D copy on this stream)
-                    M = (cameras.R[0].unsqueeze(-1) * flip.unsqueeze(0)).sum(1)             # R @ flip
-                    gtn = (M.unsqueeze(0) * gtn.unsqueeze(-2)).sum(-1)
-                    gtnorms = gtn.norm(dim=1, keepdim=True)
-                    valid_mask = (gtnorms > 0.0001)[..., 0]
-                    gtn = torch.where(valid_mask.unsqueeze(-1), gtn / gtnorms.clamp(min=1e-12), gtn)
-                    # d(deformed)/dp: the Jacobian carried by compute_cardinal_rays' jet pass over the same points with
-                    # the same parameters (the reference evaluates the deformer once more, :1207-1208)
+            pts = torch.cat([init_ps, TmpVs[sel].detach()], dim=0)
+            pts = torch.cat([pts, utils.sample_points(pts, 1.8, 0.01, 0)], dim=0).view(1, -1, 3).expand(N, -1, 3)
+            pts = pts.contiguous().requires_grad_()
+            defVs = self.deformer.defs[0](pts, d_cond, ratio=ratio, offset_type=name, jet=True)
+            Jacobs = utils.compute_Jacobian(pts, defVs, True, True)
+            s = torch.log(singular_values_3x3(Jacobs))
+            def_loss = utils.GMRobustError((s * s).sum(1), conf.get_float('def_regu.c'), True).mean()
+            self.info['def_{}_loss'.format(name)] = def_loss.detach()
+            total_loss = total_loss + def_loss * conf.get_float('def_regu.weight')
+        # the reference gates on rayInfo[1] > 0 via .item(); the gate is kept but read once per garment
+        n_valid = int(self._ray_valid[g_i])
+        self.info.setdefault('rays_converged', []).append(n_valid)
+        if n_valid > 0:
+            # rows of the converged rays: their count is on the host already, so ONE index list of known size serves the five
+            # gathers (`x[check]` would read its own count back five times: a host round trip each, in the middle of a phase the
+            # device is waiting on — tools/phase_overlap.py)
+            idx = _nonzero_known(check, n_valid)
+            self.TmpPs[g_i] = init_ps.index_select(0, idx)
+            self.TmpPs[g_i].requires_grad = True
+            self.rays[g_i] = rays.index_select(0, idx)
+            self.batch_inds[g_i] = batch_inds.index_select(0, idx)
+            self.col_inds[g_i] = col_inds.index_select(0, idx)
+            self.row_inds[g_i] = row_inds.index_select(0, idx)
+            p, b = self.TmpPs[g_i], self.batch_inds[g_i]
+            sdfs = net(p, ratio, jet=True)
+            rend_feat = net.rendcond
+            nx = net.gradient(p, sdfs)           # = autograd.grad(sdfs, p, ones, create_graph=True) (:1169-1172)
+            onx = nx.detach()
+            nx = nx / nx.norm(dim=1, keepdim=True)
+            defconds = [d_cond, [poses, trans]]
+            crays, defVs = utils.compute_cardinal_rays(self.deformer, p, self.rays[g_i], defconds, b, ratio,
+                                                       'train', offset_type=name)
+            grad_d_p = None                      # d(defVs)/dp, formed once for the two terms below that use it
+            if conf.get_float('color_weight') > 0.:
+                colors = utils.compute_netRender_color(self.netRender, p, defVs, nx, crays, rend_feat,
+                                                       rendcond[b], ratio)
+                color_loss = (gtCs[b, self.row_inds[g_i], self.col_inds[g_i], :] - colors).abs().sum(1)
+                color_loss = utils.scatter_mean(color_loss, b, N).mean()
+                self.info['{}_color_loss'.format(name)] = color_loss.detach()
+                total_loss = total_loss + conf.get_float('color_weight') * color_loss
+            if 'normal_weight' in conf and conf.get_float('normal_weight') > 0. and gtNs is not None:  # :1191-1217
+                if 'weighted_normal' in conf and conf.get_bool('weighted_normal'):
+                    # compute_deformed_normals(..., 'test') of the reference (:1196) evaluates the SDF gradient and
+                    # the deformer Jacobian at p once more without a graph; both are at hand already (the SDF jet
+                    # above, the deformer jet of compute_cardinal_rays): J^-T grad f, J grad f where J is singular
                     if grad_d_p is None:
                         grad_d_p = utils.compute_Jacobian(p, defVs, True, True)
-                    gtn = (grad_d_p.transpose(-2, -1) * gtn.unsqueeze(-2)).sum(-1)
-                    normal_loss = (gtn - nx).norm(2, dim=1) * weights
-                    w = valid_mask.to(normal_loss.dtype)
-                    from .ops import rows_sum_by_index                   # per-frame sums in a fixed order
-                    num = rows_sum_by_index((normal_loss * w).view(-1, 1), b, N).view(-1)
-                    den = rows_sum_by_index(w.view(-1, 1), b, N).view(-1)
-                    normal_loss = (num / den.clamp(min=1)).mean()
-                    self.info['{}_normal_loss'.format(name)] = normal_loss.detach()
-                    total_loss = total_loss + conf.get_float('normal_weight') * normal_loss
-                # for propagateTmpPsGrad: the two jets at these points (same parameters until the optimiser steps)
-                self.__dict__.setdefault('_prop_pre', {})[g_i] = (
-                    p, onx, grad_d_p.detach() if grad_d_p is not None else None, _param_versions(net, self.deformer))
+                    with torch.no_grad():
+                        Jd = grad_d_p.detach()
+                        Jd_inv, inv_ok = utils.FastDiff3x3MinvFunction.apply(Jd)
+                        cnx = torch.where(inv_ok.view(-1, 1), (Jd_inv.transpose(-2, -1) * onx.unsqueeze(-2)).sum(-1),
+                                          (Jd * onx.unsqueeze(-2)).sum(-1))
+                        cnx = cnx / cnx.norm(dim=1, keepdim=True)
+                    weights = torch.clamp((-self.rays[g_i] * cnx).sum(1).detach(), max=1., min=0.) ** 2
+                else:
+                    weights = torch.ones(nx.shape[0], device=dev)
+                gtn = gtNs[b, self.row_inds[g_i], self.col_inds[g_i], :]
+                flip = torch.diag(torch.ones(3, device=dev) * torch.arange(-1., 2., device=dev).abs().mul(-2.).add(1.))
+                # = diag(-1, 1, -1), formed on the device (a host list would be a blocking H2D copy on this stream)
+                M = (cameras.R[0].unsqueeze(-1) * flip.unsqueeze(0)).sum(1)             # R @ flip
+                gtn = (M.unsqueeze(0) * gtn.unsqueeze(-2)).sum(-1)
+                gtnorms = gtn.norm(dim=1, keepdim=True)
+                valid_mask = (gtnorms > 0.0001)[..., 0]
+                gtn = torch.where(valid_mask.unsqueeze(-1), gtn / gtnorms.clamp(min=1e-12), gtn)
+                # d(deformed)/dp: the Jacobian carried by compute_cardinal_rays' jet pass over the same points with
+                # the same parameters (the reference evaluates the deformer once more, :1207-1208)
+                if grad_d_p is None:
+                    grad_d_p = utils.compute_Jacobian(p, defVs, True, True)
+                gtn = (grad_d_p.transpose(-2, -1) * gtn.unsqueeze(-2)).sum(-1)
+                normal_loss = (gtn - nx).norm(2, dim=1) * weights
+                w = valid_mask.to(normal_loss.dtype)
+                from .ops import rows_sum_by_index                   # per-frame sums in a fixed order
+                num = rows_sum_by_index((normal_loss * w).view(-1, 1), b, N).view(-1)
+                den = rows_sum_by_index(w.view(-1, 1), b, N).view(-1)
+                normal_loss = (num / den.clamp(min=1)).mean()
+                self.info['{}_normal_loss'.format(name)] = normal_loss.detach()
+                total_loss = total_loss + conf.get_float('normal_weight') * normal_loss
+            # for propagateTmpPsGrad: the two jets at these points (same parameters until the optimiser steps)
+            self.__dict__.setdefault('_prop_pre', {})[g_i] = (
+                p, onx, grad_d_p.detach() if grad_d_p is not None else None, _param_versions(net, self.deformer))
         return total_loss
 
     def dct_poses_loss(self, poses, trans, frame_ids, N):
@@ -1201,7 +1240,7 @@ class HotLoop:
         they exist (like the mask loss's own, :959) instead of inside the caller's `loss.backward()`, and the value travels on in
         the returned loss detached.  The gradients are the same sums, accumulated as (mask loss) + (|SDF| terms) + (render loss +
         pose prior) — the order is the same in the serial and in the three-stream schedule."""
-        if torch.is_tensor(loss) and loss.requires_grad:
+        if torch.is_tensor(loss) and loss.requires_grad and os.environ.get('RECMV_EARLY_BWD', '1') != '0':
             loss.backward()
             return loss.detach()
         return loss
@@ -1504,6 +1543,13 @@ def sample_fan_mesh(verts, faces, count, generator=None):
     r = torch.rand(count, 2, device=verts.device, generator=generator)
     r = torch.where((r.sum(1, keepdim=True) > 1.0), r - 1.0, r).abs()
     return tri[f, 0] + e1[f] * r[:, 0:1] + e2[f] * r[:, 1:2]
+
+
+def _nonzero_known(mask, count):
+    """Indices of the `count` set entries of a 1-D boolean mask, in increasing order, without reading the count back."""
+    if hasattr(torch, 'nonzero_static') and mask.is_cuda:
+        return torch.nonzero_static(mask, size=int(count)).view(-1)
+    return mask.nonzero(as_tuple=True)[0]
 
 
 def _n_frames(dataset):

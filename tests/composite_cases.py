@@ -98,6 +98,7 @@ def run_render_loss(device, rtol_loss=2e-4, rtol_info=5e-4, rtol_grad=5e-3, atol
     fake.get_grad_parameters = lambda fids, dev: ([None, leaves["conds"]], leaves["poses"], leaves["trans"],
                                                   leaves["rendcond"])
     fake._ray_valid = [g["in_check"].sum()]
+    fake._garment_render_terms = types.MethodType(HotLoop._garment_render_terms, fake)
     cameras = types.SimpleNamespace(R=g["in_R"])
     samples = [(g["in_binds"], g["in_row"], g["in_col"], None, g["in_rays"])]
     torch.manual_seed(int(g["seed"]))

@@ -1071,6 +1071,15 @@ class HotLoop:
             after=after)
         self.info['rays_total'] = sum(c.numel() for c in checks)
         self._ray_valid = [c.sum() for c in checks]
+        self._ray_valid_host = None
+        if checks and checks[0].is_cuda:
+            # the converged-ray counts travel to pinned memory behind the root finder; the render loss waits for THIS copy (an event),
+            # once for all garments, instead of one blocking read per garment
+            host = torch.empty(len(checks), dtype=torch.int64).pin_memory()
+            host.copy_(torch.stack(self._ray_valid), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ray_valid_host = (host, ev)
         return pts, checks
 
     # ------------------------------------------------------------------------------------------ render loss
@@ -1127,9 +1136,7 @@ class HotLoop:
         name = self.garment_names[g_i]
         net = self.garment_nets[g_i]
         TmpVs = self.garment_vs[g_i]
-        V = TmpVs.shape[0]
-        sel = torch.rand(V, device=dev) < float(surface_sample_points) / float(V)
-        nonmnfld = utils.sample_points(torch.cat([init_ps, TmpVs[sel].detach()], dim=0), 1.8, 0.01)
+        nonmnfld = utils.sample_points(torch.cat([init_ps, _host_subset(TmpVs, surface_sample_points)], dim=0), 1.8, 0.01)
         nonmnfld.requires_grad_()
         pred = net(nonmnfld, ratio, jet=True, features=False)
         grad = net.gradient(nonmnfld, pred)
@@ -1138,8 +1145,7 @@ class HotLoop:
         total_loss = total_loss + grad_loss * conf.get_float('grad_weight')
         d_cond = d_cond_list[g_i + 1]
         if 'def_regu' in conf and conf.get_float('def_regu.weight') > 0.:               # :1135-1155
-            sel = torch.rand(V, device=dev) < float(surface_sample_points) / float(V)
-            pts = torch.cat([init_ps, TmpVs[sel].detach()], dim=0)
+            pts = torch.cat([init_ps, _host_subset(TmpVs, surface_sample_points)], dim=0)
             pts = torch.cat([pts, utils.sample_points(pts, 1.8, 0.01, 0)], dim=0).view(1, -1, 3).expand(N, -1, 3)
             pts = pts.contiguous().requires_grad_()
             defVs = self.deformer.defs[0](pts, d_cond, ratio=ratio, offset_type=name, jet=True)
@@ -1149,7 +1155,12 @@ class HotLoop:
             self.info['def_{}_loss'.format(name)] = def_loss.detach()
             total_loss = total_loss + def_loss * conf.get_float('def_regu.weight')
         # the reference gates on rayInfo[1] > 0 via .item(); the gate is kept but read once per garment
-        n_valid = int(self._ray_valid[g_i])
+        host = getattr(self, '_ray_valid_host', None)
+        if host is not None:
+            host[1].synchronize()
+            n_valid = int(host[0][g_i])
+        else:
+            n_valid = int(self._ray_valid[g_i])
         self.info.setdefault('rays_converged', []).append(n_valid)
         if n_valid > 0:
             # rows of the converged rays: their count is on the host already, so ONE index list of known size serves the five
@@ -1543,6 +1554,18 @@ def sample_fan_mesh(verts, faces, count, generator=None):
     r = torch.rand(count, 2, device=verts.device, generator=generator)
     r = torch.where((r.sum(1, keepdim=True) > 1.0), r - 1.0, r).abs()
     return tri[f, 0] + e1[f] * r[:, 0:1] + e2[f] * r[:, 1:2]
+
+
+def _host_subset(verts, expected):
+    """`verts[torch.rand(V) < expected / V].detach()` as the reference draws it (OptimGarmentNetwork.py:1108, :1138): the Bernoulli
+    mask comes from torch's HOST generator, so the size of the subset is known without asking the device — the selected rows travel
+    as a pinned index list (the compare and the index extraction in numpy: torch would fork its intra-op pool for ~1e5 elements)."""
+    V = verts.shape[0]
+    sel = torch.rand(V).numpy() < float(expected) / float(V)
+    idx = torch.from_numpy(np.flatnonzero(sel))
+    if verts.is_cuda:
+        idx = idx.pin_memory().to(verts.device, non_blocking=True)
+    return verts.detach().index_select(0, idx)
 
 
 def _nonzero_known(mask, count):

@@ -106,6 +106,9 @@ class _RootState:
         self.host_np = self.host.numpy()          # the same pinned words, read without creating tensors
         self.sdf_chain = tmpSdf.chain(tmpSdf._pe_weights(ratio), need_t=True)
         assert tmpSdf.d_out == 1
+        self.live = P                 # rows the steps run over: all of them until the compaction (see _compact)
+        self.perm = None
+        self.mark_ev = None
         if P == 0:
             self.finished = True
 
@@ -113,14 +116,45 @@ class _RootState:
         """One step on the current stream — identical every time it is called."""
         from .. import chains
         dthr, athr, w1, w2 = self.args
-        p = self.p
+        n = self.live
+        p, frame, rays, unfinished = self.p[:n], self.frame[:n], self.rays[:n], self.unfinished[:n]
         f = self.sdf_chain.forward(p, n_out=1, keep=True)
         gf = self.sdf_chain.vjp_input(p, None)
-        _, loss2, angle, gd = self.deformer.ray_energy_and_vjp(p, self.conds, self.frame, self.cam, self.rays,
+        _, loss2, angle, gd = self.deformer.ray_energy_and_vjp(p, self.conds, frame, self.cam, rays,
                                                                ratio=self.ratio, offset_type=self.name)
-        chains.rootfind_step(p, f, gf, loss2, angle, gd, self.unfinished, self.counters, self.marks, self.state, dthr,
+        chains.rootfind_step(p, f, gf, loss2, angle, gd, unfinished, self.counters, self.marks, self.state, dthr,
                              athr, w1, w2, self.times)
         self.host.copy_(self.marks, non_blocking=True)
+        if self.it == 1:
+            self.mark_ev = torch.cuda.Event()
+            self.mark_ev.record()
+
+    # The reference shrinks the active ray set every step (utils/FindSurfacePs.py:300-303); carrying every ray through all 21 steps
+    # costs the rows of the rays that are done — on the settled bench scene 17 % of them after the first update, then ~1 % more per
+    # step (profiles/r03_rootfind_unfinished_per_step.txt).  ONE compaction after the first update takes most of that: the host waits
+    # for that step's unfinished-ray count (a few ms into a phase in which it has slack), the unfinished rays move to the front
+    # (stable), and the remaining steps run over exactly those rows.  Rows are independent and the 64 x 32 product kernel serves
+    # every row count these launches have, so every ray gets the same bits as without the compaction; result() undoes the order.
+    COMPACT_MIN_ROWS = 1024
+    COMPACT_MAX_KEEP = 0.93
+
+    def _compact(self):
+        P = self.p.shape[0]
+        if (self.perm is not None or self.use_graph or P < self.COMPACT_MIN_ROWS or self.mark_ev is None
+                or os.environ.get('RECMV_ROOT_COMPACT', '1') == '0'):
+            return
+        self.mark_ev.synchronize()
+        n = int(self.host_np[1]) - 1
+        if n <= 0 or n > self.COMPACT_MAX_KEEP * P:
+            return
+        with torch.cuda.stream(self.stream):
+            un = self.unfinished != 0
+            order = torch.cat([torch.nonzero_static(un, size=n).view(-1), torch.nonzero_static(~un, size=P - n).view(-1)])
+            self.p = self.p.index_select(0, order)
+            self.rays = self.rays.index_select(0, order)
+            self.frame = self.frame.index_select(0, order)
+            self.unfinished = self.unfinished.index_select(0, order)
+        self.perm, self.live = order, n
 
     def step(self):
         """Enqueue one iteration on this garment's stream; returns False once the iteration is over."""
@@ -162,13 +196,19 @@ class _RootState:
                     self.graph = g
                 self.graph.replay()
         self.it += 1
+        if self.it == 2:
+            self._compact()
         return True
 
     def steps_trace(self):
         return [int(m) - 1 for m in self.host_np[:self.it]]
 
     def result(self):
-        return self.p, self.unfinished == 0
+        if self.perm is None:
+            return self.p, self.unfinished == 0
+        p = torch.empty_like(self.p).index_copy_(0, self.perm, self.p)
+        ok = torch.empty_like(self.unfinished).index_copy_(0, self.perm, self.unfinished) == 0
+        return p, ok
 
 
 class _RootGroup(_RootState):
@@ -188,6 +228,7 @@ class _RootGroup(_RootState):
         self.times, self.it, self.finished = times, 0, False
         self.deformer, self.ratio, self.name = deformer, ratio, 'rootfind'
         self.graph, self.use_graph = None, False
+        self.perm = self.mark_ev = None                   # (no compaction in the one-block form)
         sizes = [int(p.shape[0]) for p in initTmpPs_list]
         live = [g for g, n in enumerate(sizes) if n > 0]
         assert len(initTmpPs_list) <= 2, 'only support less or equal than 2 garment_type'

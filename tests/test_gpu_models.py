@@ -211,6 +211,41 @@ def test_root_finder(nets):
     assert err.max().item() < 2e-4, err.max().item()
 
 
+def test_root_finder_compaction_changes_no_ray(nets):
+    """After the first update the unfinished rays move to the front and the remaining steps run over those rows only (the
+    reference shrinks its active set every step, utils/FindSurfacePs.py:300-303): every ray ends where it ends without the
+    compaction, bit for bit, with the same convergence flags, in the original order — two garments of different sizes, enough
+    rays for the compaction to trigger."""
+    import common_setup as cs
+    from recmv.model import getTmpSdf
+    from recmv.utils import OptimizeGarmentSurfacePs
+    from recmv.utils.FindSurfacePs import _RootState
+    g, gt, gl = load("rootfind"), load("translator"), load("lbs")
+    conds = gt["conds"].to(DEV)
+    poses, trans = gl["poses"].to(DEV), gl["trans"].to(DEV)
+    sdf2 = cs.perturb(getTmpSdf("cpu", 6, bias=0.55), 77, 0.01).to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    reps = -(-2 * _RootState.COMPACT_MIN_ROWS // g["start"].shape[0])
+    jitter = lambda t: (t.repeat(reps, 1) + 1e-3 * torch.randn(t.shape[0] * reps, 3, generator=gen)).to(DEV)
+    start, rays, binds = jitter(g["start"]), g["rays"].repeat(reps, 1).to(DEV), g["binds"].repeat(reps).to(DEV)
+    k = start.shape[0] - 300
+
+    def run(compact):
+        os.environ['RECMV_ROOT_COMPACT'] = '1' if compact else '0'
+        try:
+            return OptimizeGarmentSurfacePs(g["cam_pos"].to(DEV), [rays, rays[:k]], [start.clone(), start[:k] * 0.98], [binds, binds[:k]],
+                                            [nets["sdf"], sdf2], RATIO, nets["comp"], [[conds, conds], [poses, trans]],
+                                            garment_names=["a", "b"], dthreshold=5.e-5, athreshold=0.02, w1=3.05, w2=1., times=20)
+        finally:
+            os.environ.pop('RECMV_ROOT_COMPACT', None)
+
+    (pa, oa), (pb, ob) = run(True), run(False)
+    for x, y in zip(pa + oa, pb + ob):
+        assert x.shape == y.shape and torch.equal(x, y)
+    done = float(oa[0].float().mean())
+    assert 0.07 < done < 0.95, done           # (the compaction had something to drop and something to keep)
+
+
 def test_root_finder_all_garments_in_one_block_equals_per_garment(nets):
     """The root finder over BOTH garments' rays as one block of rows (row-segmented SDF weights, shared offset MLP / skinner with
     a concatenated code table; utils/FindSurfacePs.py:273-353 loops over the garments) against one launch chain per garment.

@@ -63,7 +63,8 @@ HBM_PEAK = 8.0e12             # B/s
 
 
 NT_VARIANTS = ["gemm_nt_kernel<%d, %s, %s>" % (1 + (v & 1), "true" if v & 2 else "false", "true" if v & 4 else "false")
-               for v in range(8)] + ["gemm_tn_kernel (+ splitk_reduce_kernel)"]
+               for v in range(8)] + ["gemm_tn_occ_kernel<16> (+ splitk_reduce_kernel)", "gemm_nt_occ_kernel<false, 16, true, 2, 2>",
+                                      "gemm_nt_occ_kernel<false, 16, true, 1, 2>", "gemm_nt_occ_kernel<true, 16, true, *, 2>"]
 
 
 class KernelEvents:
@@ -81,8 +82,8 @@ class KernelEvents:
     def end(self):
         import ctypes as C
         from recmv import _lib as L
-        buf = (C.c_double * 45)()
-        L.check(L.lib().recmv_profile_end(C.cast(buf, C.c_void_p), 9), "profile_end")
+        buf = (C.c_double * (5 * len(NT_VARIANTS)))()
+        L.check(L.lib().recmv_profile_end(C.cast(buf, C.c_void_p), len(NT_VARIANTS)), "profile_end")
         out, small = {}, {}
         for v, name in enumerate(NT_VARIANTS):
             n, sec, fl, un, ufl = buf[5 * v:5 * v + 5]
@@ -341,7 +342,9 @@ def pmc_traffic(kernel_name):
         return None
     stamp = "profiles/%s (%s)" % (f.name, table.get("measured_at", "round-2 passes of 13:13, before the batching / mulgrad / "
                                                                  "gemm_tn changes; commit not recorded"))
-    # bench names the variant by <T, FAST, AMUL>; the kernel's 4th template argument is the matrix mode (BF3)
+    if kernel_name in table.get("kernels", {}):                      # gemm_nt_occ_kernel<...>: the full symbol is the name
+        return dict(table["kernels"][kernel_name], traffic_source=stamp)
+    # bench names gemm_nt_kernel by <T, FAST, AMUL>; the kernel's 4th template argument is the matrix mode (BF3)
     want = kernel_name.split(" ")[0].rstrip(">")
     mode = ", true>" if "bf16x6" in kernel_name else ", false>"
     for k, v in table.get("kernels", {}).items():

@@ -178,11 +178,11 @@ __device__ __forceinline__ float4 emul4(float4 v, const AMul& m, int gm, int gn,
   return v;
 }
 
-template <int T, int ACT>
-__device__ __forceinline__ void nt_epilogue(const float* __restrict__ Cs, const float* __restrict__ bias,
-                                            float* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
-                                            float act_param, float out_scale, bool c_vec, const AMul& em) {
-  constexpr int TBM = 64 * T, TBN = 64 * T, LDC = TBN + 4;
+template <int TBM, int TBN, int ACT>
+__device__ __forceinline__ void nt_epilogue_rows(const float* __restrict__ Cs, const float* __restrict__ bias,
+                                                 float* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
+                                                 float act_param, float out_scale, bool c_vec, const AMul& em) {
+  constexpr int LDC = TBN + 4;
   constexpr int C4 = TBN / 4;                 // float4 strips per tile row (32 or 16): divides kBlk
   constexpr int ROWS_PER_PASS = kBlk / C4;    // 8 or 16
   const int tid = threadIdx.x;
@@ -218,6 +218,13 @@ __device__ __forceinline__ void nt_epilogue(const float* __restrict__ Cs, const 
       if (gn + 3 < N) dst[3] = v.w;
     }
   }
+}
+
+template <int T, int ACT>
+__device__ __forceinline__ void nt_epilogue(const float* __restrict__ Cs, const float* __restrict__ bias,
+                                            float* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
+                                            float act_param, float out_scale, bool c_vec, const AMul& em) {
+  nt_epilogue_rows<64 * T, 64 * T, ACT>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec, em);
 }
 
 template <int T, bool FAST, bool AMUL, bool BF3>
@@ -385,6 +392,159 @@ __global__ __launch_bounds__(kBlk) void gemm_nt_kernel(const float* __restrict__
       break;
     default:
       nt_epilogue<T, RECMV_ACT_NONE>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec, AMUL ? AMul{nullptr, 0, 0, 0.f, 1.f, 1.f} : am);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ NT 128x128, three workgroups per CU
+// The 128x128 f32 kernel above keeps two K-tiles of both operands in LDS (72 KB): two workgroups per CU, i.e. two waves per SIMD, and
+// with K = 512 a workgroup lives for only 16 K-tiles — its prologue (first operand tile from HBM) and its epilogue (accumulators ->
+// LDS -> activation -> HBM) leave its SIMD partner alone with the matrix pipe for ~15 % of its life, and one wave alone does not
+// keep the pipe busy across its own barriers.  This variant holds LESS in LDS so that THREE workgroups fit a CU (registers allow
+// exactly three: 94 + 64 accumulators): either one K-tile of 32 columns (SINGLE: the next tile waits in registers, two barriers per
+// tile) or two K-tiles of 16 columns; the epilogue goes through LDS in two halves of 64 rows.  Same products in the same order
+// as gemm_nt_kernel<2, true, ...>: bit-identical results.
+template <bool AMUL, int BKT, bool SINGLE, int MI, int NI>
+__global__ __launch_bounds__(kBlk, (MI * NI == 4 ? (BKT <= 16 ? 4 : 3) : 5))
+void gemm_nt_occ_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                        const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int M, int N, int K, int act,
+                        float act_param, float out_scale, int nbm, int nbn, bool c_vec, AMul am) {
+  constexpr int TBM = 64 * MI, TBN = 64 * NI;   // workgroup tile; 2 x 2 waves of (32 MI) x (32 NI)
+  constexpr int LDKT = BKT + 4;                 // padded k stride (floats) of an LDS row
+  constexpr int C4R = BKT / 4;                  // float4 per operand row and K-tile
+  constexpr int NLA = TBM * C4R / kBlk, NLB = TBN * C4R / kBlk;   // float4 per thread per operand tile
+  constexpr int NBUF = SINGLE ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                             // [NBUF][TBM][LDKT]
+  float* Bs = smem + NBUF * TBM * LDKT;         // [NBUF][TBN][LDKT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t logical = xcd_remap(blockIdx.x, (int64_t)nbm * nbn);
+  const int tile_m = (int)(logical / nbn), tile_n = (int)(logical % nbn);
+  const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+  if (am.B2 && m0 >= am.split) {
+    B = am.B2;
+    bias = am.bias2;
+  }
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < NI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 ra[NLA], rb[NLB];
+  const float* pa[NLA];
+  const float* pb[NLB];
+  const float* py[NLA];
+#pragma unroll
+  for (int r = 0; r < NLA; ++r) {
+    const int idx = tid + kBlk * r;
+    int gm = m0 + idx / C4R;
+    gm = gm < M ? gm : M - 1;                   // clamped rows are computed and never stored
+    pa[r] = A + (int64_t)gm * lda + (idx % C4R) * 4;
+    if (AMUL) py[r] = am.Y + (int64_t)gm * am.ldy + (idx % C4R) * 4;
+  }
+#pragma unroll
+  for (int r = 0; r < NLB; ++r) {
+    const int idx = tid + kBlk * r;
+    int gn = n0 + idx / C4R;
+    gn = gn < N ? gn : N - 1;
+    pb[r] = B + (int64_t)gn * ldb + (idx % C4R) * 4;
+  }
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < NLA; ++r) {
+      const bool in = k0 + ((tid + kBlk * r) % C4R) * 4 < K;       // K % 4 == 0: a float4 is entirely inside or outside
+      ra[r] = in ? *reinterpret_cast<const float4*>(pa[r] + k0) : make_float4(0, 0, 0, 0);
+      if (AMUL && in) ra[r] = amul4(ra[r], *reinterpret_cast<const float4*>(py[r] + k0), am);
+    }
+#pragma unroll
+    for (int r = 0; r < NLB; ++r) {
+      const bool in = k0 + ((tid + kBlk * r) % C4R) * 4 < K;
+      rb[r] = in ? *reinterpret_cast<const float4*>(pb[r] + k0) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < NLA; ++r) {
+      const int idx = tid + kBlk * r;
+      *reinterpret_cast<float4*>(As + (buf * TBM + idx / C4R) * LDKT + (idx % C4R) * 4) = ra[r];
+    }
+#pragma unroll
+    for (int r = 0; r < NLB; ++r) {
+      const int idx = tid + kBlk * r;
+      *reinterpret_cast<float4*>(Bs + (buf * TBN + idx / C4R) * LDKT + (idx % C4R) * 4) = rb[r];
+    }
+  };
+
+  const int nk = (K + BKT - 1) / BKT;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int arow = wm * 32 * MI + (lane & 31), brow = wn * 32 * NI + (lane & 31), khalf = (lane >> 5) * 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = SINGLE ? 0 : (kt & 1);
+    if (kt + 1 < nk) gload((kt + 1) * BKT);
+    const float* as = As + (buf * TBM + arow) * LDKT + khalf;
+    const float* bs = Bs + (buf * TBN + brow) * LDKT + khalf;
+#pragma unroll
+    for (int kk = 0; kk < BKT / 8; ++kk) {
+      float4 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDKT + kk * 8);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) b[i] = *reinterpret_cast<const float4*>(bs + i * 32 * LDKT + kk * 8);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+        }
+    }
+    if (SINGLE) __syncthreads();                 // every wave has read the tile: the buffer may be overwritten
+    if (kt + 1 < nk) lstore(SINGLE ? 0 : (buf ^ 1));
+    __syncthreads();
+  }
+
+  // accumulators -> LDS -> HBM in two passes: pass h takes the rows of the waves with wm == h (the half-tile fits the LDS the
+  // occupancy allows)
+  constexpr int HR = 32 * MI, LDC = TBN + 4;
+  float* Cs = smem;                              // [HR][LDC]
+  const AMul em = AMUL ? AMul{nullptr, 0, 0, 0.f, 1.f, 1.f} : am;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+    if (wm == h) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = wn * 32 * NI + ni * 32 + (lane & 31);
+            Cs[row * LDC + col] = acc[mi][ni][r];
+          }
+    }
+    __syncthreads();
+    const int mh = m0 + HR * h;
+    switch (act) {
+      case RECMV_ACT_RELU:
+        nt_epilogue_rows<HR, TBN, RECMV_ACT_RELU>(Cs, bias, C, ldc, M, N, mh, n0, act_param, out_scale, c_vec, em);
+        break;
+      case RECMV_ACT_SOFTPLUS:
+        nt_epilogue_rows<HR, TBN, RECMV_ACT_SOFTPLUS>(Cs, bias, C, ldc, M, N, mh, n0, act_param, out_scale, c_vec, em);
+        break;
+      case RECMV_ACT_TANH:
+        nt_epilogue_rows<HR, TBN, RECMV_ACT_TANH>(Cs, bias, C, ldc, M, N, mh, n0, act_param, out_scale, c_vec, em);
+        break;
+      default:
+        nt_epilogue_rows<HR, TBN, RECMV_ACT_NONE>(Cs, bias, C, ldc, M, N, mh, n0, act_param, out_scale, c_vec, em);
+    }
   }
 }
 
@@ -978,6 +1138,110 @@ __global__ __launch_bounds__(kBlk) void gemm_tn_kernel(const float* __restrict__
   }
 }
 
+// The same partial products with ONE 16-row K-tile in LDS (17 KB instead of 68 KB) and at most 128 registers: four workgroups
+// per CU instead of two (the same step the NT kernel took: a workgroup's barriers, prologue and register -> HBM epilogue are
+// covered by three neighbours instead of one).  f32 mode, aligned whole-float4 operands only; same summation order.
+template <int BKT>
+__global__ __launch_bounds__(kBlk, 4) void gemm_tn_occ_kernel(const float* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ B, int64_t ldb,
+                                                              float* __restrict__ P, int M, int N, int64_t K, int nbm,
+                                                              int nbn, int64_t kchunk) {
+  constexpr int NLD = BKT * 32 / kBlk;    // float4 per thread per operand tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                       // [BKT][LDM]
+  float* Bs = smem + BKT * LDM;           // [BKT][LDM]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles = nbm * nbn;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int tile_m = tile / nbn, tile_n = tile % nbn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int64_t kbeg = (int64_t)split * kchunk;
+  int64_t kend = kbeg + kchunk;
+  if (kend > K) kend = K;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 ra[NLD], rb[NLD];
+  const bool whole_mn = m0 + BM <= M && n0 + BN <= N;
+  auto gload = [&](int64_t k0) {
+    const bool whole = whole_mn && k0 + BKT <= kend;
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+      const int idx = tid + kBlk * r;
+      const int krow = idx >> 5, c4 = idx & 31;
+      const int64_t k = k0 + krow;
+      const int cm = m0 + c4 * 4, cn = n0 + c4 * 4;
+      if (whole) {
+        ra[r] = *reinterpret_cast<const float4*>(A + k * lda + cm);
+        rb[r] = *reinterpret_cast<const float4*>(B + k * ldb + cn);
+      } else {
+        const bool kin = k < kend, ain = kin && cm < M, bin = kin && cn < N;
+        const int64_t kc = kin ? k : kend - 1;
+        float4 a = *reinterpret_cast<const float4*>(A + kc * lda + (cm < M ? cm : M - 4));
+        float4 b = *reinterpret_cast<const float4*>(B + kc * ldb + (cn < N ? cn : N - 4));
+        ra[r] = make_float4(ain ? a.x : 0.f, ain ? a.y : 0.f, ain ? a.z : 0.f, ain ? a.w : 0.f);
+        rb[r] = make_float4(bin ? b.x : 0.f, bin ? b.y : 0.f, bin ? b.z : 0.f, bin ? b.w : 0.f);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+      const int idx = tid + kBlk * r;
+      const int krow = idx >> 5, c4 = idx & 31;
+      *reinterpret_cast<float4*>(As + krow * LDM + c4 * 4) = ra[r];
+      *reinterpret_cast<float4*>(Bs + krow * LDM + c4 * 4) = rb[r];
+    }
+  };
+
+  const int nk = (int)((kend - kbeg + BKT - 1) / BKT);
+  if (nk > 0) {
+    gload(kbeg);
+    lstore();
+  }
+  __syncthreads();
+  const int acol = wm * 64 + (lane & 31), bcol = wn * 64 + (lane & 31), kh = lane >> 5;
+  const float* as = As + kh * LDM + acol;
+  const float* bs = Bs + kh * LDM + bcol;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(kbeg + (int64_t)(kt + 1) * BKT);
+#pragma unroll
+    for (int k2 = 0; k2 < BKT / 2; ++k2) {
+      const float a0 = as[k2 * 2 * LDM], a1 = as[k2 * 2 * LDM + 32];
+      const float b0 = bs[k2 * 2 * LDM], b1 = bs[k2 * 2 * LDM + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) lstore();
+    __syncthreads();
+  }
+
+  float* Ps = P + (int64_t)split * M * N;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int gn = n0 + wn * 64 + ni * 32 + (lane & 31);
+    if (gn >= N) continue;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm < M) Ps[(int64_t)gm * N + gn] = acc[mi][ni][r];
+      }
+    }
+  }
+}
+
 // C[m][n] = sum_s P[s][m][n]   (fixed order -> deterministic)
 __global__ __launch_bounds__(kBlk) void splitk_reduce_kernel(const float* __restrict__ P, float* __restrict__ C,
                                                              int64_t ldc, int M, int N, int splits) {
@@ -1035,7 +1299,7 @@ struct LaunchRec {
 struct Profiler {
   bool on = false;
   double min_flops = 0.0;          // launches below this are counted but not bracketed by events
-  double untimed[9][2] = {};       // [variant][launches, flops]
+  double untimed[12][2] = {};      // [variant][launches, flops]
   std::vector<LaunchRec> recs;
   std::vector<hipEvent_t> pool;
   std::mutex mu;        // autograd's backward thread launches too
@@ -1089,6 +1353,11 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 constexpr int kNtLds = (2 * BM * LDK + 2 * BN * LDK) * 4;   // 73728 B (T=2); half of it for T=1
 constexpr int kTnLds = (4 * BK * LDM) * 4;                  // 67584 B
 
+bool tn_occ() {     // RECMV_GEMM_OCC=0: the two-workgroups-per-CU kernels (A/B)
+  static const bool v = [] { const char* e = getenv("RECMV_GEMM_OCC"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
 int tn_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
   int64_t want = ceil_div((int64_t)kNumCU * 4, tiles);        // ~4 workgroups per CU overall
@@ -1123,6 +1392,20 @@ static int launch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, c
                      lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, a_vec,
                      b_vec, c_vec, am);
   return check_launch("gemm_nt");
+}
+
+template <bool AMUL, int BKT, bool SINGLE, int MI, int NI>
+static int launch_nt_occ(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
+                         int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
+                         bool c_vec, const AMul& am, hipStream_t stream) {
+  constexpr int lds_ops = (SINGLE ? 1 : 2) * 64 * (MI + NI) * (BKT + 4) * 4, lds_c = 32 * MI * (64 * NI + 4) * 4;
+  constexpr int lds = lds_ops > lds_c ? lds_ops : lds_c;
+  const int nbm = (int)ceil_div(M, 64 * MI), nbn = (int)ceil_div(N, 64 * NI);
+  ScopedLaunchTimer timer(AMUL ? 11 : (MI == 2 ? 9 : 10), 2.0 * M * N * K, stream);
+  hipLaunchKernelGGL((gemm_nt_occ_kernel<AMUL, BKT, SINGLE, MI, NI>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds,
+                     stream, A, lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, c_vec,
+                     am);
+  return check_launch("gemm_nt(occ)");
 }
 
 template <int T, bool AMUL>
@@ -1176,6 +1459,16 @@ static int dispatch_nt(const float* A, int64_t lda, const float* B, int64_t ldb,
   if (big_blocks >= 2 * kNumCU) {
     if (g_gemm_mode == 1 && fast) {
       return launch_nt_b3<2, AMUL>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, c_vec, am, s);
+    }
+    // f32 mode, aligned operands: the high-occupancy kernels (gemm_nt_occ_kernel) — 128x128 tiles at four workgroups per CU
+    // for the largest launches, 64x128 tiles at five per CU below ~3600 large tiles (finer tail, measured crossover between
+    // 90 k and 150 k rows at N = 512: profiles/r03_gemm_occupancy_variants.txt).  RECMV_GEMM_OCC=0 keeps the two-per-CU
+    // kernel for the A/B.
+    static const bool occ = [] { const char* e = getenv("RECMV_GEMM_OCC"); return !(e && e[0] == '0'); }();
+    if (fast && g_gemm_mode == 0 && occ) {
+      if (big_blocks >= 3600)
+        return launch_nt_occ<AMUL, 16, true, 2, 2>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, c_vec, am, s);
+      return launch_nt_occ<AMUL, 16, true, 1, 2>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, c_vec, am, s);
     }
     return fast ? RECMV_NT(2, true) : RECMV_NT(2, false);
   }
@@ -1314,7 +1607,11 @@ extern "C" int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_
   int64_t kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
   const bool a_vec = aligned16(A) && lda % 4 == 0, b_vec = aligned16(B) && ldb % 4 == 0;
   ScopedLaunchTimer timer(8, 2.0 * M * N * K, s);
-  if (g_gemm_mode == 1)
+  if (g_gemm_mode == 0 && tn_occ() && a_vec && b_vec && (M & 3) == 0 && (N & 3) == 0 && M >= 4 && N >= 4) {
+    kchunk = ceil_div(ceil_div(K, splits), 16) * 16;
+    hipLaunchKernelGGL(gemm_tn_occ_kernel<16>, dim3((unsigned)(nbm * nbn * splits)), dim3(kBlk), 2 * 16 * LDM * 4, s, A, lda,
+                       B, ldb, (float*)workspace, (int)M, (int)N, K, nbm, nbn, kchunk);
+  } else if (g_gemm_mode == 1)
     hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)(nbm * nbn * splits)), dim3(kBlk), kTnLds, s, A, lda, B,
                        ldb, (float*)workspace, (int)M, (int)N, K, nbm, nbn, kchunk, a_vec, b_vec);
   else
@@ -1346,7 +1643,7 @@ extern "C" int recmv_posenc_forward(const float* x, int64_t ldx, float* out, int
 // Per-launch HIP-event timing of the MFMA kernels.  recmv_profile_begin() starts recording (events on the launch
 // stream around every gemm_nt / gemm_tn launch); recmv_profile_end() waits for the recorded events and returns, per
 // kernel variant v (0..7: gemm_nt_kernel<T, FAST, AMUL> with v = (T-1) + 2*FAST + 4*AMUL; 8: gemm_tn_kernel +
-// its split-K reduction), out[5v] = timed launches, out[5v+1] = their summed duration in seconds, out[5v+2] = their
+// its split-K reduction; 9 / 10: gemm_nt_occ_kernel<false, ...> with 128x128 / 64x128 tiles, 11: gemm_nt_occ_kernel<true, ...>), out[5v] = timed launches, out[5v+1] = their summed duration in seconds, out[5v+2] = their
 // summed algorithmic FLOP (2 M N K), out[5v+3] / out[5v+4] = launches / FLOP of the launches below `min_flops`, which
 // are only counted (bracketing tens of thousands of ~20 us launches with events would perturb the run being timed).
 extern "C" int recmv_profile_begin(double min_flops) {
@@ -1361,17 +1658,19 @@ extern "C" int recmv_profile_end(double* out, int n_variants) {
   g_prof.on = false;
   RECMV_REQUIRE(out && n_variants >= 9, "profile_end: need room for 9 variants");
   for (int i = 0; i < 5 * n_variants; ++i) out[i] = 0.0;
-  for (int v = 0; v < 9; ++v) {
-    out[5 * v + 3] = g_prof.untimed[v][0];
-    out[5 * v + 4] = g_prof.untimed[v][1];
+  // slots 9..11 (the high-occupancy NT kernels) fold into the slots of the kernels they replace for a caller with 9 slots
+  auto slot = [&](int v) { return v < n_variants ? v : (v == 11 ? 7 : 3); };
+  for (int v = 0; v < 12; ++v) {
+    out[5 * slot(v) + 3] += g_prof.untimed[v][0];
+    out[5 * slot(v) + 4] += g_prof.untimed[v][1];
   }
   for (auto& r : g_prof.recs) {
     RECMV_HIP_TRY(hipEventSynchronize(r.b));
     float ms = 0.f;
     RECMV_HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
-    out[5 * r.variant + 0] += 1.0;
-    out[5 * r.variant + 1] += (double)ms * 1e-3;
-    out[5 * r.variant + 2] += r.flops;
+    out[5 * slot(r.variant) + 0] += 1.0;
+    out[5 * slot(r.variant) + 1] += (double)ms * 1e-3;
+    out[5 * slot(r.variant) + 2] += r.flops;
     g_prof.pool.push_back(r.a);
     g_prof.pool.push_back(r.b);
   }

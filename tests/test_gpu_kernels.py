@@ -4,6 +4,9 @@ Bars: bit-exact for indices/masks and for every kernel whose arithmetic is a fix
 with the oracle (inv3x3, sampler forward/backward, interp2x, MC vertices+faces); stated f32 tolerances
 for the MFMA contractions (different summation order than a sequential reference).
 """
+import os
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -11,6 +14,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+REPO = Path(__file__).resolve().parent.parent
 
 
 def gpu(t):
@@ -359,7 +363,7 @@ def test_mc_full_size_257_properties():
 # ------------------------------------------------------------------------------------------ GEMM / PE
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 3, 39), (257, 512, 39), (300, 473, 512), (1000, 257, 512),
                                    (129, 130, 167), (4096, 512, 512), (77, 3, 512), (640, 512, 289), (6144, 512, 512),
-                                   (3072, 512, 473), (20000, 512, 512)])
+                                   (3072, 512, 473), (20000, 512, 512), (116000, 512, 64)])   # the last two: 64x128 / 128x128 occupancy tiles
 def test_gemm_nt_vs_fp64(M, N, K):
     from recmv import ops
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -425,6 +429,47 @@ def test_gemm_nt_seg_equals_two_plain_products(M0, M1, N, K):
         same(out[rows], ref, A[rows], W, part)
     # a split that is not a multiple of the tile height is refused
     assert lib.recmv_gemm_nt_seg(L.ptr(A), K, L.ptr(B), K, None, L.ptr(B2), None, 100, L.ptr(out), N, M0 + M1, N, K, 0, 0.0, 1.0, st) != 0
+
+
+_OCC_CHILD = """
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from recmv import _lib as L, ops
+out = {}
+for (M, N, K) in ((20000, 512, 512), (116000, 512, 64), (115300, 473, 100)):
+    g = torch.Generator().manual_seed(M + K)
+    A, B, b = torch.randn(M, K, generator=g).cuda(), (torch.randn(N, K, generator=g) / K ** 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    Y = torch.rand(M, N, generator=g).cuda() * 0.05
+    out[f"softplus{M}"] = ops.gemm_nt(A, B, b, ops.ACT_SOFTPLUS, 100.0, 0.5).cpu()
+    o = torch.empty(M, N, device="cuda")
+    L.check(L.lib().recmv_gemm_nt_mulgrad(L.ptr(A), K, L.ptr(B), K, L.ptr(o), N, M, N, K, L.ptr(Y), N, ops.ACT_SOFTPLUS, 100.0, 1.0,
+                                          1.0, L.stream_ptr(A.device)), "mulgrad")
+    out[f"mulgrad{M}"] = o.cpu()
+    if K % 4 == 0 and N == 512:
+        Yk = torch.rand(M, K, generator=g).cuda() * 0.05
+        L.check(L.lib().recmv_gemm_nt_actgrad(L.ptr(A), K, L.ptr(Yk), K, L.ptr(B), K, L.ptr(o), N, M, N, K, ops.ACT_SOFTPLUS, 100.0,
+                                              1.0, 1.0, L.stream_ptr(A.device)), "actgrad")
+        out[f"actgrad{M}"] = o.cpu()
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_gemm_nt_occupancy_kernels_bit_equal_to_the_kernel_they_replace(tmp_path):
+    """The large f32 products run gemm_nt_occ_kernel (one 16-column K-tile in LDS, four / five workgroups per CU, 128x128 or 64x128
+    tiles by launch size); RECMV_GEMM_OCC=0 keeps gemm_nt_kernel<2, ...> (two per CU).  Same products, same order along k: the
+    outputs are equal bit for bit — forward epilogue, activation-gradient epilogue and operand transform, aligned and ragged
+    shapes (the switch is read once per process, hence two children)."""
+    import subprocess
+    import sys
+    res = {}
+    for occ in ("1", "0"):
+        f = tmp_path / f"occ{occ}.pt"
+        env = dict(os.environ, RECMV_GEMM_OCC=occ)
+        subprocess.run([sys.executable, "-c", _OCC_CHILD, str(REPO / "rec-mv_amd"), str(f)], env=env, check=True, timeout=600)
+        res[occ] = torch.load(f)
+    assert set(res["1"]) == set(res["0"]) and len(res["1"]) >= 8
+    for k in res["1"]:
+        assert torch.equal(res["1"][k], res["0"][k]), (k, float((res["1"][k] - res["0"][k]).abs().max()))
 
 
 def test_gemm_nt_strided_views():

@@ -1184,8 +1184,11 @@ __global__ __launch_bounds__(kBlk, 4) void gemm_tn_occ_kernel(const float* __res
       } else {
         const bool kin = k < kend, ain = kin && cm < M, bin = kin && cn < N;
         const int64_t kc = kin ? k : kend - 1;
-        float4 a = *reinterpret_cast<const float4*>(A + kc * lda + (cm < M ? cm : M - 4));
-        float4 b = *reinterpret_cast<const float4*>(B + kc * ldb + (cn < N ? cn : N - 4));
+        // widths that are no multiple of 4 (the skip layer's 473 columns inside a 512-wide buffer): the launcher has checked that
+        // the row strides cover the rounded-up widths, so the last float4 of a row reads up to 3 elements of padding — they only
+        // reach output rows / columns >= M / N, which are never stored
+        float4 a = *reinterpret_cast<const float4*>(A + kc * lda + (cm < M ? cm : (M - 1) & ~3));
+        float4 b = *reinterpret_cast<const float4*>(B + kc * ldb + (cn < N ? cn : (N - 1) & ~3));
         ra[r] = make_float4(ain ? a.x : 0.f, ain ? a.y : 0.f, ain ? a.z : 0.f, ain ? a.w : 0.f);
         rb[r] = make_float4(bin ? b.x : 0.f, bin ? b.y : 0.f, bin ? b.z : 0.f, bin ? b.w : 0.f);
       }
@@ -1606,8 +1609,10 @@ extern "C" int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_
   const int nbm = (int)ceil_div(M, BM), nbn = (int)ceil_div(N, BN);
   int64_t kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
   const bool a_vec = aligned16(A) && lda % 4 == 0, b_vec = aligned16(B) && ldb % 4 == 0;
+  int rc;
+  {                          // the events bracket the product kernel alone (slot 8 = one kernel symbol); its reduction pass follows
   ScopedLaunchTimer timer(8, 2.0 * M * N * K, s);
-  if (g_gemm_mode == 0 && tn_occ() && a_vec && b_vec && (M & 3) == 0 && (N & 3) == 0 && M >= 4 && N >= 4) {
+  if (g_gemm_mode == 0 && tn_occ() && a_vec && b_vec && lda >= ((M + 3) & ~3ll) && ldb >= ((N + 3) & ~3ll) && M >= 4 && N >= 4) {
     kchunk = ceil_div(ceil_div(K, splits), 16) * 16;
     hipLaunchKernelGGL(gemm_tn_occ_kernel<16>, dim3((unsigned)(nbm * nbn * splits)), dim3(kBlk), 2 * 16 * LDM * 4, s, A, lda,
                        B, ldb, (float*)workspace, (int)M, (int)N, K, nbm, nbn, kchunk);
@@ -1617,7 +1622,8 @@ extern "C" int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_
   else
     hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3((unsigned)(nbm * nbn * splits)), dim3(kBlk), kTnLds, s, A, lda, B,
                        ldb, (float*)workspace, (int)M, (int)N, K, nbm, nbn, kchunk, a_vec, b_vec);
-  int rc = check_launch("gemm_tn");
+  rc = check_launch("gemm_tn");
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stream_grid(M * N, kBlk)), dim3(kBlk), 0, s,
                      (const float*)workspace, C, ldc, (int)M, (int)N, splits);
@@ -1642,8 +1648,8 @@ extern "C" int recmv_posenc_forward(const float* x, int64_t ldx, float* out, int
 
 // Per-launch HIP-event timing of the MFMA kernels.  recmv_profile_begin() starts recording (events on the launch
 // stream around every gemm_nt / gemm_tn launch); recmv_profile_end() waits for the recorded events and returns, per
-// kernel variant v (0..7: gemm_nt_kernel<T, FAST, AMUL> with v = (T-1) + 2*FAST + 4*AMUL; 8: gemm_tn_kernel +
-// its split-K reduction; 9 / 10: gemm_nt_occ_kernel<false, ...> with 128x128 / 64x128 tiles, 11: gemm_nt_occ_kernel<true, ...>), out[5v] = timed launches, out[5v+1] = their summed duration in seconds, out[5v+2] = their
+// kernel variant v (0..7: gemm_nt_kernel<T, FAST, AMUL> with v = (T-1) + 2*FAST + 4*AMUL; 8: gemm_tn_occ_kernel / gemm_tn_kernel
+// (the product alone, its split-K reduction pass is not bracketed); 9 / 10: gemm_nt_occ_kernel<false, ...> with 128x128 / 64x128 tiles, 11: gemm_nt_occ_kernel<true, ...>), out[5v] = timed launches, out[5v+1] = their summed duration in seconds, out[5v+2] = their
 // summed algorithmic FLOP (2 M N K), out[5v+3] / out[5v+4] = launches / FLOP of the launches below `min_flops`, which
 // are only counted (bracketing tens of thousands of ~20 us launches with events would perturb the run being timed).
 extern "C" int recmv_profile_begin(double min_flops) {

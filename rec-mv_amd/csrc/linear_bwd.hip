@@ -170,7 +170,7 @@ extern "C" int recmv_colsum(const float* g, int64_t ld, int64_t rows, int64_t co
 
 extern "C" int64_t recmv_linear_backward_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0) return 256;
-  return align256(M * N * 4) + align256(recmv_gemm_tn_workspace_bytes(N, K, M)) +
+  return align256(M * ((N + 3) & ~3ll) * 4) + align256(recmv_gemm_tn_workspace_bytes(N, K, M)) +
          align256(recmv_colsum_workspace_bytes(M, N)) + 256;
 }
 
@@ -189,7 +189,8 @@ extern "C" int recmv_linear_backward(const float* gy, int64_t ldgy, const float*
   }
   char* ws = (char*)workspace;
   float* gzbuf = (float*)ws;
-  char* tn_ws = ws + align256(M * N * 4);
+  const int64_t ldz = (N + 3) & ~3ll;     // dZ rows padded to whole float4s: the dW product then takes its aligned path for N = 473
+  char* tn_ws = ws + align256(M * ldz * 4);
   const int64_t tn_bytes = align256(recmv_gemm_tn_workspace_bytes(N, K, M));
   char* cs_ws = tn_ws + tn_bytes;
   const int64_t cs_bytes = align256(recmv_colsum_workspace_bytes(M, N));
@@ -206,11 +207,11 @@ extern "C" int recmv_linear_backward(const float* gy, int64_t ldgy, const float*
                        ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
       if (vec)
         hipLaunchKernelGGL(act_grad_colsum_kernel<4>, dim3((unsigned)ceil_div(N, kColTile), (unsigned)chunks), dim3(kBlk),
-                           0, (hipStream_t)stream, gy, ldgy, y, ldy, gzbuf, N, M, (int)N, rpc, act, act_param,
+                           0, (hipStream_t)stream, gy, ldgy, y, ldy, gzbuf, ldz, M, (int)N, rpc, act, act_param,
                            (float*)cs_ws);
       else
         hipLaunchKernelGGL(act_grad_colsum_kernel<1>, dim3((unsigned)ceil_div(N, kColTile), (unsigned)chunks), dim3(kBlk),
-                           0, (hipStream_t)stream, gy, ldgy, y, ldy, gzbuf, N, M, (int)N, rpc, act, act_param,
+                           0, (hipStream_t)stream, gy, ldgy, y, ldy, gzbuf, ldz, M, (int)N, rpc, act, act_param,
                            (float*)cs_ws);
       rc = check_launch("linear_backward/act_grad_colsum");
       if (rc) return rc;
@@ -220,11 +221,11 @@ extern "C" int recmv_linear_backward(const float* gy, int64_t ldgy, const float*
       if (rc) return rc;
       gb_done = true;
     } else {
-      rc = recmv_act_grad_2d(gy, ldgy, y, ldy, gzbuf, N, M, N, act, act_param, 1.f, 1.f, stream);
+      rc = recmv_act_grad_2d(gy, ldgy, y, ldy, gzbuf, ldz, M, N, act, act_param, 1.f, 1.f, stream);
       if (rc) return rc;
     }
     gz = gzbuf;
-    ldgz = N;
+    ldgz = ldz;
   }
   if (gb && !gb_done) {
     rc = recmv_colsum(gz, ldgz, M, N, gb, cs_ws, cs_bytes, stream);

@@ -500,6 +500,29 @@ def test_gemm_tn_vs_fp64(K, M, N):
     assert torch.equal(out, ops.gemm_tn(gpu(A), gpu(B))), "split-K reduction order is fixed: deterministic"
 
 
+def test_gemm_tn_widths_inside_wider_buffers():
+    """dW of the skip layer: 473 of 512 columns on either side (row stride 512 covers the width rounded up to 4, so the
+    four-workgroups-per-CU kernel runs with whole-float4 loads; what lies in the padding columns — NaN here — must not reach
+    the result)."""
+    from recmv import ops
+    g = torch.Generator().manual_seed(5)
+    K = 9000
+    bufA, bufB = torch.randn(K, 512, generator=g), torch.randn(K, 512, generator=g)
+    bufA[:, 473:] = float("nan")
+    bufB[:, 473:] = float("nan")
+    for (M, N) in ((473, 473), (473, 512), (512, 473), (6, 473)):
+        A, B = gpu(bufA)[:, :M], gpu(bufB)[:, :N]
+        if N == 512:
+            B = gpu(torch.nan_to_num(bufB, nan=0.5))
+        if M == 512:
+            A = gpu(torch.nan_to_num(bufA, nan=0.25))
+        ref = A.cpu().double().t() @ B.cpu().double()
+        out = ops.gemm_tn(A, B)
+        bound = 4e-7 * (A.cpu().abs().double().t() @ B.cpu().abs().double()) + 1e-6
+        assert torch.isfinite(out).all()
+        assert ((out.cpu().double() - ref).abs() <= bound).all(), (M, N)
+
+
 def test_matmul_functions_gradcheck_structure():
     """First and second derivatives of the product Functions stay on the kernels and match autograd of @."""
     from recmv import ops

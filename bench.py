@@ -64,7 +64,8 @@ HBM_PEAK = 8.0e12             # B/s
 
 NT_VARIANTS = ["gemm_nt_kernel<%d, %s, %s>" % (1 + (v & 1), "true" if v & 2 else "false", "true" if v & 4 else "false")
                for v in range(8)] + ["gemm_tn_occ_kernel<16>", "gemm_nt_occ_kernel<false, 16, true, 2, 2>",
-                                      "gemm_nt_occ_kernel<false, 16, true, 1, 2>", "gemm_nt_occ_kernel<true, 16, true, *, 2>"]
+                                      "gemm_nt_occ_kernel<false, 16, true, 1, 2>", "gemm_nt_occ_kernel<true, 16, true, *, 2>",
+                                      "gemm_nt_narrow_kernel<true, false, false>", "gemm_nt_narrow_kernel<other instantiations>"]
 
 
 class KernelEvents:

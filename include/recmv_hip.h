@@ -467,8 +467,10 @@ int recmv_gather_rows(const float* table, int64_t ldt, const int64_t* index, flo
  * recmv_profile_begin() and recmv_profile_end() every gemm_nt / gemm_tn launch (from Python or from inside the
  * launch chains) is bracketed by events recorded on its launch stream.  recmv_profile_end fills, per kernel variant
  * v (0..7: gemm_nt_kernel<T, FAST, AMUL>, v = (T-1) + 2*FAST + 4*AMUL; 8: gemm_tn_occ_kernel / gemm_tn_kernel, the product
- * alone without its split-K reduction pass; 9 / 10: gemm_nt_occ_kernel<false, ...> with 128x128 / 64x128 tiles; 11: gemm_nt_occ_kernel<true, ...> — a caller
- * that passes fewer than 12 slots gets 9..11 folded into 3 / 3 / 7, the kernels they replace):
+ * alone without its split-K reduction pass; 9 / 10: gemm_nt_occ_kernel<false, ...> with 128x128 / 64x128 tiles; 11:
+ * gemm_nt_occ_kernel<true, ...>;
+ * 12 / 13: gemm_nt_narrow_kernel<true, false, .> / its other instantiations — a caller that passes fewer than 14 slots gets
+ * 9..13 folded into 3 / 3 / 7 / 2 / 6, the slots that carried those launches before):
  * out[5v] = timed launches, out[5v+1] = their summed duration [s], out[5v+2] = their summed algorithmic FLOP
  * (2 M N K), out[5v+3] / out[5v+4] = launches / FLOP of the launches smaller than `min_flops`, which are counted
  * but not bracketed (out must hold 5 * n_variants doubles, n_variants >= 9).

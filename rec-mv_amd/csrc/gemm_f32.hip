@@ -1302,7 +1302,7 @@ struct LaunchRec {
 struct Profiler {
   bool on = false;
   double min_flops = 0.0;          // launches below this are counted but not bracketed by events
-  double untimed[12][2] = {};      // [variant][launches, flops]
+  double untimed[14][2] = {};      // [variant][launches, flops]
   std::vector<LaunchRec> recs;
   std::vector<hipEvent_t> pool;
   std::mutex mu;        // autograd's backward thread launches too
@@ -1437,7 +1437,7 @@ static int launch_nt_narrow(const float* A, int64_t lda, const float* B, int64_t
                             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
                             bool a_vec, bool b_vec, bool c_vec, const AMul& am, hipStream_t stream) {
   const int nbm = (int)ceil_div(M, 64), nbn = (int)ceil_div(N, 32);
-  ScopedLaunchTimer timer(2 * (FAST ? 1 : 0) + 4 * (AMUL ? 1 : 0), 2.0 * M * N * K, stream);
+  ScopedLaunchTimer timer(FAST && !AMUL ? 12 : 13, 2.0 * M * N * K, stream);
   hipLaunchKernelGGL((gemm_nt_narrow_kernel<FAST, AMUL, BF3>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk),
                      kNarrowLds, stream, A, lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale,
                      nbm, nbn, a_vec, b_vec, c_vec, am);
@@ -1649,7 +1649,7 @@ extern "C" int recmv_posenc_forward(const float* x, int64_t ldx, float* out, int
 // Per-launch HIP-event timing of the MFMA kernels.  recmv_profile_begin() starts recording (events on the launch
 // stream around every gemm_nt / gemm_tn launch); recmv_profile_end() waits for the recorded events and returns, per
 // kernel variant v (0..7: gemm_nt_kernel<T, FAST, AMUL> with v = (T-1) + 2*FAST + 4*AMUL; 8: gemm_tn_occ_kernel / gemm_tn_kernel
-// (the product alone, its split-K reduction pass is not bracketed); 9 / 10: gemm_nt_occ_kernel<false, ...> with 128x128 / 64x128 tiles, 11: gemm_nt_occ_kernel<true, ...>), out[5v] = timed launches, out[5v+1] = their summed duration in seconds, out[5v+2] = their
+// (the product alone, its split-K reduction pass is not bracketed); 9 / 10: gemm_nt_occ_kernel<false, ...> with 128x128 / 64x128 tiles, 11: gemm_nt_occ_kernel<true, ...>; 12 / 13: gemm_nt_narrow_kernel<true, false, .> / its other instantiations), out[5v] = timed launches, out[5v+1] = their summed duration in seconds, out[5v+2] = their
 // summed algorithmic FLOP (2 M N K), out[5v+3] / out[5v+4] = launches / FLOP of the launches below `min_flops`, which
 // are only counted (bracketing tens of thousands of ~20 us launches with events would perturb the run being timed).
 extern "C" int recmv_profile_begin(double min_flops) {
@@ -1665,8 +1665,8 @@ extern "C" int recmv_profile_end(double* out, int n_variants) {
   RECMV_REQUIRE(out && n_variants >= 9, "profile_end: need room for 9 variants");
   for (int i = 0; i < 5 * n_variants; ++i) out[i] = 0.0;
   // slots 9..11 (the high-occupancy NT kernels) fold into the slots of the kernels they replace for a caller with 9 slots
-  auto slot = [&](int v) { return v < n_variants ? v : (v == 11 ? 7 : 3); };
-  for (int v = 0; v < 12; ++v) {
+  auto slot = [&](int v) { return v < n_variants ? v : (v == 11 ? 7 : (v == 12 ? 2 : (v == 13 ? 6 : 3))); };
+  for (int v = 0; v < 14; ++v) {
     out[5 * slot(v) + 3] += g_prof.untimed[v][0];
     out[5 * slot(v) + 4] += g_prof.untimed[v][1];
   }

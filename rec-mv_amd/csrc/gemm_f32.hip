@@ -1153,7 +1153,15 @@ __global__ __launch_bounds__(kBlk, 4) void gemm_tn_occ_kernel(const float* __res
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles = nbm * nbn;
-  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  // consecutive workgroup ids go round the 8 XCDs: keep ALL output tiles of a split (they read the same operand rows) on one XCD,
+  // so that its L2 fetches those rows once — XCD x takes the splits x, x + 8, ...
+  int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int splits = gridDim.x / tiles;
+  if (splits % kNumXCD == 0) {
+    const int x = blockIdx.x % kNumXCD, j = blockIdx.x / kNumXCD;
+    split = x + kNumXCD * (j / tiles);
+    tile = j % tiles;
+  }
   const int tile_m = tile / nbn, tile_n = tile % nbn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int64_t kbeg = (int64_t)split * kchunk;

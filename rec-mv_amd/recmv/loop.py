@@ -44,8 +44,7 @@ from . import raster
 from . import utils
 from .FastMinv import Fast3x3Minv
 from .MCAcc import Seg3dLossless
-from .model import (CompositeDeformer, LBSkinner, MLPTranslator, RectifiedPerspectiveCameras, getRenderNet, getTmpSdf,
-                    getTranslatorNet)
+from .model import CompositeDeformer, LBSkinner, RectifiedPerspectiveCameras, getRenderNet, getTmpSdf, getTranslatorNet
 from .utils.constant import CURVE_AWARE, FL_INFOS, MASK_KEYS, TEMPLATE_GARMENT
 
 SMPL_PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21],

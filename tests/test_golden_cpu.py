@@ -5,7 +5,6 @@ import sys
 from pathlib import Path
 
 import numpy as np
-import pytest
 import torch
 
 GOLD = Path(__file__).resolve().parent / "golden"

@@ -3,7 +3,6 @@ points found through the rasteriser are consistent with the rays they seed, and 
 import sys
 from pathlib import Path
 
-import numpy as np
 import pytest
 import torch
 

@@ -70,8 +70,6 @@ __global__ __launch_bounds__(kBlk) void act_grad_colsum_kernel(const float* __re
 #pragma unroll
   for (int v = 0; v < VEC; ++v) s[v] = 0.f;
   if (c < cols) {
-    // (four rows per trip: eight 16-byte loads in flight per lane instead of two; the sums keep their row order)
-#pragma unroll 4
     for (int64_t r = r0 + rgrp; r < r1; r += RG) {
       if (VEC == 4) {
         const float4 g4 = *reinterpret_cast<const float4*>(gy + r * ldg + c);

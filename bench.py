@@ -414,7 +414,58 @@ def whole_step_matrix_rate(roofline, steps, ms_per_step):
             "note": "all MFMA launches of the timed region on rank 0 (every variant, both GEMM kernels) over the whole step time"}
 
 
-def main():
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv, device_type="cuda"):
+    """`python bench.py --gpus N` outside a torchrun environment: start the N ranks HERE — one process per GPU under
+    torch.distributed.run on 127.0.0.1 and a free port — hand the children's exit code back, never measure fewer ranks than were
+    asked for.  Fewer than N visible devices is an error (exit 2), except in the two functional modes that say so themselves:
+    RECMV_SHARE_GPU0=1 (all ranks on device 0, gloo collectives: the N > 1 code path on a 1-GPU box) and the CPU port of the tests."""
+    import subprocess
+    env = dict(os.environ)
+    if device_type == "cuda":
+        have = torch.cuda.device_count()
+        if env.get("RECMV_SHARE_GPU0") == "1":
+            if have < 1:
+                raise SystemExit("bench.py --gpus %d: RECMV_SHARE_GPU0=1 needs one GPU, found none" % n)
+            env.setdefault("RECMV_DIST_BACKEND", "gloo")
+        elif have < n:
+            print("bench.py --gpus %d: %d GPU(s) visible — refusing to measure fewer ranks than asked for" % (n, have),
+                  file=sys.stderr, flush=True)
+            raise SystemExit(2)
+    else:
+        env.setdefault("RECMV_DIST_BACKEND", "gloo")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or n) // n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(Path(sys.argv[0]).resolve())] + list(argv)
+    log("starting %d ranks: %s" % (n, " ".join(cmd[1:])))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def replica_digest(tensors):
+    """Two 64-bit sums over the bit patterns of `tensors` (plain and position-weighted): equal on two ranks <=> the replicas hold
+    the same bits (up to a collision nobody will meet).  On the device, one read-back."""
+    acc = torch.zeros(2, dtype=torch.int64, device=tensors[0].device)
+    for i, t in enumerate(tensors):
+        bits = t.detach().reshape(-1).contiguous().view(torch.int32).to(torch.int64)
+        w = (torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 65521) + 1 + i
+        acc[0] += bits.sum()
+        acc[1] += (bits * w).sum()
+    return acc
+
+
+def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
+    """`device_type`, `hotloop_kw` and `conf_overrides` exist for tests/bench_cpu_entry.py, which runs this same entry — launcher,
+    rank set-up, timed region, JSON line — on the CPU port of the kernels with a scene cut down for host cores."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    hotloop_kw = HOTLOOP_KW if hotloop_kw is None else hotloop_kw
+    on_gpu = device_type == "cuda"
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -445,10 +496,17 @@ def main():
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--state", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--conf", default=str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.cpu_baseline_child:
         _cpu_baseline_child(args.conf, args.state)
         return
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            launch_ranks(args.gpus, argv, device_type)          # does not return
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the line would not describe the job")
 
     from recmv import dist as rdist
     from recmv.hocon import ConfigFactory
@@ -457,15 +515,21 @@ def main():
 
     # the loop's host side only launches kernels; torch's intra-op pool (one thread per core: 256 here) makes every
     # small CPU op (index bookkeeping, the ray sampler's host RNG) pay a fork/join of the whole pool
-    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    torch.set_num_threads(min(8, os.cpu_count() or 1) if on_gpu else int(os.environ.get("OMP_NUM_THREADS", "2")))
     rank, local_rank, world = rdist.init_distributed()
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+        if os.environ.get("RECMV_SHARE_GPU0") != "1" and torch.cuda.device_count() < world:
+            raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPU(s) visible")
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
+    else:
+        device = torch.device(device_type)
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     conf = ConfigFactory.parse_file(args.conf)
-    loop = HotLoop(conf, device, stage=args.stage, world_size=world, rank=rank, curves=args.curves, **HOTLOOP_KW)
+    for k, v in (conf_overrides or {}).items():
+        conf.put(k, v)
+    loop = HotLoop(conf, device, stage=args.stage, world_size=world, rank=rank, curves=args.curves, **hotloop_kw)
     rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters())
                           + (list(loop.inter_free_curve.parameters()) if loop.curves else []))
     allreduce = rdist.GradAllReduce(world) if world > 1 else None
@@ -479,18 +543,18 @@ def main():
         loop.step(it, allreduce)
         it += 1
         if it % 60 == 0:
-            torch.cuda.synchronize()
+            sync()
             log("settling: iteration %d, rays converged %s" % (it, loop.info.get('rays_converged')))
     for _ in range(args.warmup):
         loop.step(it, allreduce)
         it += 1
-        torch.cuda.synchronize()
+        sync()
         log("warm-up step %d done" % it)
     # one re-mesh inside the timed region whatever K is (see the module docstring)
     period = loop.remesh_intersect
     if args.steps < period:
         loop.forward_time = period - args.steps // 2
-    prof = KernelEvents() if not args.no_kernel_events else None
+    prof = KernelEvents() if (on_gpu and not args.no_kernel_events) else None
     if prof:
         prof.begin()
     if getattr(loop, "phase_ms", None):
@@ -498,24 +562,26 @@ def main():
     rays = 0
     rays_local = 0
     converged = 0
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if on_gpu else None
     remesh_steps = []
     rdist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
-    marks[0].record()
+    if marks:
+        marks[0].record()
     for k in range(args.steps):
         if loop.forward_time % loop.remesh_intersect == 0:
             remesh_steps.append(k)
         _, r = loop.step(it, allreduce)
-        marks[k + 1].record()
+        if marks:
+            marks[k + 1].record()
         rays += int(r)
         rays_local += int(r)
         converged += sum(loop.info.get('rays_converged', []))     # host ints the loop's own gate read back
         it += 1
         if it % 5 == 0:
             log("step %d" % it)
-    torch.cuda.synchronize()
+    sync()
     rdist.barrier()
     elapsed = time.perf_counter() - t0
     gs = prof.end() if prof else {}
@@ -530,12 +596,12 @@ def main():
             loop.step(it, allreduce)
             it += 1
         rdist.barrier()
-        torch.cuda.synchronize()
+        sync()
         ta = time.perf_counter()
         for _ in range(n_alt):
             loop.step(it, allreduce)
             it += 1
-        torch.cuda.synchronize()
+        sync()
         rdist.barrier()
         alt_elapsed = time.perf_counter() - ta
         L.lib().recmv_set_gemm_mode(mode_id[args.gemm_mode])
@@ -554,16 +620,16 @@ def main():
         try:
             loop.step(it, allreduce)
             it += 1
-            torch.cuda.synchronize()
+            sync()
             prof.begin()
             for _ in range(max(2, min(5, args.steps))):
                 loop.step(it, allreduce)
                 it += 1
-            torch.cuda.synchronize()
+            sync()
             gs_serial = prof.end()
         finally:
             del os.environ["RECMV_SERIAL"]
-    per_rank_ms, allreduce_us = None, None
+    per_rank_ms, allreduce_us, replicas_identical = None, None, None
     if world > 1:
         mine = elapsed
         t = torch.tensor([elapsed, float(rays)], device=device, dtype=torch.float64)
@@ -577,20 +643,32 @@ def main():
         tdist.all_reduce(slots, op=tdist.ReduceOp.SUM)
         per_rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in slots]
         # the step's collective alone: the flattened all-reduce of the shared gradients (~25 MB), 10 repetitions
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         allreduce(loop.shared_parameters())
-        torch.cuda.synchronize()
-        e0.record()
+        sync()
+        if on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        tw = time.perf_counter()
         for _ in range(10):
             allreduce(loop.shared_parameters())
-        e1.record()
-        torch.cuda.synchronize()
-        allreduce_us = round(e0.elapsed_time(e1) * 1e2, 1)
+        if on_gpu:
+            e1.record()
+        sync()
+        allreduce_us = round(e0.elapsed_time(e1) * 1e2, 1) if on_gpu else round((time.perf_counter() - tw) * 1e5, 1)
+        # every rank must hold the same replica after the same steps: shared parameters, per-frame tables, the body net, the
+        # explicit meshes and the curve parameters — bit for bit (the exchanges are sums in one order, MC is deterministic)
+        with torch.no_grad():
+            mine_d = replica_digest([p for p in loop.shared_parameters()] + list(loop.sdf.parameters()) + list(loop.garment_vs)
+                                    + (list(loop.inter_free_curve.parameters()) if loop.curves else []))
+        digests = torch.zeros(world, 2, dtype=torch.int64, device=device)
+        digests[rank] = mine_d
+        tdist.all_reduce(digests, op=tdist.ReduceOp.SUM)
+        replicas_identical = bool((digests == digests[0:1]).all().item())
 
     if rank == 0:
         iters = args.steps * world
         line = {
-            "metric": "optimiser iters/sec, female-3-casual-like 512x512 (synthetic frames)",
+            "metric": "optimiser iters/sec, female-3-casual-like %dx%d (synthetic frames)" % (loop.dataset.H, loop.dataset.W),
             "value": round(iters / elapsed, 4),
             "unit": "iters/s",
             "n_gpus": world,
@@ -608,17 +686,18 @@ def main():
             "rays_per_sec": round(rays / elapsed, 1),
             "rays_converged_fraction": round(converged / max(rays_local, 1), 4),
             "config": {
-                "workload": "configs[1]: PeopleSnapshot female-3-casual-like, 512x512, frames_per_step=%d per GPU, "
+                "workload": "configs[1]: PeopleSnapshot female-3-casual-like, %dx%d, frames_per_step=%d per GPU, "
                             "2 garments, sample_pix_num=%d, stage=%s pyramid %s, remesh every %d iters (at least one "
                             "inside the timed region: period %d); surface points from the HIP first-hit mesh rasteriser + "
                             "FindSurfacePs, mask loss on the HIP point-splat silhouettes; feature-curve branch %s "
-                            "(recmv/loop.py docstring)" % (loop.batch_size, loop.sample_pix, args.stage,
+                            "(recmv/loop.py docstring)" % (loop.dataset.H, loop.dataset.W, loop.batch_size, loop.sample_pix, args.stage,
                                                           tuple(int(v) for v in loop.engine.resolutions[-1]),
                                                           loop.remesh_intersect, loop.remesh_intersect,
                                                           "ON (project_2d_loss + curve_aware_loss)" if args.curves else "OFF (--no-curves)"),
                 "parallelism": "frame-sharded dp%d, three-stream order on every rank; per step: all-reduce of the explicit-vertex gradients, of the curve gradients, and of the shared gradients in two asynchronous buckets" % world,
                 "per_rank_ms_per_step": per_rank_ms,
                 "shared_grad_allreduce_us": allreduce_us,
+                "replicas_bit_identical": replicas_identical,
                 "shared_grad_bytes": int(sum(p.numel() for p in loop.shared_parameters()) * 4),
                 "mc_vertices": [int(v.shape[0]) for v in loop.garment_vs],
                 "rays_per_iter": int(loop.info.get('rays_total', 0)),
@@ -658,9 +737,9 @@ def main():
                     "note": "the same kernel in a short pass with the iteration in the reference's serial order on one "
                             "stream (RECMV_SERIAL=1), i.e. alone on the device; in the timed region the ray pipeline and "
                             "the curve branch run beside it on other streams and share the CUs with it"}
-        step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
+        step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)] if marks else []
         plain = [m for k, m in enumerate(step_ms) if k not in remesh_steps]
-        with_r = [step_ms[k] for k in remesh_steps]
+        with_r = [step_ms[k] for k in remesh_steps if k < len(step_ms)]
         if plain:
             plain_ms = sum(plain) / len(plain)
             extra = (sum(with_r) / len(with_r) - plain_ms) if with_r else None

@@ -11,6 +11,8 @@ launches) — SURVEY.md §5, §8e.
 """
 from __future__ import annotations
 
+import contextlib
+import datetime
 import os
 
 import torch
@@ -35,8 +37,26 @@ def init_distributed(backend: str | None = None):
             local_rank = 0
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # The default collective timeout (10 min for RCCL) is shorter than a first run's start-up stage, during which the other
+        # ranks wait for rank 0 (train.py: skinner bake, SDF pre-fit, feature-line registration): two hours unless told otherwise.
+        timeout = datetime.timedelta(seconds=float(os.environ.get("RECMV_DIST_TIMEOUT_S", "7200")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local_rank, world
+
+
+def startup_gate(ok: bool = True, what: str = "start-up stage"):
+    """Rendezvous behind a stage that only rank 0 ran: every rank learns whether it succeeded.  A plain barrier leaves the waiting
+    ranks hanging until the collective timeout when rank 0 raised; here rank 0 reports its outcome (MIN over one flag per rank) and
+    every rank leaves with the same SystemExit when it failed."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if not ok:
+            raise SystemExit(f"{what} failed")
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        raise SystemExit(f"{what} failed on another rank" if ok else f"{what} failed")
 
 
 class GradAllReduce:
@@ -82,24 +102,37 @@ class GradAllReduce:
             else:
                 flat[off:off + k].copy_(t.grad.reshape(-1))
             off += k
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-        return (tensors, flat, work, buf)
+        try:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        except BaseException:
+            buf[1] = False
+            raise
+        dev = tensors[0].device
+        stream = torch.cuda.current_stream(dev) if dev.type == 'cuda' else None
+        return (tensors, flat, work, buf, stream)
 
     def finish(self, handle):
         if handle is None:
             return
-        tensors, flat, work, buf = handle
-        work.wait()                             # (device tensors: the current stream waits, the host does not)
-        flat.div_(self.world)
-        off = 0
-        for t in tensors:
-            k = t.numel()
-            if t.grad is None:
-                t.grad = flat[off:off + k].view_as(t).clone()
-            else:
-                t.grad.copy_(flat[off:off + k].view_as(t))
-            off += k
-        buf[1] = False
+        tensors, flat, work, buf, stream = handle
+        # the staging buffer belongs to the stream start() packed it on: wait, scale and unpack there whatever stream the caller
+        # is on now, and free the buffer also when something below raises
+        try:
+            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                work.wait()                     # (device tensors: the stream waits, the host does not)
+                flat.div_(self.world)
+                off = 0
+                for t in tensors:
+                    k = t.numel()
+                    if t.grad is None:
+                        t.grad = flat[off:off + k].view_as(t).clone()
+                    else:
+                        t.grad.copy_(flat[off:off + k].view_as(t))
+                    off += k
+            if stream is not None and torch.cuda.current_stream(stream.device) != stream:
+                torch.cuda.current_stream(stream.device).wait_stream(stream)      # the caller consumes the gradients where it is
+        finally:
+            buf[1] = False
 
     def __call__(self, tensors):
         self.finish(self.start(tensors))

@@ -238,6 +238,9 @@ def main(argv=None, large_pose=False):
         from recmv.utils.constant import TEMPLATE_GARMENT
         garment_type = args.garment_type or (config.get_string('train.garment_type') if 'train.garment_type' in config
                                              else osp.basename(osp.normpath(args.data)))
+        if garment_type not in TEMPLATE_GARMENT:
+            raise SystemExit("unknown capture %r: train.garment_type / --garment_type / the data folder's name must be one of %s "
+                             "(recmv/utils/constant.py TEMPLATE_GARMENT)" % (garment_type, sorted(TEMPLATE_GARMENT)))
         config.put('train.garment_type', garment_type)
         conds_lens = {'deformer': config.get_int('mlp_deformer.condlen') * (1 + len(TEMPLATE_GARMENT[garment_type])),
                       'renderer': config.get_int('render_net.condlen')}
@@ -252,21 +255,28 @@ def main(argv=None, large_pose=False):
     # stored files (initial_skinner_*.pth, initial_sdf_*.pth, fl_init/init_trans_matrix.pth) like any later run does.
     staged = world > 1 and capture is not None
     if staged and rank != 0:
-        rdist.barrier()
-    # train.py:170-171 (bmins / bmaxs None: the canonical box is sized from the initial surfaces)
-    optNet, sdf_initialized = getOptNet(capture, args.save_folder, batch_size, None, None, resolutions['coarse'], device,
-                                        config, opt_large=large_pose, n_frames=args.frames, H=512, W=512,
-                                        world_size=world, rank=rank, curves=not args.no_curves)
-    dataset = optNet.dataset
-    dataloader = FrameLoader(optNet) if capture is None else CaptureLoader(capture, optNet)
-    if sdf_initialized > 0:
-        prefit_sdf(optNet, sdf_initialized, config, args, save_root, rank)
-    if args.fl_templates is not None and capture is not None and not args.no_curves:
-        from recmv.utils.constant import FL_INFOS
-        register_feature_lines(optNet, dataloader, load_fl_templates(args.fl_templates, FL_INFOS[optNet.garment_type], device),
-                               save_root)
+        rdist.startup_gate(True)               # leaves with rank 0's outcome: SystemExit on every rank when its start-up raised
+    try:
+        # train.py:170-171 (bmins / bmaxs None: the canonical box is sized from the initial surfaces)
+        optNet, sdf_initialized = getOptNet(capture, args.save_folder, batch_size, None, None, resolutions['coarse'], device,
+                                            config, opt_large=large_pose, n_frames=args.frames, H=512, W=512,
+                                            world_size=world, rank=rank, curves=not args.no_curves)
+        dataset = optNet.dataset
+        dataloader = FrameLoader(optNet) if capture is None else CaptureLoader(capture, optNet)
+        if sdf_initialized > 0:
+            prefit_sdf(optNet, sdf_initialized, config, args, save_root, rank)
+        if args.fl_templates is not None and capture is not None and not args.no_curves:
+            from recmv.utils.constant import FL_INFOS
+            register_feature_lines(optNet, dataloader, load_fl_templates(args.fl_templates, FL_INFOS[optNet.garment_type], device),
+                                   save_root)
+    except BaseException:
+        if staged and rank == 0:
+            import traceback
+            traceback.print_exc()
+            rdist.startup_gate(False)          # releases the waiting ranks with the failure instead of the collective timeout
+        raise
     if staged and rank == 0:
-        rdist.barrier()
+        rdist.startup_gate(True)
     if rank == 0:                                 # train.py:86: wandb when it is there, a jsonl file under logs/ otherwise
         from recmv.engineer.visualizer import wandb_visualizer
         optNet.visualizer = wandb_visualizer(args.project_name, args.exp_name, resume=False, log_dir=osp.join(save_root, 'logs'))

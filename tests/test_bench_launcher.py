@@ -1,0 +1,59 @@
+"""`python bench.py --gpus N` must start N ranks itself and never measure fewer.
+
+The driver's SCALE step calls `bench.py --gpus N` (and, for N > 1, the same under torch.distributed.run).  Both forms are covered
+here without a GPU: the launcher's refusals on the real script, and the whole entry — launcher, two gloo ranks, timed region, JSON
+line — through tests/bench_cpu_entry.py on the CPU port with a scene cut down for host cores.
+"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+SMALL = ["--steps", "2", "--warmup", "1", "--settle-iters", "0", "--no-mc", "--no-hbm-kernels", "--no-cpu-baseline", "--no-config2",
+         "--no-alt-mode", "--no-kernel-events", "--no-curves"]
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="2", **kw)
+    return env
+
+
+def test_gpus_n_without_n_devices_exits_non_zero():
+    """No GPU in this container: `--gpus 2` must refuse (exit 2) instead of running one rank and printing n_gpus 1."""
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2"] + SMALL, env=_env(HIP_VISIBLE_DEVICES="",
+                       CUDA_VISIBLE_DEVICES=""), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "refusing to measure fewer ranks" in r.stderr and not r.stdout.strip()
+
+
+def test_world_size_that_contradicts_gpus_is_refused():
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "4"] + SMALL,
+                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+
+
+def _line(args, **env):
+    r = subprocess.run([sys.executable, str(REPO / "tests" / "bench_cpu_entry.py")] + args + SMALL, env=_env(**env),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line: %r" % r.stdout[-500:]
+    return json.loads(lines[0])
+
+
+def test_gpus_2_launches_two_ranks_with_identical_replicas():
+    """The entry with `--gpus 2` and no torchrun environment: two ranks over gloo, one line with n_gpus 2, a step time per rank,
+    the shared-gradient exchange timed, replicas bit-identical after the run; twice the frames of the one-rank job per step."""
+    two = _line(["--gpus", "2"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["steps"] == 2
+    cfg = two["config"]
+    assert len(cfg["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in cfg["per_rank_ms_per_step"])
+    assert cfg["shared_grad_allreduce_us"] > 0 and cfg["shared_grad_bytes"] > 1e6
+    assert cfg["replicas_bit_identical"] is True
+    assert "dp2" in cfg["parallelism"]
+    assert abs(two["value"] - 2 * 1e3 / two["ms_per_step"]) < 1e-2 * two["value"]       # whole-job rate: N iterations per step time
+    one = _line(["--gpus", "1"])
+    assert one["n_gpus"] == 1 and one["config"]["per_rank_ms_per_step"] is None and one["config"]["replicas_bit_identical"] is None

@@ -309,6 +309,29 @@ int recmv_mlp_forward(const recmv_mlp* m, const float* x, const float* cond, int
 int recmv_mlp_vjp_input(const recmv_mlp* m, const float* x, int64_t P, int n_out, const float* g_out, int64_t ldg,
                         float* gx, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Row-tile-persistent form of the two passes above for the few-thousand-row launches of the ray path (csrc/mlp_rows.hip): ONE
+ * launch per pass — a workgroup keeps the activations of 16 rays in LDS across all layers (positional encoding, per-frame code
+ * gather, skip concatenation, bias, activation, residual; in the reverse pass the activation gradients and the encoding's VJP),
+ * the weights stream from L2 in MFMA-fragment order.  Replaces, like the chains, model/network.py:98-133 (SDF value + input
+ * gradient) and model/Deformer.py:141-206 (offset MLP + VJP) as they are called by utils/FindSurfacePs.py:273-353.
+ *   recmv_mlp_rows_supported : 1 when the descriptor fits (2..12 layers, widths <= 512, <= 8 encoding bands, one net).
+ *   recmv_mlp_pack(_bytes)   : lays every layer's weight (and its transpose) out in fragment order, zero-padded — once per
+ *                              weight version; the packed buffer is what the two passes read.
+ *   recmv_mlp_rows_forward   : as recmv_mlp_forward with n_out <= 16; keep = 1 stores the hidden activations in `workspace`
+ *                              (recmv_mlp_rows_workspace_bytes) for the reverse pass.
+ *   recmv_mlp_rows_vjp_input : as recmv_mlp_vjp_input, after recmv_mlp_rows_forward(keep = 1) on the same workspace.
+ * Same arithmetic as the per-layer kernels (exact f32 MFMA products, f32 accumulation) in another summation order: results agree
+ * to rounding.  Rows are independent of the tile they sit in. */
+int recmv_mlp_rows_supported(const recmv_mlp* m);
+int64_t recmv_mlp_pack_bytes(const recmv_mlp* m);
+int recmv_mlp_pack(const recmv_mlp* m, void* packed, int64_t packed_bytes, void* stream);
+int64_t recmv_mlp_rows_workspace_bytes(const recmv_mlp* m, int64_t P);
+int recmv_mlp_rows_forward(const recmv_mlp* m, const void* packed, const float* x, const float* cond, int64_t ld_cond,
+                           const int64_t* cond_index, int64_t P, int n_out, float* out, int64_t ldo, void* workspace,
+                           int64_t workspace_bytes, int keep, void* stream);
+int recmv_mlp_rows_vjp_input(const recmv_mlp* m, const void* packed, const float* x, int64_t P, int n_out, const float* g_out,
+                             int64_t ldg, float* gx, const void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Strided element-wise helpers of the chains:
  *   recmv_act_grad_2d   : out[r,c] = out_scale * gy[r,c] * act'(z),  y = act(z) = y_scale * ybuf[r,c]; ldg may be 0
  *   recmv_add_scaled_2d : out[r,c] = a[r,c] + s * b[r,c]                                                       */

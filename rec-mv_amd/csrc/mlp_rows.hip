@@ -1,0 +1,652 @@
+// Row-tile-persistent fused MLP for the ray path — gfx950 (CDNA4, wave64, f32-input MFMA).
+//
+// The surface root finder (utils/FindSurfacePs.py:273-353 of the reference) evaluates, up to 21 times per iteration and
+// garment, the SDF net with its input gradient (model/network.py:98-133) and the deformer's offset MLP with a
+// vector-Jacobian product to its input (model/Deformer.py:141-206) on a few thousand rays.  csrc/mlp_chain.hip enqueues
+// those passes as one launch per layer: at 3 k rows a 512 x 512 layer is ONE round of workgroups, a third of its 22 us is
+// launch ramp / first operand tile / epilogue / drain, and the activations travel through L2 between every two launches.
+//
+// Here ONE launch evaluates a whole pass.  A workgroup (4 waves) owns a tile of 16 rays for all layers:
+//   * the tile's activations stay in LDS (two buffers of 16 x 520 floats, ping-pong; the row stride of 520 = 8 mod 64 makes
+//     every ds_read_b128 of an A fragment conflict-free for the 16x16x4 lane map), positional encoding, per-frame code
+//     gather, skip concatenation, bias, activation, residual and — in the reverse pass — the activation gradient and the
+//     encoding's VJP are all done on the tile in place;
+//   * the weights are streamed from L2 straight into MFMA B fragments: recmv_mlp_pack lays every layer out ONCE per weight
+//     version in fragment order (tile of 16 outputs x chunk of 16 inputs = 64 lanes x 16 bytes = one fully coalesced 1 KB
+//     wave load, zero-padded, so the loop has no guards), each wave owns a quarter of the layer's output columns and keeps
+//     the next chunk's fragments in flight under the 32 MFMAs (1 024 cycles) of the current one;
+//   * v_mfma_f32_16x16x4_f32: exact f32 products and accumulation (an fma chain) like the layer kernels of gemm_f32.hip;
+//     the k order inside a chunk differs from theirs, so results agree to rounding, not bitwise.  Rows are independent: a
+//     ray gets the same bits whatever tile it sits in.
+// With 16-row tiles every weight element fetched feeds 16 rows — 8 FLOP per byte from L2, 32 B/clk/CU at the matrix
+// pipe's full rate — which is why this form is for the few-thousand-row passes only; recmv_mlp_forward keeps the
+// per-layer kernels above RECMV_MLP_ROWS_MAX rows.
+#include "common.h"
+
+namespace recmv {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRows = 16;              // rays per workgroup
+constexpr int kThreads = 256;          // 4 waves: one quarter of a layer's output columns each
+constexpr int kLD = 520;               // LDS row stride in floats (= 8 mod 64, >= 512 + 8)
+constexpr int kMaxWidth = 512;
+constexpr int kPeLD = 52;              // gamma(x) rows kept for the skip connection (3 + 6 * 8 = 51 max)
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+constexpr float kSqrt2 = 1.41421356237309504880f;
+
+struct RowsLayer {
+  const float* Wp;       // packed weights: [tile][chunk][lane][4]
+  const float* bias;     // forward only
+  int32_t N;             // valid output columns
+  int32_t KC;            // chunks of 16 inputs (= chunk stride of a tile in the packed array)
+  int32_t TPW;           // 16-column tiles per wave (1, 2, 3, 4 or 8)
+  int32_t pad_;
+};
+
+struct RowsArgs {
+  RowsLayer fwd[RECMV_MLP_MAX_LAYERS];
+  RowsLayer bwd[RECMV_MLP_MAX_LAYERS];
+  const float* W_last;   // un-packed last weight (row 0 = the broadcast cotangent of a scalar output)
+  int32_t n_layers, multires, cond_dim, skip_layer, hidden_act, residual;
+  int32_t dims[RECMV_MLP_MAX_LAYERS + 1];
+  int32_t rows[RECMV_MLP_MAX_LAYERS];
+  float act_param;
+  float pe_w[32];
+};
+
+__device__ __forceinline__ float act_fwd(float z, int act, float p, float inv_p) {
+  if (act == RECMV_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == RECMV_ACT_SOFTPLUS) {       // the epilogue formula of gemm_f32.hip (torch semantics, hardware exp2 / log2)
+    const float zb = z * p;
+    const float t = __expf(-fabsf(zb));
+    const float series = t * (1.f - t * (0.5f - t * (0.33333334f - 0.25f * t)));
+    const float l = t < 0.015625f ? series : __logf(1.f + t);
+    const float y = (fmaxf(zb, 0.f) + l) * inv_p;
+    return zb > 20.f ? z : y;
+  }
+  if (act == RECMV_ACT_TANH) return tanhf(z);
+  return z;
+}
+
+__device__ __forceinline__ float act_grad(float y, int act, float p) {   // act'(z) through y = act(z) (mlp_chain.hip)
+  switch (act) {
+    case RECMV_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case RECMV_ACT_SOFTPLUS: return -expm1f(-p * y);
+    case RECMV_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+// acc[t] += A[16 x 16*KC] . B_t^T for the wave's TPW column tiles.  A: LDS, row stride kLD, lane (r = l & 15, j = l >> 4)
+// reads the four inputs 16c + 4j .. + 3 of row r with one ds_read_b128; the packed B chunk holds the same four inputs of output
+// column 16t + r for that lane.  The next chunk's fragments are requested before the current chunk's 4 * TPW MFMAs are issued.
+template <int TPW>
+__device__ __forceinline__ void chunk_load(const f32x4* __restrict__ wp, int64_t tile_stride, int c, const float* __restrict__ arow,
+                                           f32x4 (&b)[TPW], f32x4& a) {
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) b[t] = wp[t * tile_stride + (int64_t)c * 64];
+  a = *reinterpret_cast<const f32x4*>(arow + 16 * c);
+}
+
+template <int TPW>
+__device__ __forceinline__ void chunk_mma(const f32x4 (&b)[TPW], const f32x4& a, f32x4 (&acc)[TPW]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
+  }
+}
+
+// Two register sets, the loop unrolled by two: the loads of chunk c + 1 are ISSUED before the MFMAs of chunk c (the scheduling
+// barriers keep the compiler from sinking them behind the matrix instructions), and a set is only waited for one whole chunk
+// (4 * TPW MFMAs) later.  The tail re-requests the last chunk instead of branching around loads.
+template <int TPW>
+__device__ __forceinline__ void tile_mma(const float* __restrict__ A, int KC, const float* __restrict__ Wp, int KCs, int wave,
+                                         int lane, f32x4 (&acc)[TPW]) {
+  const float* arow = A + (lane & 15) * kLD + 4 * (lane >> 4);
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((int64_t)wave * TPW * KCs) * 64 + lane;
+  const int64_t ts = (int64_t)KCs * 64;
+  const int last = KC - 1;
+  f32x4 b0[TPW], b1[TPW];
+  f32x4 a0, a1;
+  chunk_load<TPW>(wp, ts, 0, arow, b0, a0);
+  // (no exit between a request and its use: a load whose only use sits behind a branch gets sunk behind that branch)
+  for (int c = 0; c + 1 < KC; c += 2) {
+    chunk_load<TPW>(wp, ts, c + 1, arow, b1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_mma<TPW>(b0, a0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_load<TPW>(wp, ts, c + 2 < last ? c + 2 : last, arow, b0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    chunk_mma<TPW>(b1, a1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (KC & 1) chunk_mma<TPW>(b0, a0, acc);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// Epilogue of a hidden layer: bias + activation (+ 1/sqrt2 in front of the skip concatenation) from the accumulators into the
+// other LDS buffer; columns >= N (tile padding) are written as zeros.
+template <int TPW>
+__device__ __forceinline__ void hidden_layer(const RowsLayer& L, const float* __restrict__ in, float* __restrict__ outb, int wave,
+                                             int lane, int act, float p, float inv_p, float scale, bool zero_pad) {
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  tile_mma<TPW>(in, L.KC, L.Wp, L.KC, wave, lane, acc);
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int n = (wave * TPW + t) * 16 + (lane & 15);
+    const bool ok = n < L.N;
+    const float b = (ok && L.bias) ? L.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * (lane >> 4) + i;
+      const float v = act_fwd(acc[t][i] + b, act, p, inv_p) * scale;
+      // (behind the skip concatenation the columns past N belong to the encoding, written by the caller)
+      if (ok) outb[r * kLD + n] = v;
+      else if (zero_pad && n < kMaxWidth) outb[r * kLD + n] = 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void run_hidden(const RowsLayer& L, const float* in, float* outb, int wave, int lane, int act, float p,
+                                           float inv_p, float scale, bool zero_pad) {
+  switch (L.TPW) {
+    case 1: hidden_layer<1>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    case 2: hidden_layer<2>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    case 3: hidden_layer<3>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    case 4: hidden_layer<4>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    default: hidden_layer<8>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+  }
+}
+
+// x [P,3] -> out [P,n_out] (n_out <= 16): positional encoding (+ per-frame code) -> hidden layers -> last layer, one launch.
+// keep: every hidden activation tile is also written to acts[l] ([P16, ld_act] per layer) for mlp_rows_vjp_kernel.
+__global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, const float* __restrict__ x,
+                                                                const float* __restrict__ cond, int64_t ld_cond,
+                                                                const int64_t* __restrict__ cond_index, int64_t P, int n_out,
+                                                                float* __restrict__ out, int64_t ldo, float* __restrict__ acts,
+                                                                int64_t ld_act, int64_t act_stride, int keep) {
+  extern __shared__ float smem[];
+  float* buf0 = smem;
+  float* buf1 = smem + kRows * kLD;
+  float* pe = smem + 2 * kRows * kLD;            // [16][kPeLD] weighted gamma(x), unscaled
+  float* xs = pe + kRows * kPeLD;                // [16][4]
+  float* red = xs + kRows * 4;                   // [4 waves][64 lanes][4] partial sums of the last layer
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * kRows;
+  const int L = a.multires, nf = 1 + 2 * L, d_pe = 3 * nf;
+  const int n = a.n_layers;
+
+  if (tid < kRows * 3) {
+    const int r = tid / 3, c = tid - 3 * r;
+    xs[r * 4 + c] = (row0 + r < P) ? x[(row0 + r) * 3 + c] : 0.f;
+  }
+  __syncthreads();
+  // ---- input tile: [gamma(x) | code[frame] | zeros up to the chunk boundary]
+  for (int e = tid; e < kRows * nf; e += kThreads) {
+    const int r = e / nf, f = e - r * nf;
+    const float x0 = xs[r * 4], x1 = xs[r * 4 + 1], x2 = xs[r * 4 + 2];
+    float v0, v1, v2;
+    if (f == 0) {
+      v0 = x0; v1 = x1; v2 = x2;
+    } else {
+      const float freq = (float)(1 << ((f - 1) >> 1));
+      const float wt = a.pe_w[f - 1];
+      if ((f - 1) & 1) {
+        v0 = wt * cosf(x0 * freq); v1 = wt * cosf(x1 * freq); v2 = wt * cosf(x2 * freq);
+      } else {
+        v0 = wt * sinf(x0 * freq); v1 = wt * sinf(x1 * freq); v2 = wt * sinf(x2 * freq);
+      }
+    }
+    float* o = buf0 + r * kLD + 3 * f;
+    o[0] = v0; o[1] = v1; o[2] = v2;
+    float* q = pe + r * kPeLD + 3 * f;
+    q[0] = v0; q[1] = v1; q[2] = v2;
+  }
+  {
+    const int fill = a.fwd[0].KC * 16 - d_pe;     // code columns + zero padding
+    for (int e = tid; e < kRows * fill; e += kThreads) {
+      const int r = e / fill, c = e - r * fill;
+      float v = 0.f;
+      if (c < a.cond_dim && row0 + r < P) v = cond[(cond_index ? cond_index[row0 + r] : 0) * ld_cond + c];
+      buf0[r * kLD + d_pe + c] = v;
+    }
+  }
+  __syncthreads();
+  float* in = buf0;
+  float* ob = buf1;
+  const float p = a.act_param, inv_p = p != 0.f ? 1.f / p : 0.f;
+  for (int l = 0; l + 1 < n; ++l) {
+    const bool skip_next = (l + 1 == a.skip_layer);
+    run_hidden(a.fwd[l], in, ob, wave, lane, a.hidden_act, p, inv_p, skip_next ? kInvSqrt2 : 1.f, !skip_next);
+    const int width = a.dims[l + 1];              // = N (+ d_pe behind the skip)
+    if (skip_next) {
+      for (int e = tid; e < kRows * d_pe; e += kThreads) {
+        const int r = e / d_pe, c = e - r * d_pe;
+        ob[r * kLD + a.fwd[l].N + c] = pe[r * kPeLD + c] * kInvSqrt2;
+      }
+    }
+    {
+      const int padded = a.fwd[l + 1].KC * 16;     // the next layer reads whole chunks: zero what the tiles did not cover
+      const int covered = skip_next ? width : ((a.fwd[l].N + 15) / 16) * 16;
+      const int extra = padded - covered;
+      for (int e = tid; e < kRows * extra; e += kThreads) {
+        const int r = e / extra, c = e - r * extra;
+        ob[r * kLD + covered + c] = 0.f;
+      }
+    }
+    __syncthreads();
+    if (keep) {
+      float* dst = acts + (int64_t)l * act_stride + row0 * ld_act;
+      const int w4 = (width + 3) / 4;
+      for (int e = tid; e < kRows * w4; e += kThreads) {
+        const int r = e / w4, c = (e - r * w4) * 4;
+        *reinterpret_cast<float4*>(dst + (int64_t)r * ld_act + c) = *reinterpret_cast<const float4*>(ob + r * kLD + c);
+      }
+    }
+    float* t = in; in = ob; ob = t;
+  }
+  // ---- last layer, n_out <= 16 outputs: ONE column tile, its chunks dealt to the four waves, partial sums through LDS
+  {
+    const RowsLayer& Ll = a.fwd[n - 1];
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int KC = Ll.KC, per = (KC + 3) / 4;
+    const int c0 = wave * per, c1 = (c0 + per < KC) ? c0 + per : KC;
+    const float* arow = in + (lane & 15) * kLD + 4 * (lane >> 4);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(Ll.Wp) + lane;
+    for (int c = c0; c < c1; ++c) {
+      const f32x4 bv = wp[(int64_t)c * 64];
+      const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * c);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+    }
+    *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (wave == 0) {
+      const int nn = lane & 15;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * (lane >> 4) + i;
+        float v = red[lane * 4 + i] + red[(64 + lane) * 4 + i];
+        v += red[(128 + lane) * 4 + i];
+        v += red[(192 + lane) * 4 + i];
+        if (nn < n_out && row0 + r < P) {
+          if (Ll.bias) v += Ll.bias[nn];
+          if (a.residual) v += xs[r * 4 + nn];
+          out[(row0 + r) * ldo + nn] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ reverse pass
+// g <- dZ . W for the wave's column tiles, then the NEXT (earlier) layer's activation gradient applied in the epilogue:
+//   dZ_prev[r][c] = g[r][c] * act'(y_scale * y_prev[r][c]) * out_scale   for c < n_act (columns of the activation),
+//   park[r][c - n_act] = g[r][c] / sqrt2                                  for n_act <= c < n_act + d_pe (skip connection),
+// written to the other LDS buffer (zeros in the tile padding).  y_prev comes from the forward pass's workspace.
+template <int TPW>
+__device__ __forceinline__ void reverse_layer(const RowsLayer& L, const float* __restrict__ in, float* __restrict__ outb,
+                                              float* __restrict__ park, const float* __restrict__ yprev, int64_t ld_act, int n_act,
+                                              int d_park, int wave, int lane, int act, float p, float y_scale, float out_scale) {
+  f32x4 acc[TPW];
+  float yv[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int c = (wave * TPW + t) * 16 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yv[t][i] = (yprev && c < n_act) ? yprev[(int64_t)(4 * (lane >> 4) + i) * ld_act + c] : 0.f;
+  }
+  tile_mma<TPW>(in, L.KC, L.Wp, L.KC, wave, lane, acc);
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int c = (wave * TPW + t) * 16 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * (lane >> 4) + i;
+      const float g = acc[t][i];
+      if (c < n_act) {
+        outb[r * kLD + c] = yprev ? g * act_grad(yv[t][i] * y_scale, act, p) * out_scale : g;
+      } else {
+        if (c < n_act + d_park) park[r * kPeLD + (c - n_act)] = g * kInvSqrt2;
+        if (c < kMaxWidth) outb[r * kLD + c] = 0.f;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void run_reverse(const RowsLayer& L, const float* in, float* outb, float* park, const float* yprev,
+                                            int64_t ld_act, int n_act, int d_park, int wave, int lane, int act, float p,
+                                            float y_scale, float out_scale) {
+  switch (L.TPW) {
+    case 1: reverse_layer<1>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    case 2: reverse_layer<2>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    case 3: reverse_layer<3>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    case 4: reverse_layer<4>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    default: reverse_layer<8>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+  }
+}
+
+// gx [P,3] = J(x)^T g_out through the layers in reverse, from the activations mlp_rows_fwd_kernel(keep) left in `acts`.
+// g_out NULL: ones on a scalar output (the cotangent of every ray is row 0 of the last weight).
+__global__ __launch_bounds__(kThreads) void mlp_rows_vjp_kernel(RowsArgs a, const float* __restrict__ x, int64_t P, int n_out,
+                                                                const float* __restrict__ g_out, int64_t ldg,
+                                                                float* __restrict__ gx, const float* __restrict__ acts,
+                                                                int64_t ld_act, int64_t act_stride) {
+  extern __shared__ float smem[];
+  float* buf0 = smem;
+  float* buf1 = smem + kRows * kLD;
+  float* park = smem + 2 * kRows * kLD;          // [16][kPeLD] gradient of the encoding that entered through the skip
+  float* xs = park + kRows * kPeLD;              // [16][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * kRows;
+  const int L = a.multires, d_pe = 3 * (1 + 2 * L);
+  const int n = a.n_layers;
+  const float p = a.act_param;
+  if (tid < kRows * 3) {
+    const int r = tid / 3, c = tid - 3 * r;
+    xs[r * 4 + c] = (row0 + r < P) ? x[(row0 + r) * 3 + c] : 0.f;
+  }
+  for (int e = tid; e < kRows * kPeLD; e += kThreads) park[e] = 0.f;
+  const float* yt = acts + row0 * ld_act;        // this tile's rows of every stored activation
+  float* in = buf0;
+  float* ob = buf1;
+  // ---- dZ of the last hidden layer: (cotangent of the last layer's input) (.) act'
+  {
+    const int l = n - 2;                           // layer whose output feeds the last layer (n >= 2 checked by the host)
+    const bool skip_here = (l + 1 == a.skip_layer);
+    const int n_act = a.rows[l];
+    const float y_scale = skip_here ? kSqrt2 : 1.f, o_scale = skip_here ? kInvSqrt2 : 1.f;
+    const float* yprev = yt + (int64_t)l * act_stride;
+    if (!g_out) {
+      const int width = (a.dims[n - 1] + 15) / 16 * 16;
+      for (int e = tid; e < kRows * width; e += kThreads) {
+        const int r = e / width, c = e - r * width;
+        float v = 0.f;
+        if (c < a.dims[n - 1]) {
+          const float g = a.W_last[c];
+          if (c < n_act) v = g * act_grad(yprev[(int64_t)r * ld_act + c] * y_scale, a.hidden_act, p) * o_scale;
+          else if (c < n_act + d_pe) park[r * kPeLD + (c - n_act)] = g * kInvSqrt2;
+        }
+        in[r * kLD + c] = v;
+      }
+      __syncthreads();
+    } else {
+      // stage the cotangent tile (zero-padded to one chunk per 16 outputs), multiply by the last weight
+      const int kc = a.bwd[n - 1].KC;             // chunks of the packed last layer that hold outputs < n_out
+      for (int e = tid; e < kRows * kc * 16; e += kThreads) {
+        const int r = e / (kc * 16), c = e - r * (kc * 16);
+        ob[r * kLD + c] = (c < n_out && row0 + r < P) ? g_out[(row0 + r) * ldg + c] : 0.f;
+      }
+      __syncthreads();
+      run_reverse(a.bwd[n - 1], ob, in, park, yprev, ld_act, n_act, skip_here ? d_pe : 0, wave, lane, a.hidden_act, p, y_scale,
+                  o_scale);
+      __syncthreads();
+    }
+  }
+  // ---- hidden layers in reverse: in = dZ_l  ->  ob = dZ_{l-1}
+  for (int l = n - 2; l >= 1; --l) {
+    const bool skip_here = (l == a.skip_layer);   // layer l's input = [act(z_{l-1}) / sqrt2 | gamma / sqrt2]
+    const int n_act = a.rows[l - 1];
+    const float* yprev = yt + (int64_t)(l - 1) * act_stride;
+    run_reverse(a.bwd[l], in, ob, park, yprev, ld_act, n_act, skip_here ? d_pe : 0, wave, lane, a.hidden_act, p,
+                skip_here ? kSqrt2 : 1.f, skip_here ? kInvSqrt2 : 1.f);
+    {
+      const int padded = a.bwd[l - 1].KC * 16;     // zero what the column tiles of this layer did not cover
+      const int covered = a.bwd[l].TPW * 64 < kMaxWidth ? a.bwd[l].TPW * 64 : kMaxWidth;
+      const int extra = padded - covered;
+      for (int e = tid; e < kRows * extra; e += kThreads) {
+        const int r = e / extra, c = e - r * extra;
+        ob[r * kLD + covered + c] = 0.f;
+      }
+    }
+    __syncthreads();
+    float* t = in; in = ob; ob = t;
+  }
+  // ---- first layer: gradient of [gamma(x) | code]; only the encoding's columns flow to x
+  run_reverse(a.bwd[0], in, ob, park, nullptr, ld_act, d_pe, 0, wave, lane, RECMV_ACT_NONE, 0.f, 1.f, 1.f);
+  __syncthreads();
+  if (tid < kRows * 3) {
+    const int r = tid / 3, c = tid - 3 * r;
+    if (row0 + r < P) {
+      const float xc = xs[r * 4 + c];
+      const float* gp = ob + r * kLD;
+      const float* sp = park + r * kPeLD;
+      float acc = gp[c] + sp[c];
+      for (int b = 0; b < L; ++b) {
+        const float f = (float)(1 << b);
+        float s, co;
+        sincosf(xc * f, &s, &co);
+        const float gs = gp[3 + 6 * b + c] + sp[3 + 6 * b + c], gc = gp[3 + 6 * b + 3 + c] + sp[3 + 6 * b + 3 + c];
+        acc += f * (a.pe_w[2 * b] * co * gs - a.pe_w[2 * b + 1] * s * gc);
+      }
+      if (a.residual) acc += g_out[(row0 + r) * ldg + c];
+      gx[(row0 + r) * 3 + c] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ packing
+// out[((t * KC + c) * 64 + l) * 4 + s] = B[n = 16 t + (l & 15)][k = 16 c + 4 (l >> 4) + s], zero outside [N) x [K);
+// B[n][k] = W[n * sn + k * sk]: (ldw, 1) packs W for the forward product, (1, ldw) packs W^T for the reverse one.
+__global__ __launch_bounds__(kThreads) void mlp_pack_kernel(const float* __restrict__ W, int64_t sn, int64_t sk, int N, int K,
+                                                            int KC, int64_t total4, float* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total4; e += (int64_t)gridDim.x * kThreads) {
+    const int l = (int)(e & 63);
+    const int64_t blk = e >> 6;
+    const int c = (int)(blk % KC);
+    const int t = (int)(blk / KC);
+    const int nn = 16 * t + (l & 15);
+    const int k0 = 16 * c + 4 * (l >> 4);
+    float4 v;
+    v.x = (nn < N && k0 + 0 < K) ? W[nn * sn + (k0 + 0) * sk] : 0.f;
+    v.y = (nn < N && k0 + 1 < K) ? W[nn * sn + (k0 + 1) * sk] : 0.f;
+    v.z = (nn < N && k0 + 2 < K) ? W[nn * sn + (k0 + 2) * sk] : 0.f;
+    v.w = (nn < N && k0 + 3 < K) ? W[nn * sn + (k0 + 3) * sk] : 0.f;
+    reinterpret_cast<float4*>(out)[e] = v;
+  }
+}
+
+inline int tpw_for(int N) {
+  const int tiles = (N + 15) / 16;
+  const int per = (tiles + 3) / 4;
+  return per <= 4 ? (per < 1 ? 1 : per) : 8;
+}
+
+struct PackPlan {
+  int64_t off_fwd[RECMV_MLP_MAX_LAYERS], off_bwd[RECMV_MLP_MAX_LAYERS];   // float offsets into the packed buffer
+  int N_fwd[RECMV_MLP_MAX_LAYERS], K_fwd[RECMV_MLP_MAX_LAYERS], N_bwd[RECMV_MLP_MAX_LAYERS], K_bwd[RECMV_MLP_MAX_LAYERS];
+  int64_t floats;
+};
+
+inline int64_t packed_floats(int N, int K, bool whole_tiles_only) {
+  const int tiles = whole_tiles_only ? (N + 15) / 16 : tpw_for(N) * 4;
+  return (int64_t)tiles * ((K + 15) / 16) * 256;
+}
+
+// forward: layer l maps dims[l] inputs to rows[l] outputs (the last layer is packed tile by tile, it is evaluated one tile at a
+// time); reverse: layer l maps rows[l] cotangents to dims[l] input gradients — only the encoding's columns for layer 0.
+PackPlan make_plan(const recmv_mlp* m) {
+  PackPlan pl;
+  int64_t o = 0;
+  const int n = m->n_layers, d_pe = 3 + 6 * m->multires;
+  for (int l = 0; l < n; ++l) {
+    pl.N_fwd[l] = m->rows[l];
+    pl.K_fwd[l] = m->dims[l];
+    pl.off_fwd[l] = o;
+    o += packed_floats(pl.N_fwd[l], pl.K_fwd[l], l == n - 1);
+    pl.N_bwd[l] = l == 0 ? d_pe : m->dims[l];
+    pl.K_bwd[l] = m->rows[l];
+    pl.off_bwd[l] = o;
+    o += packed_floats(pl.N_bwd[l], pl.K_bwd[l], false);
+  }
+  pl.floats = o;
+  return pl;
+}
+
+int rows_supported(const recmv_mlp* m) {
+  if (!m || m->n_layers < 2 || m->n_layers > RECMV_MLP_MAX_LAYERS) return 0;
+  if (m->multires < 0 || m->multires > 8) return 0;
+  if (m->split_row > 0 && m->W2[0]) return 0;
+  for (int l = 0; l <= m->n_layers; ++l)
+    if (m->dims[l] > kMaxWidth && l < m->n_layers) return 0;
+  for (int l = 0; l + 1 < m->n_layers; ++l)
+    if (m->rows[l] > kMaxWidth) return 0;
+  if (m->skip_layer == 0 || m->skip_layer >= m->n_layers) return 0;
+  return 1;
+}
+
+void fill_args(const recmv_mlp* m, const float* packed, RowsArgs* a) {
+  const PackPlan pl = make_plan(m);
+  const int n = m->n_layers;
+  memset(a, 0, sizeof(*a));
+  for (int l = 0; l < n; ++l) {
+    a->fwd[l].Wp = packed + pl.off_fwd[l];
+    a->fwd[l].bias = m->bias[l];
+    a->fwd[l].N = pl.N_fwd[l];
+    a->fwd[l].KC = (pl.K_fwd[l] + 15) / 16;
+    a->fwd[l].TPW = tpw_for(pl.N_fwd[l]);
+    a->bwd[l].Wp = packed + pl.off_bwd[l];
+    a->bwd[l].bias = nullptr;
+    a->bwd[l].N = pl.N_bwd[l];
+    a->bwd[l].KC = (pl.K_bwd[l] + 15) / 16;
+    a->bwd[l].TPW = tpw_for(pl.N_bwd[l]);
+    a->rows[l] = m->rows[l];
+  }
+  for (int l = 0; l <= n; ++l) a->dims[l] = m->dims[l];
+  a->W_last = m->W[n - 1];
+  a->n_layers = n;
+  a->multires = m->multires;
+  a->cond_dim = m->cond_dim;
+  a->skip_layer = m->skip_layer;
+  a->hidden_act = m->hidden_act;
+  a->residual = m->residual;
+  a->act_param = m->act_param;
+  for (int i = 0; i < 32; ++i) a->pe_w[i] = m->pe_weights[i];
+}
+
+constexpr size_t kFwdLds = (size_t)(2 * kRows * kLD + kRows * kPeLD + kRows * 4 + 4 * 64 * 4) * sizeof(float);
+constexpr size_t kVjpLds = (size_t)(2 * kRows * kLD + kRows * kPeLD + kRows * 4) * sizeof(float);
+
+inline int64_t pad16(int64_t v) { return (v + 15) / 16 * 16; }
+
+struct RowsLayout {
+  int64_t ld_act, act_stride, bytes;
+};
+
+RowsLayout rows_layout(const recmv_mlp* m, int64_t P) {
+  RowsLayout L;
+  int64_t maxw = 16;
+  for (int l = 1; l < m->n_layers; ++l) maxw = m->dims[l] > maxw ? m->dims[l] : maxw;
+  L.ld_act = pad16(maxw);
+  L.act_stride = pad16(P) * L.ld_act;
+  L.bytes = (int64_t)(m->n_layers - 1) * L.act_stride * 4;
+  return L;
+}
+
+}  // namespace
+}  // namespace recmv
+
+using namespace recmv;
+
+extern "C" int recmv_mlp_rows_supported(const recmv_mlp* m) { return rows_supported(m); }
+
+extern "C" int64_t recmv_mlp_pack_bytes(const recmv_mlp* m) {
+  if (!rows_supported(m)) return 0;
+  return make_plan(m).floats * 4;
+}
+
+extern "C" int recmv_mlp_pack(const recmv_mlp* m, void* packed, int64_t packed_bytes, void* stream) {
+  RECMV_REQUIRE(rows_supported(m), "mlp_pack: this net does not fit the row-tile kernels");
+  const PackPlan pl = make_plan(m);
+  RECMV_REQUIRE(packed && packed_bytes >= pl.floats * 4, "mlp_pack: buffer %lld < %lld bytes", (long long)packed_bytes,
+                (long long)(pl.floats * 4));
+  float* out = (float*)packed;
+  const int n = m->n_layers;
+  for (int l = 0; l < n; ++l) {
+    RECMV_REQUIRE(m->W[l], "mlp_pack: layer %d has no weight", l);
+    const int ldw = m->dims[l];
+    {
+      const int KC = (pl.K_fwd[l] + 15) / 16;
+      const int64_t total4 = packed_floats(pl.N_fwd[l], pl.K_fwd[l], l == n - 1) / 4;
+      hipLaunchKernelGGL(mlp_pack_kernel, dim3(stream_grid(total4, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, m->W[l],
+                         (int64_t)ldw, (int64_t)1, pl.N_fwd[l], pl.K_fwd[l], KC, total4, out + pl.off_fwd[l]);
+    }
+    {
+      const int KC = (pl.K_bwd[l] + 15) / 16;
+      const int64_t total4 = packed_floats(pl.N_bwd[l], pl.K_bwd[l], false) / 4;
+      hipLaunchKernelGGL(mlp_pack_kernel, dim3(stream_grid(total4, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, m->W[l],
+                         (int64_t)1, (int64_t)ldw, pl.N_bwd[l], pl.K_bwd[l], KC, total4, out + pl.off_bwd[l]);
+    }
+  }
+  return check_launch("mlp_pack");
+}
+
+extern "C" int64_t recmv_mlp_rows_workspace_bytes(const recmv_mlp* m, int64_t P) {
+  if (!rows_supported(m) || P <= 0) return 0;
+  return rows_layout(m, P).bytes;
+}
+
+extern "C" int recmv_mlp_rows_forward(const recmv_mlp* m, const void* packed, const float* x, const float* cond, int64_t ld_cond,
+                                      const int64_t* cond_index, int64_t P, int n_out, float* out, int64_t ldo, void* workspace,
+                                      int64_t workspace_bytes, int keep, void* stream) {
+  RECMV_REQUIRE(rows_supported(m), "mlp_rows_forward: this net does not fit the row-tile kernels");
+  RECMV_REQUIRE(P >= 0, "mlp_rows_forward: negative P");
+  if (P == 0) return RECMV_OK;
+  RECMV_REQUIRE(packed && x && out, "mlp_rows_forward: NULL pointer");
+  RECMV_REQUIRE(n_out >= 1 && n_out <= 16 && n_out <= m->rows[m->n_layers - 1] && ldo >= n_out, "mlp_rows_forward: bad n_out %d", n_out);
+  RECMV_REQUIRE(m->cond_dim == 0 || cond, "mlp_rows_forward: the net takes a per-frame code but cond is NULL");
+  RECMV_REQUIRE(!m->residual || n_out == 3, "mlp_rows_forward: residual nets are 3-d");
+  const RowsLayout L = rows_layout(m, P);
+  if (keep) {
+    RECMV_REQUIRE(workspace, "mlp_rows_forward: keep needs a workspace");
+    if (workspace_bytes < L.bytes) {
+      set_error("mlp_rows_forward: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)L.bytes);
+      return RECMV_ERR_WORKSPACE;
+    }
+  }
+  RowsArgs a;
+  fill_args(m, (const float*)packed, &a);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RECMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_rows_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kFwdLds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mlp_rows_fwd_kernel, dim3((unsigned)ceil_div(P, kRows)), dim3(kThreads), kFwdLds, (hipStream_t)stream, a, x, cond,
+                     ld_cond, cond_index, P, n_out, out, ldo, (float*)workspace, L.ld_act, L.act_stride, keep);
+  return check_launch("mlp_rows_forward");
+}
+
+extern "C" int recmv_mlp_rows_vjp_input(const recmv_mlp* m, const void* packed, const float* x, int64_t P, int n_out,
+                                        const float* g_out, int64_t ldg, float* gx, const void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
+  RECMV_REQUIRE(rows_supported(m), "mlp_rows_vjp_input: this net does not fit the row-tile kernels");
+  RECMV_REQUIRE(P >= 0, "mlp_rows_vjp_input: negative P");
+  if (P == 0) return RECMV_OK;
+  RECMV_REQUIRE(packed && x && gx && workspace, "mlp_rows_vjp_input: NULL pointer");
+  RECMV_REQUIRE(n_out >= 1 && n_out <= 16 && n_out <= m->rows[m->n_layers - 1], "mlp_rows_vjp_input: bad n_out %d", n_out);
+  RECMV_REQUIRE(g_out || n_out == 1, "mlp_rows_vjp_input: a NULL cotangent means ones and needs n_out == 1");
+  RECMV_REQUIRE(!m->residual || (g_out && n_out == 3), "mlp_rows_vjp_input: residual nets need their 3-d cotangent");
+  const RowsLayout L = rows_layout(m, P);
+  if (workspace_bytes < L.bytes) {
+    set_error("mlp_rows_vjp_input: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)L.bytes);
+    return RECMV_ERR_WORKSPACE;
+  }
+  RowsArgs a;
+  fill_args(m, (const float*)packed, &a);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RECMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_rows_vjp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kVjpLds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mlp_rows_vjp_kernel, dim3((unsigned)ceil_div(P, kRows)), dim3(kThreads), kVjpLds, (hipStream_t)stream, a, x, P,
+                     n_out, g_out, ldg, gx, (const float*)workspace, L.ld_act, L.act_stride);
+  return check_launch("mlp_rows_vjp_input");
+}

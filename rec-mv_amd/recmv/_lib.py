@@ -105,6 +105,12 @@ def _declare(lib):
         "recmv_mlp_workspace_bytes": (i64, [C.POINTER(Mlp), i64, i32]),
         "recmv_mlp_forward": (C.c_int, [C.POINTER(Mlp), vp, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp]),
         "recmv_mlp_vjp_input": (C.c_int, [C.POINTER(Mlp), vp, i64, i32, vp, i64, vp, vp, i64, vp]),
+        "recmv_mlp_rows_supported": (C.c_int, [C.POINTER(Mlp)]),
+        "recmv_mlp_pack_bytes": (i64, [C.POINTER(Mlp)]),
+        "recmv_mlp_pack": (C.c_int, [C.POINTER(Mlp), vp, i64, vp]),
+        "recmv_mlp_rows_workspace_bytes": (i64, [C.POINTER(Mlp), i64]),
+        "recmv_mlp_rows_forward": (C.c_int, [C.POINTER(Mlp), vp, vp, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp]),
+        "recmv_mlp_rows_vjp_input": (C.c_int, [C.POINTER(Mlp), vp, vp, i64, i32, vp, i64, vp, vp, i64, vp]),
         "recmv_act_grad_2d": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i32, f32, f32, f32, vp]),
         "recmv_add_scaled_2d": (C.c_int, [vp, i64, vp, i64, f32, vp, i64, i64, i64, vp]),
         "recmv_colsum_workspace_bytes": (i64, [i64, i64]),

@@ -8,10 +8,19 @@ garment (utils/FindSurfacePs.py:273-353 of the reference) and the no-grad grid q
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib as L
+
+# Passes of at most this many rows run as ONE launch of the row-tile kernels (csrc/mlp_rows.hip); above it a 16-row tile re-reads
+# the weights too often and the per-layer kernels win.  RECMV_MLP_ROWS=0 keeps the per-layer chains everywhere (the A/B switch).
+MLP_ROWS_MAX = int(os.environ.get("RECMV_MLP_ROWS_MAX", "6144"))
+
+
+def _rows_enabled():
+    return os.environ.get("RECMV_MLP_ROWS", "1") != "0"
 
 
 class MlpChain:
@@ -58,6 +67,42 @@ class MlpChain:
         self.n_layers = n
         self.rows_last = rows[-1]
         self._ws = {}
+        # row-tile form (csrc/mlp_rows.hip): the packed weights are built on first use, once per descriptor = per weight version
+        self._rows_ok = second is None and bool(L.lib().recmv_mlp_rows_supported(C.byref(m)))
+        self._packed = None
+        self._packed_ev = None
+        self._packed_seen = set()
+        self._rows_ws = {}
+        self._rows_last = {}          # slot -> did the last forward(keep=True) take the row-tile path?
+
+    def _use_rows(self, P, n_out, split_row):
+        return (self._rows_ok and 0 < P <= MLP_ROWS_MAX and n_out <= 16 and (split_row is None or not self.has_second)
+                and _rows_enabled())
+
+    def _pack(self, dev):
+        """The packed weights, valid on the current stream of `dev` (packed on the first caller's stream; other streams wait for
+        that once)."""
+        st = torch.cuda.current_stream(dev)
+        if self._packed is None:
+            n = int(L.lib().recmv_mlp_pack_bytes(C.byref(self.m)))
+            self._packed = torch.empty(n, dtype=torch.uint8, device=dev)
+            with L.device_guard(dev):
+                L.check(L.lib().recmv_mlp_pack(C.byref(self.m), L.ptr(self._packed), n, L.stream_ptr(dev)), "mlp_pack")
+            self._packed_ev = torch.cuda.Event()
+            self._packed_ev.record(st)
+            self._packed_seen.add(st.cuda_stream)
+        elif st.cuda_stream not in self._packed_seen:
+            st.wait_event(self._packed_ev)
+            self._packed_seen.add(st.cuda_stream)
+        return self._packed
+
+    def _rows_workspace(self, P, slot):
+        need = int(L.lib().recmv_mlp_rows_workspace_bytes(C.byref(self.m), P))
+        ws = self._rows_ws.get(slot)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+            self._rows_ws[slot] = ws
+        return ws
 
     def _workspace(self, P, keep, slot=None):
         """Activation workspace; `slot` separates concurrent users of one chain (e.g. two garments evaluated on two
@@ -84,13 +129,25 @@ class MlpChain:
         n_out = self.rows_last if n_out is None else n_out
         if out is None:
             out = torch.empty((P, n_out), dtype=torch.float32, device=x.device)
-        ws = self._workspace(P, int(keep), slot)
         ld_cond = 0
         if cond is not None:
             assert cond.dtype == torch.float32 and cond.stride(-1) == 1 and cond.dim() == 2
             ld_cond = cond.stride(0)
             if cond_index is not None:
                 assert cond_index.dtype == torch.int64 and cond_index.is_contiguous() and cond_index.numel() == P
+        rows = self._use_rows(P, n_out, split_row)
+        if keep:
+            self._rows_last[slot] = rows
+        if rows:
+            packed = self._pack(x.device)
+            ws = self._rows_workspace(P, slot) if keep else None
+            with L.device_guard(x.device):
+                L.check(L.lib().recmv_mlp_rows_forward(C.byref(self.m), L.ptr(packed), L.ptr(x), L.ptr(cond), ld_cond,
+                                                       L.ptr(cond_index), P, n_out, L.ptr(out), out.stride(0) if P > 1 else n_out,
+                                                       L.ptr(ws), ws.numel() if ws is not None else 0, int(keep),
+                                                       L.stream_ptr(x.device)), "mlp_rows_forward")
+            return out
+        ws = self._workspace(P, int(keep), slot)
         with L.device_guard(x.device):
             L.check(L.lib().recmv_mlp_forward(C.byref(self.m), L.ptr(x), L.ptr(cond), ld_cond, L.ptr(cond_index), P,
                                               n_out, L.ptr(out), out.stride(0) if P > 1 else n_out, L.ptr(ws), ws.numel(),
@@ -103,11 +160,19 @@ class MlpChain:
         self._split(split_row, P)
         n_out = (1 if g_out is None else g_out.shape[1]) if n_out is None else n_out
         gx = torch.empty((P, 3), dtype=torch.float32, device=x.device)
-        ws = self._workspace(P, 1, slot)
         ldg = 0
         if g_out is not None:
             assert g_out.dtype == torch.float32 and g_out.stride(1) == 1 and g_out.shape == (P, n_out)
             ldg = g_out.stride(0) if P > 1 else n_out
+        if self._rows_last.get(slot, False):          # the activations are where the row-tile forward left them
+            packed = self._pack(x.device)
+            ws = self._rows_workspace(P, slot)
+            with L.device_guard(x.device):
+                L.check(L.lib().recmv_mlp_rows_vjp_input(C.byref(self.m), L.ptr(packed), L.ptr(x), P, n_out, L.ptr(g_out), ldg,
+                                                         L.ptr(gx), L.ptr(ws), ws.numel(), L.stream_ptr(x.device)),
+                        "mlp_rows_vjp_input")
+            return gx
+        ws = self._workspace(P, 1, slot)
         with L.device_guard(x.device):
             L.check(L.lib().recmv_mlp_vjp_input(C.byref(self.m), L.ptr(x), P, n_out, L.ptr(g_out), ldg, L.ptr(gx),
                                                 L.ptr(ws), ws.numel(), L.stream_ptr(x.device)), "mlp_vjp_input")

@@ -18,6 +18,19 @@ ROWS = 24
 BOX = ((-0.8, -1.1, -0.6), (0.8, 1.1, 0.6))
 RESOLUTIONS = [(9, 11, 7), (17, 21, 13)]
 BODY_BIAS = 0.5
+# the trajectory case (row g: north_star's "canonical-mesh Chamfer within 1e-4 of reference"): TRAJ_ITERS optimiser iterations from
+# the fixture's state, the scheduled re-mesh at forward_time 30 inside, canonical extraction on a finer pyramid at the end
+TRAJ_ITERS = 35
+import os as _os
+TRAJ_LR = float(_os.environ.get('TRAJ_LR', 1e-4))            # the reference's train.learning_rate (configs/people_snapshot/*.conf); the one-iteration fixtures use 1e-3
+TRAJ_CANONICAL_RES = [(9, 11, 7), (17, 21, 13), (33, 41, 25), (65, 81, 49)]
+
+
+def trajectory_frames(it):
+    """The three frames of iteration `it` (a fixed schedule over the 40-frame sequence; the images stay the fixture's)."""
+    return [(7 * it) % F, (11 * it + 3) % F, (13 * it + 5) % F]
+
+
 GARMENT_TYPE = 'male-1-casual'      # TEMPLATE_GARMENT: short_sleeve_upper + long_pants, the garment names the fixture was made with
 
 
@@ -91,17 +104,10 @@ class CaseDataset:
         return [self.poses, self.trans, self.dcond, self.rend, self.focal, self.pp, self.T]
 
 
-def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, remesh=False, rtol_loss=None, rtol_cam=None, single=False):
-    """One whole iteration of recmv's loop — HotLoop.forward, backward, propagateTmpPsGrad — on the fixture's state against
-    what the reference's forward / backward / propagateTmpPsGrad produced; returns the largest relative deviations.
-    `large_pose`: the large-pose stage on both sides (OptimGarmentNetwork_LargePose: SDF nets frozen, curve terms zero-weighted);
-    `inputs`: the fixture that holds the `in_*` state when `g` has outputs only; `remesh`: the iteration starts with the re-mesh
-    (forward_time = 0: Seg3dLossless pyramid + MC of the body net and both garment nets) instead of given explicit meshes;
-    `single`: the one-piece-garment case (`leyang_jump` = ['dress'], train.is_upper_bottom: single_state()).
-    Tolerances (relative to the largest reference entry of each tensor): `rtol_loss` for the total loss (default `rtol`), `rtol`
-    for the per-term info values and the stepped vertices, `rtol_grad` for the gradients the main optimiser consumes, `rtol_cam`
-    (default `rtol_grad`) for the two camera-intrinsic gradients — sums of thousands of signed per-ray terms that cancel to a
-    few per cent of their magnitude."""
+def build(g, device, large_pose=False, inputs=None, remesh=False, single=False, trajectory=False, lr=1e-3):
+    """recmv's loop on the fixture's state: the facade object getOptNet returns with the fixture's networks, meshes, curves, camera
+    and per-frame tensors put in (see run() for the switches; `trajectory`: explicit meshes given AND a body net for the scheduled
+    re-mesh).  Returns (optNet, dataset, optimizer, frame_ids, modules) with modules = (sdfs, translator, skinner, colour net, curve)."""
     from pathlib import Path
     import numpy as np
     import common_setup as cs
@@ -132,12 +138,12 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
     optNet.deformer = CompositeDeformer([tr, sk])
     optNet.netRender = rn
     optNet.tmpBodyVs, optNet.tmpBodyFs = st['body_v'], st['body_f'].long()
-    if remesh:
+    if remesh or trajectory:
         torch.manual_seed(520)
         optNet.sdf = cs.perturb(getTmpSdf("cpu", 6, bias=BODY_BIAS), 502, 0.003).to(dev)
         optNet.body_vs = optNet.body_fs = None
         assert [tuple(r) for r in optNet.engine.resolutions.tolist()] == RESOLUTIONS
-    else:
+    if not remesh:
         verts = [leaf(st['verts_u']), leaf(st['verts_b'])][:len(sdfs)]
         optNet.garment_vs, optNet.garment_fs = verts, [st['faces_u'].long(), st['faces_b'].long()][:len(sdfs)]
         optNet.body_vs, optNet.body_fs = st['body_v'], st['body_f'].long()
@@ -170,8 +176,25 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
         return torch.from_numpy(pts).float().to(dev)
 
     optNet.curve_aware_loss = lambda ratio: HotLoop.curve_aware_loss(optNet, ratio, sampler=sampler)
-    opt = optNet.rebuild_optimizer(lr=1e-3)
+    opt = optNet.rebuild_optimizer(lr=lr)
     frame_ids = torch.tensor(FRAME_IDS, device=dev)
+    return optNet, ds, opt, frame_ids, (sdfs, tr, sk, rn, curve)
+
+
+def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, remesh=False, rtol_loss=None, rtol_cam=None, single=False):
+    """One whole iteration of recmv's loop — HotLoop.forward, backward, propagateTmpPsGrad — on the fixture's state against
+    what the reference's forward / backward / propagateTmpPsGrad produced; returns the largest relative deviations.
+    `large_pose`: the large-pose stage on both sides (OptimGarmentNetwork_LargePose: SDF nets frozen, curve terms zero-weighted);
+    `inputs`: the fixture that holds the `in_*` state when `g` has outputs only; `remesh`: the iteration starts with the re-mesh
+    (forward_time = 0: Seg3dLossless pyramid + MC of the body net and both garment nets) instead of given explicit meshes;
+    `single`: the one-piece-garment case (`leyang_jump` = ['dress'], train.is_upper_bottom: single_state()).
+    Tolerances (relative to the largest reference entry of each tensor): `rtol_loss` for the total loss (default `rtol`), `rtol`
+    for the per-term info values and the stepped vertices, `rtol_grad` for the gradients the main optimiser consumes, `rtol_cam`
+    (default `rtol_grad`) for the two camera-intrinsic gradients — sums of thousands of signed per-ray terms that cancel to a
+    few per cent of their magnitude."""
+    from recmv.loop import HotLoop
+    optNet, ds, opt, frame_ids, (sdfs, tr, sk, rn, curve) = build(g, device, large_pose, inputs, remesh, single)
+    verts = optNet.garment_vs
     torch.manual_seed(SEED)
     loss = HotLoop.forward(optNet, frame_ids, pc.RATIO, global_optimizer=opt)
     loss.backward()
@@ -246,3 +269,65 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
         got2 = [optNet.info['rays_total'], *[int(v) for v in optNet.info['rays_converged']]]
         assert got2[0] == want2[0] + want2[2] and abs(got2[1] - want2[1]) <= 2 and abs(got2[2] - want2[3]) <= 2, (got2, want2)
     return worst
+
+
+def chamfer_vertices(a, b):
+    """Symmetric Chamfer distance between two vertex sets in pytorch3d's convention (mean over points of the SQUARED distance to
+    the nearest neighbour, both directions summed) and the mean UNsquared nearest-neighbour distance, in float64."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    d2 = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+    ab, ba = d2.min(1).values, d2.min(0).values
+    return float(ab.mean() + ba.mean()), float(0.5 * (ab.sqrt().mean() + ba.sqrt().mean()))
+
+
+def run_trajectory(g, inputs, device, iters=None):
+    """Row (g) of the scope table — north_star's "canonical-mesh Chamfer within 1e-4 of reference": recmv's loop for TRAJ_ITERS
+    optimiser iterations in train.py's order (train.py:317-328) from the fixture's state, the scheduled re-mesh (forward_time 30)
+    inside, then the canonical meshes of the body net and both garment nets on the finer pyramid — against the reference's own loop
+    run the same way (tests/golden/make_golden_forward.py trajectory -> trajectory.npz).  Returns a dict of what was measured; the
+    caller asserts."""
+    from recmv.MCAcc import Seg3dLossless
+    from recmv.loop import HotLoop
+    T = int(g['losses'].shape[0]) if iters is None else iters
+    optNet, ds, opt, _, (sdfs, tr, sk, rn, curve) = build(g, device, inputs=inputs, trajectory=True, lr=TRAJ_LR)
+    dev = torch.device(device)
+    losses, rays, verts_n, faces_equal = [], [], [], None
+    for it in range(T):
+        fids = torch.tensor(trajectory_frames(it), device=dev)
+        torch.manual_seed(SEED + it)
+        opt.zero_grad()
+        remesh_now = optNet.forward_time % optNet.remesh_intersect == 0
+        loss = HotLoop.forward(optNet, fids, pc.RATIO, global_optimizer=opt)
+        if loss.requires_grad:
+            loss.backward()
+        optNet.propagateTmpPsGrad(fids, pc.RATIO)
+        opt.step()
+        losses.append(float(loss.detach()))
+        conv = [int(v) for v in optNet.info['rays_converged']]
+        rays.append((int(optNet.info['rays_total']), *conv))
+        verts_n.append([int(v.shape[0]) for v in optNet.garment_vs])
+        if remesh_now:
+            faces_equal = [tuple(f.shape) == tuple(g[k].shape) and bool(torch.equal(f.cpu(), g[k].long()))
+                           for f, k in zip(optNet.garment_fs, ('final_faces_u', 'final_faces_b'))]
+    out = dict(losses=losses, rays=rays, verts_n=verts_n, remesh_faces_equal=faces_equal)
+    ref_l = g['losses'].double()
+    out['loss_rel_dev'] = [abs(a - float(b)) / max(abs(float(b)), 1e-12) for a, b in zip(losses, ref_l)]
+    ref_rays = g['rays']                                         # per garment (entering, converged)
+    out['rays_ref'] = [(int(r[0] + r[2]), int(r[1]), int(r[3])) for r in ref_rays[:T]]
+    if T == int(g['losses'].shape[0]):
+        fine = Seg3dLossless(query_func=None, b_min=list(BOX[0]), b_max=list(BOX[1]), resolutions=TRAJ_CANONICAL_RES,
+                             align_corners=False, balance_value=0.0, use_cuda_impl=dev.type == 'cuda', faster=False).to(dev)
+        vs, fs = optNet.discretizeSDF(pc.RATIO, fine, 0.)
+        for tag, v, f in zip(('body', 'u', 'b'), vs, fs):
+            sq, lin = chamfer_vertices(v, g['canon_v_' + tag])
+            out['canon_%s' % tag] = dict(chamfer_sq=sq, mean_dist=lin, moved_sq=float(g['canon_moved_' + tag][0]),
+                                         moved_dist=float(g['canon_moved_' + tag][1]), verts=(int(v.shape[0]), int(g['canon_v_' + tag].shape[0])),
+                                         faces_equal=tuple(f.shape) == tuple(g['canon_f_' + tag].shape)
+                                         and bool(torch.equal(f.cpu(), g['canon_f_' + tag].long())))
+        for tag, v in zip(('u', 'b'), optNet.garment_vs):
+            ref_v = g['final_verts_' + tag]
+            sq, lin = chamfer_vertices(v, ref_v)
+            same = tuple(v.shape) == tuple(ref_v.shape)
+            out['explicit_%s' % tag] = dict(chamfer_sq=sq, mean_dist=lin,
+                                            max_abs_dev=float((v.detach().cpu() - ref_v).abs().max()) if same else None)
+    return out

@@ -11,6 +11,7 @@ surface sampling by common_setup.TrimeshStandIn; no re-mesh inside (forward_time
 
     python tests/golden/make_golden_forward.py
 """
+import os
 import sys
 import types
 from pathlib import Path
@@ -55,10 +56,14 @@ class Pointclouds:
         return torch.cat(self.features, 0)
 
 
-def main(large_pose=False, remesh=False, single=False):
+def main(large_pose=False, remesh=False, single=False, trajectory=0):
     """`single`: ONE one-piece garment — capture `leyang_jump` = ['dress'] with `train.is_upper_bottom` (configs/female_large_pose/
     leyang_jump*.conf): the union region `datas['upper_bottom']` supervises it (:1894-1905), the deformer code holds body + one
-    garment (:670-676), four feature lines (neck, cuffs, hem), no curve-aware disc."""
+    garment (:670-676), four feature lines (neck, cuffs, hem), no curve-aware disc.
+    `trajectory` = T > 0: T whole optimiser iterations in train.py's order (train.py:317-328: zero_grad -> forward -> backward ->
+    propagateTmpPsGrad -> optimizer.step) from the explicit meshes of the fixture, the scheduled re-mesh (marching_cube_update,
+    forward_time % remesh_intersect == 0) inside, then the canonical meshes of the body and both garment nets extracted on a finer
+    pyramid (discretizeSDF :581-618) — the loss curve, the rays per iteration, the final explicit and canonical meshes."""
     Nref = ref_loader.ref_module("model.network")
     Dref = ref_loader.ref_module("model.Deformer")
     Rref = ref_loader.ref_module("model.RenderNet")
@@ -167,7 +172,7 @@ def main(large_pose=False, remesh=False, single=False):
         dataset.get_grad_parameters = lambda fids, dev: (leaves['poses_all'][fids], leaves['trans_all'][fids],
                                                          torch.cat([torch.zeros(fc.F, 128), leaves['cu_all']], dim=1)[fids],
                                                          leaves['rend_all'][fids])
-    if remesh:
+    if remesh or trajectory:
         # forward_time = 0: the iteration starts with marching_cube_update (:678-740) -> discretizeSDF (:581-618): the reference's
         # Seg3dLossless pyramid over the body net and both garment nets, MC through the oracle (canonical order), the explicit
         # vertices become leaves with fresh SGD / AdamW optimisers.  openmesh's vertex->face table (never read afterwards) is a
@@ -178,7 +183,7 @@ def main(large_pose=False, remesh=False, single=False):
                                          align_corners=False, balance_value=0.0, use_cuda_impl=False, faster=False)
         torch.manual_seed(520)
         fake.sdf = cs.perturb(Nref.getTmpSdf("cpu", 6, bias=fc.BODY_BIAS), 502, 0.003)
-        fake.forward_time, fake.visualizer, fake.opt_times = 0, None, 0.
+        fake.forward_time, fake.visualizer, fake.opt_times = (1 if trajectory else 0), None, 0.
         fake.update_hierarchical_config = lambda *a, **k: None
 
         class TriMesh:
@@ -205,7 +210,7 @@ def main(large_pose=False, remesh=False, single=False):
                  'find_surface_ps', 'compute_garment_pc_loss', 'curve_aware_loss', 'sample_train_ray', 'opt_garment_surface_ps',
                  'surface_render_loss', 'dct_poses_loss', 'save_debug'):
         setattr(fake, name, types.MethodType(getattr(KLASS, name), fake))
-    if remesh:
+    if remesh or trajectory:
         fake.save_debug = lambda *a, **k: None               # (`root` is set during a re-mesh iteration: no debug dumps)
     fake.garment_optimizer = torch.optim.SGD(verts, lr=0.05, momentum=0.9)
     fake.fl_optimizer = torch.optim.AdamW(ref.parameters(), lr=1e-4)
@@ -214,7 +219,7 @@ def main(large_pose=False, remesh=False, single=False):
         fake.garment_nets = torch.nn.ModuleList(sdfs)
         KLASS.freeze_sdf(fake)
     shared = [q for m in sdfs + [comp, rn] for q in m.parameters() if q.requires_grad] + list(leaves.values())
-    opt = torch.optim.Adam(shared, lr=1e-3)
+    opt = torch.optim.Adam(shared, lr=fc.TRAJ_LR if trajectory else 1e-3)
     datas = dict(img=st['img'], mask=((st['gt_u'] + st['gt_b']) > 0).float(), fl_pts=st['gt'], fl_masks=st['fl_masks'],
                  upper=st['gt_u'], bottom=st['gt_b'], body=torch.zeros_like(st['gt_u']), normal=st['normal'])
     if single:                                             # (only the union region is read with is_upper_bottom, :1901-1904)
@@ -223,6 +228,8 @@ def main(large_pose=False, remesh=False, single=False):
     real_cuda = torch.Tensor.cuda
     torch.Tensor.cuda = lambda self, *a, **k: self                    # curve_aware_loss uploads its samples with .cuda() (:809)
     try:
+        if trajectory:
+            return _trajectory(KLASS, fake, datas, opt, root, trajectory, Sref, names)
         torch.manual_seed(fc.SEED)
         loss = KLASS.forward(fake, datas, fc.SAMPLE_PIX, pc.RATIO, frame_ids, root if remesh else None, global_optimizer=opt)
         loss.backward()
@@ -295,7 +302,45 @@ def main(large_pose=False, remesh=False, single=False):
         save("forward", **res)
 
 
+def _trajectory(KLASS, fake, datas, opt, root, T, Sref, names):
+    """The reference's loop body (train.py:317-328) T times, then the canonical extraction; see main()."""
+    import time
+    losses, rays, verts_n = [], [], []
+    t0 = time.time()
+    fine = Sref.Seg3dLossless(query_func=None, b_min=list(fc.BOX[0]), b_max=list(fc.BOX[1]), resolutions=fc.TRAJ_CANONICAL_RES,
+                              align_corners=False, balance_value=0.0, use_cuda_impl=False, faster=False)
+    coarse, fake.engine = fake.engine, fine                # (discretizeSDF hands engine=None to its helper, :601-611: self.engine it is)
+    vs0, _ = KLASS.discretizeSDF(fake, pc.RATIO, None, 0.)         # the canonical meshes BEFORE the first step: how far the T steps move them
+    fake.engine = coarse
+    for it in range(T):
+        fids = torch.tensor(fc.trajectory_frames(it))
+        torch.manual_seed(fc.SEED + it)                     # (both sides re-seed per iteration: one extra surface pixel on one
+        opt.zero_grad()                                     #  side would otherwise shift every later host draw)
+        loss = KLASS.forward(fake, datas, fc.SAMPLE_PIX, pc.RATIO, fids, root, global_optimizer=opt)
+        loss.backward()
+        KLASS.propagateTmpPsGrad(fake, fids, pc.RATIO)
+        opt.step()
+        fake.root = None                                    # (set by a re-mesh: the next iterations dump nothing either way)
+        losses.append(float(loss.detach()))
+        rays.append([float(x) for n in names for x in fake.info['%s_rayInfo' % n]])
+        verts_n.append([int(v.shape[0]) for v in fake.garment_vs])
+        print("it %2d loss %.6f rays %s verts %s  (%.0f s)" % (it, losses[-1], rays[-1], verts_n[-1], time.time() - t0), flush=True)
+    fake.engine = fine
+    vs, fs = KLASS.discretizeSDF(fake, pc.RATIO, None, 0.)
+    res = dict(losses=torch.tensor(losses, dtype=torch.float64), rays=torch.tensor(rays), verts_n=torch.tensor(verts_n),
+               final_verts_u=fake.garment_vs[0].detach(), final_verts_b=fake.garment_vs[1].detach(),
+               final_faces_u=fake.garment_fs[0], final_faces_b=fake.garment_fs[1])
+    for tag, v, f in zip(('body', 'u', 'b'), vs, fs):
+        res['canon_v_' + tag], res['canon_f_' + tag] = v.detach(), f
+        res['canon_moved_' + tag] = torch.tensor(fc.chamfer_vertices(v, vs0[('body', 'u', 'b').index(tag)]))
+        print("canonical %s: %d vertices, %d faces" % (tag, v.shape[0], f.shape[0]))
+    save(os.environ.get("TRAJ_NAME", "trajectory"), **res)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "trajectory":     # (minutes of host time: generated on its own)
+        main(trajectory=fc.TRAJ_ITERS)
+        sys.exit(0)
     main()
     main(large_pose=True)
     main(remesh=True)

@@ -211,6 +211,50 @@ def test_root_finder(nets):
     assert err.max().item() < 2e-4, err.max().item()
 
 
+@pytest.mark.parametrize("P", [1, 15, 16, 1000, 3072, 5003])
+def test_row_tile_mlp_equals_the_per_layer_chain(nets, P, monkeypatch):
+    """csrc/mlp_rows.hip — ONE launch per pass, the activations of a 16-ray tile resident in LDS across all layers — against the
+    per-layer launch chain of csrc/mlp_chain.hip on the same descriptor: the SDF net's value and input gradient (softplus(100),
+    skip connection at layer 4, annealed encoding; model/network.py:98-133) and the deformer's offset MLP with its VJP (ReLU,
+    per-frame code gathered by frame id, residual; model/Deformer.py:141-206).  Same exact-f32 MFMA products in another summation
+    order: agreement to f32 rounding (1e-5 of the largest entry; softplus(100) amplifies pre-activation rounding 100x in the
+    gradient).  Row counts around the 16-row tile and the loop's sizes; a ray's result does not depend on its tile."""
+    import recmv.chains as chains
+    sdf, tr = nets["sdf"], nets["tr"]
+    gen = torch.Generator().manual_seed(P)
+    x = (torch.rand(P, 3, generator=gen) - 0.5).mul(1.4).to(DEV)
+    conds = load("translator")["conds"].to(DEV)
+    frame = torch.randint(0, conds.shape[0], (P,), generator=gen).to(DEV)
+    g3 = torch.randn(P, 3, generator=gen).to(DEV)
+
+    def run(rows):
+        monkeypatch.setenv("RECMV_MLP_ROWS", "1" if rows else "0")
+        ch = sdf.chain(sdf._pe_weights(RATIO), need_t=True)
+        f = ch.forward(x, n_out=1, keep=True, slot="t")
+        gf = ch.vjp_input(x, None, slot="t")
+        assert ch._rows_last["t"] == rows
+        ct = tr.prepare_explicit(conds, ratio=RATIO)
+        d = ct.forward(x, cond=conds, cond_index=frame, n_out=3, keep=True, slot="t")
+        gd = ct.vjp_input(x, g3, slot="t")
+        f_only = ch.forward(x, n_out=1, keep=False)             # (no workspace: the Seg3dLossless-style query)
+        torch.cuda.synchronize()
+        return f, gf, d, gd, f_only
+
+    a, b = run(True), run(False)
+    for name, u, v in zip(("sdf value", "sdf input gradient", "offset MLP", "offset MLP vjp", "sdf value (no keep)"), a, b):
+        scale = float(v.abs().max())
+        err = float((u - v).abs().max())
+        assert err <= 1e-5 * scale + 1e-7, (name, P, err, scale)
+    assert torch.equal(a[0], a[4])
+    if P >= 1000:       # the same rays in other tiles (shifted by 5 rows): bit-identical per ray
+        monkeypatch.setenv("RECMV_MLP_ROWS", "1")
+        ch = sdf.chain(sdf._pe_weights(RATIO), need_t=True)
+        xs = torch.cat([x[-5:], x[:-5]]).contiguous()
+        f2 = ch.forward(xs, n_out=1, keep=True, slot="t")
+        g2 = ch.vjp_input(xs, None, slot="t")
+        assert torch.equal(f2[5:], a[0][:-5]) and torch.equal(g2[5:], a[1][:-5])
+
+
 def test_root_finder_compaction_changes_no_ray(nets):
     """After the first update the unfinished rays move to the front and the remaining steps run over those rows only (the
     reference shrinks its active set every step, utils/FindSurfacePs.py:300-303): every ray ends where it ends without the

@@ -207,6 +207,124 @@ def run_interp(out_json):
     json.dump(cases, open(out_json, "w"))
 
 
+def run_pmc(out_json):
+    """The HBM-bound kernels at the sizes the bench line quotes (default kernels only), for the counter passes of
+    tools/pmc_hbm_kernels.sh: sampler forward / backward / double backward at 85 k, 256 k, 2^20 and 2^22 surface-coherent points,
+    marching cubes 257^3 and the loop's coarse pyramid, the 2x upsampler 129^3 -> 257^3, the 3x3 inverse at 2^20."""
+    import ctypes as C
+    import torch
+    from recmv import FastMinv, GridSamplerMine, _lib as L, interp2x_boundary3d
+    from microbench import body_like_volume
+    dev = "cuda:0"
+    cases = []
+    sep = torch.zeros(257, device=dev)
+
+    def case(name, nbytes, fn):
+        torch.sort(sep)
+        fn()
+        torch.cuda.synchronize()
+        torch.sort(sep)
+        for _ in range(REPS):
+            fn()
+        torch.cuda.synchronize()
+        cases.append({"name": name, "alg_bytes": int(nbytes)})
+
+    Cc, D, H, W = 24, 65, 225, 129
+    vol = torch.softmax(2 * torch.randn(1, Cc, D, H, W, device=dev), dim=1).contiguous(memory_format=torch.channels_last_3d)
+    for P in (85000, 256000, 1 << 20, 1 << 22):
+        n = int(round(P ** 0.5))
+        u, v = torch.meshgrid(torch.linspace(-0.9, 0.9, n, device=dev), torch.linspace(-0.9, 0.9, n, device=dev), indexing="ij")
+        surf = torch.stack([u, v, 0.3 * torch.sin(3 * u) * torch.cos(2 * v)], -1).view(1, 1, 1, -1, 3).contiguous()
+        Pc = surf.shape[3]
+        go = torch.randn(1, Cc, 1, 1, Pc, device=dev)
+        gg = torch.randn(1, 1, 1, Pc, 3, device=dev)
+        case(f"sampler fwd, surface-coherent P={Pc} (coords + output bytes)", Pc * (12 + 4 * Cc),
+             lambda: GridSamplerMine.forward(vol, surf, 0, 1))
+        case(f"sampler bwd (grid only), surface-coherent P={Pc}", Pc * (12 + 4 * Cc + 12),
+             lambda: GridSamplerMine.backward(vol, surf, go, 0, 1, need_grad_input=False))
+        case(f"sampler dbwd, surface-coherent P={Pc}", Pc * (12 + 12 + 4 * Cc + 12 + 4 * Cc),
+             lambda: GridSamplerMine.dbackward(None, gg, vol, surf, go, 0, 1, need_grad_input=False))
+    lib = L.lib()
+    for shape in ((257, 257, 257), (225, 321, 129)):
+        nx, ny, nz = shape
+        torch.sort(sep)
+        if nx == ny == nz:
+            vol3 = body_like_volume(nx)
+        else:
+            ax = [torch.linspace(-1, 1, k, device=dev) for k in shape]
+            X, Y, Z = torch.meshgrid(*ax, indexing="ij")
+            vol3 = (torch.sqrt(X * X + (0.8 * Y) ** 2 + Z * Z) - 0.6 + 0.03 * torch.sin(9 * X) * torch.cos(7 * Z)).contiguous()
+        ws = torch.empty(int(lib.recmv_mc_workspace_bytes(nx, ny, nz)), dtype=torch.uint8, device=dev)
+        cnt = (C.c_int32 * 3)(0, 0, 0)
+        L.check(lib.recmv_mc_count(L.ptr(vol3), nx, ny, nz, 0.0, L.ptr(ws), ws.numel(), C.cast(cnt, C.c_void_p), L.stream_ptr(vol3.device)), "mc")
+        V, F = int(cnt[0]), int(cnt[1])
+        vb = torch.empty(V, 3, device=dev)
+        fb = torch.empty(F, 3, dtype=torch.int64, device=dev)
+        cdev = torch.empty(3, dtype=torch.int32, device=dev)
+        case(f"mc_run {nx}x{ny}x{nz} (V={V}, F={F}): volume + vertices + faces", 4 * nx * ny * nz + 12 * V + 24 * F,
+             lambda: L.check(lib.recmv_mc_run(L.ptr(vol3), nx, ny, nz, 0.0, 2. / nx, 2. / ny, 2. / nz, -1.0, -1.0, -1.0, L.ptr(ws), ws.numel(),
+                                              L.ptr(vb), V, L.ptr(fb), F, L.ptr(cdev), L.stream_ptr(vol3.device)), "mc_run"))
+    x = torch.randn(1, 1, 129, 129, 129, device=dev)
+    case("interp2x fwd 129^3 -> 257^3", 4 * 129 ** 3 + 5 * 257 ** 3, lambda: interp2x_boundary3d.forward(x, 0.0))
+    ms = torch.randn(1 << 20, 3, 3, device=dev)
+    case("inv3x3 fwd n=1048576", 73 * (1 << 20), lambda: FastMinv.Fast3x3Minv(ms))
+    json.dump(cases, open(out_json, "w"))
+
+
+def report_pmc(cases_json, *prof_dirs):
+    """Counter passes (one directory per `rocprofv3 --pmc` run over `run_pmc`) -> per case and kernel: HBM-side bytes per launch
+    (FETCH_SIZE x 2 per MI355X_MICROARCH.md's gfx950 correction for wide reads — an UPPER bound for narrow gathers —, WRITE_SIZE as
+    reported; both in KiB units x 1024), L2 hit rate, and traffic / algorithmic bytes."""
+    import csv
+    cases = json.load(open(cases_json))
+    per_case = [dict() for _ in cases]
+    for d in prof_dirs:
+        rows = []
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            with open(f, newline="") as fh:
+                rows += list(csv.DictReader(fh))
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        body, ci = None, 0
+        last_id = None
+        seq = []                                 # (dispatch id, kernel, {counter: value}) in dispatch order
+        for r in rows:
+            did = int(r["Dispatch_Id"])
+            if did != last_id:
+                seq.append((r["Kernel_Name"], {}))
+                last_id = did
+            seq[-1][1][r["Counter_Name"]] = seq[-1][1].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        for name, ctr in seq + [("sort (sentinel)", {})]:
+            if "recmv::" not in name and "sort" in name.lower():
+                if body and max(len(v) for v in body.values()) >= REPS and ci < len(cases):
+                    for k, lst in body.items():
+                        tgt = per_case[ci].setdefault(k, {})
+                        for c in lst[0]:
+                            tgt[c] = sum(x[c] for x in lst) / len(lst)
+                        tgt["launches_per_call"] = max(len(lst) // REPS, 1)
+                    ci += 1
+                body = {}
+            elif body is not None and "recmv::" in name:
+                body.setdefault(name.split("recmv::(anonymous namespace)::")[-1].split("(")[0], []).append(ctr)
+        if ci != len(cases):
+            print("# WARNING: %s matched %d of %d cases" % (d, ci, len(cases)))
+    print("# rocprofv3 --pmc passes over tools/kernel_only.py run_pmc (%d launches per case, means per launch).  fetch = FETCH_SIZE x 1024 x 2"
+          " (gfx950 wide-read correction: an upper bound for gathers), write = WRITE_SIZE x 1024; L2 hit = TCC_HIT_sum / (HIT + MISS)" % REPS)
+    for c, ks in zip(cases, per_case):
+        tot_f = tot_w = 0.0
+        parts = []
+        for k, v in ks.items():
+            f = v.get("FETCH_SIZE", float("nan")) * 1024 * 2 * v["launches_per_call"]
+            w = v.get("WRITE_SIZE", float("nan")) * 1024 * v["launches_per_call"]
+            hit = v.get("TCC_HIT_sum")
+            miss = v.get("TCC_MISS_sum")
+            tot_f += f
+            tot_w += w
+            parts.append("%s: fetch %.2f MB write %.2f MB%s" % (k, f / 1e6, w / 1e6, "" if hit is None or miss is None or hit + miss == 0
+                                                                  else " L2 hit %.3f" % (hit / (hit + miss))))
+        print("%-74s alg %8.2f MB  fetch %8.2f MB  write %8.2f MB  traffic/alg %.2f   [%s]" % (
+            c["name"], c["alg_bytes"] / 1e6, tot_f / 1e6, tot_w / 1e6, (tot_f + tot_w) / c["alg_bytes"], "; ".join(parts)))
+
+
 def report(prof_dir, cases_json):
     cases = json.load(open(cases_json))
     db = glob.glob(prof_dir + "/**/*.db", recursive=True)[0]
@@ -251,5 +369,9 @@ if __name__ == "__main__":
         run_mc(sys.argv[2])
     elif sys.argv[1] == "run_interp":
         run_interp(sys.argv[2])
+    elif sys.argv[1] == "run_pmc":
+        run_pmc(sys.argv[2])
+    elif sys.argv[1] == "report_pmc":
+        report_pmc(sys.argv[2], *sys.argv[3:])
     else:
         report(sys.argv[2], sys.argv[3])

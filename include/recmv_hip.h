@@ -321,8 +321,12 @@ int recmv_mlp_vjp_input(const recmv_mlp* m, const float* x, int64_t P, int n_out
  *                              (recmv_mlp_rows_workspace_bytes) for the reverse pass.
  *   recmv_mlp_rows_vjp_input : as recmv_mlp_vjp_input, after recmv_mlp_rows_forward(keep = 1) on the same workspace.
  * Same arithmetic as the per-layer kernels (exact f32 MFMA products, f32 accumulation) in another summation order: results agree
- * to rounding.  Rows are independent of the tile they sit in. */
+ * to rounding.  Rows are independent of the tile they sit in.
+ *   recmv_set_mlp_rows_tile  : rows per workgroup of the two passes — 1: 16 rows (one round of workgroups up to 4 096 rows: lowest
+ *                              latency), 2: 32 rows (every weight byte from L2 feeds twice the FLOP, half the CUs per pass),
+ *                              0 (default): 16 up to 4 096 rows, 32 above.  Process-global, like recmv_set_gemm_mode. */
 int recmv_mlp_rows_supported(const recmv_mlp* m);
+int recmv_set_mlp_rows_tile(int row_tiles);
 int64_t recmv_mlp_pack_bytes(const recmv_mlp* m);
 int recmv_mlp_pack(const recmv_mlp* m, void* packed, int64_t packed_bytes, void* stream);
 int64_t recmv_mlp_rows_workspace_bytes(const recmv_mlp* m, int64_t P);

@@ -28,7 +28,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kRows = 16;              // rays per workgroup
 constexpr int kThreads = 256;          // 4 waves: one quarter of a layer's output columns each
 constexpr int kLD = 520;               // LDS row stride in floats (= 8 mod 64, >= 512 + 8)
 constexpr int kMaxWidth = 512;
@@ -73,121 +72,147 @@ __device__ __forceinline__ float act_fwd(float z, int act, float p, float inv_p)
 __device__ __forceinline__ float act_grad(float y, int act, float p) {   // act'(z) through y = act(z) (mlp_chain.hip)
   switch (act) {
     case RECMV_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-    case RECMV_ACT_SOFTPLUS: return -expm1f(-p * y);
+    case RECMV_ACT_SOFTPLUS: {               // sigmoid(beta z) = 1 - exp(-beta y): dact_y of gemm_f32.hip (series below 1/64)
+      const float t = p * y;
+      const float series = t * (1.f - t * (0.5f - t * (0.16666667f - 0.041666668f * t)));
+      return t < 0.015625f ? series : 1.f - __expf(-t);
+    }
     case RECMV_ACT_TANH: return 1.f - y * y;
     default: return 1.f;
   }
 }
 
-// acc[t] += A[16 x 16*KC] . B_t^T for the wave's TPW column tiles.  A: LDS, row stride kLD, lane (r = l & 15, j = l >> 4)
-// reads the four inputs 16c + 4j .. + 3 of row r with one ds_read_b128; the packed B chunk holds the same four inputs of output
-// column 16t + r for that lane.  The next chunk's fragments are requested before the current chunk's 4 * TPW MFMAs are issued.
-template <int TPW>
+// acc[rt][t] += A_rt[16 x 16*KC] . B_t^T for the wave's TPW column tiles and the workgroup's RT row tiles.  A: LDS, row stride
+// kLD, lane (r = l & 15, j = l >> 4) reads the four inputs 16c + 4j .. + 3 of row 16 rt + r with one ds_read_b128; the packed B
+// chunk holds the same four inputs of output column 16t + r for that lane, and feeds RT MFMAs: with RT = 2 a byte of weights from
+// L2 does 16 FLOP instead of 8.
+template <int TPW, int RT>
+struct Frag {
+  f32x4 b[TPW];
+  f32x4 a[RT];
+};
+
+template <int TPW, int RT>
 __device__ __forceinline__ void chunk_load(const f32x4* __restrict__ wp, int64_t tile_stride, int c, const float* __restrict__ arow,
-                                           f32x4 (&b)[TPW], f32x4& a) {
+                                           Frag<TPW, RT>& f) {
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) b[t] = wp[t * tile_stride + (int64_t)c * 64];
-  a = *reinterpret_cast<const f32x4*>(arow + 16 * c);
+  for (int t = 0; t < TPW; ++t) f.b[t] = wp[t * tile_stride + (int64_t)c * 64];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) f.a[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 16 * kLD + 16 * c);
 }
 
-template <int TPW>
-__device__ __forceinline__ void chunk_mma(const f32x4 (&b)[TPW], const f32x4& a, f32x4 (&acc)[TPW]) {
+template <int TPW, int RT>
+__device__ __forceinline__ void chunk_mma(const Frag<TPW, RT>& f, bool live, f32x4 (&acc)[RT][TPW]) {
+  f32x4 a[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) a[rt] = live ? f.a[rt] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
+    for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][s], f.b[t][s], acc[rt][t], 0, 0, 0);
+    }
   }
 }
 
-// Two register sets, the loop unrolled by two: the loads of chunk c + 1 are ISSUED before the MFMAs of chunk c (the scheduling
-// barriers keep the compiler from sinking them behind the matrix instructions), and a set is only waited for one whole chunk
-// (4 * TPW MFMAs) later.  The tail re-requests the last chunk instead of branching around loads.
-template <int TPW>
+// Two register sets, the loop unrolled by two: the fragments of chunk c + 1 are REQUESTED before the MFMAs of chunk c are issued
+// (the scheduling barriers keep the compiler from sinking the requests behind the matrix instructions), so a set has a whole chunk
+// (4 * TPW * RT MFMAs, >= 1 000 cycles at TPW = 8) to arrive.  No exit between a request and its use (a load whose only use sits
+// behind a branch gets sunk behind that branch): the trip count is rounded up to a pair, a chunk past the end re-requests the last
+// one and multiplies it by a zero A fragment.  (A ring of four sets measured the same, profiles/r04_mlp_rows_bench_v2.txt.)
+template <int TPW, int RT>
 __device__ __forceinline__ void tile_mma(const float* __restrict__ A, int KC, const float* __restrict__ Wp, int KCs, int wave,
-                                         int lane, f32x4 (&acc)[TPW]) {
+                                         int lane, f32x4 (&acc)[RT][TPW]) {
   const float* arow = A + (lane & 15) * kLD + 4 * (lane >> 4);
   const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((int64_t)wave * TPW * KCs) * 64 + lane;
   const int64_t ts = (int64_t)KCs * 64;
   const int last = KC - 1;
-  f32x4 b0[TPW], b1[TPW];
-  f32x4 a0, a1;
-  chunk_load<TPW>(wp, ts, 0, arow, b0, a0);
-  // (no exit between a request and its use: a load whose only use sits behind a branch gets sunk behind that branch)
-  for (int c = 0; c + 1 < KC; c += 2) {
-    chunk_load<TPW>(wp, ts, c + 1, arow, b1, a1);
+  Frag<TPW, RT> f0, f1;
+  chunk_load<TPW, RT>(wp, ts, 0, arow, f0);
+  for (int c = 0; c < KC; c += 2) {
+    chunk_load<TPW, RT>(wp, ts, c + 1 < last ? c + 1 : last, arow, f1);
     __builtin_amdgcn_sched_barrier(0);
-    chunk_mma<TPW>(b0, a0, acc);
+    chunk_mma<TPW, RT>(f0, true, acc);
     __builtin_amdgcn_sched_barrier(0);
-    chunk_load<TPW>(wp, ts, c + 2 < last ? c + 2 : last, arow, b0, a0);
+    chunk_load<TPW, RT>(wp, ts, c + 2 < last ? c + 2 : last, arow, f0);
     __builtin_amdgcn_sched_barrier(0);
-    chunk_mma<TPW>(b1, a1, acc);
+    chunk_mma<TPW, RT>(f1, c + 1 < KC, acc);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (KC & 1) chunk_mma<TPW>(b0, a0, acc);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
 // Epilogue of a hidden layer: bias + activation (+ 1/sqrt2 in front of the skip concatenation) from the accumulators into the
-// other LDS buffer; columns >= N (tile padding) are written as zeros.
-template <int TPW>
+// other LDS buffer; columns >= N (tile padding) are written as zeros unless the encoding follows there.
+template <int TPW, int RT>
 __device__ __forceinline__ void hidden_layer(const RowsLayer& L, const float* __restrict__ in, float* __restrict__ outb, int wave,
                                              int lane, int act, float p, float inv_p, float scale, bool zero_pad) {
-  f32x4 acc[TPW];
+  f32x4 acc[RT][TPW];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  tile_mma<TPW>(in, L.KC, L.Wp, L.KC, wave, lane, acc);
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  tile_mma<TPW, RT>(in, L.KC, L.Wp, L.KC, wave, lane, acc);
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int n = (wave * TPW + t) * 16 + (lane & 15);
     const bool ok = n < L.N;
     const float b = (ok && L.bias) ? L.bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 4 * (lane >> 4) + i;
-      const float v = act_fwd(acc[t][i] + b, act, p, inv_p) * scale;
-      // (behind the skip concatenation the columns past N belong to the encoding, written by the caller)
-      if (ok) outb[r * kLD + n] = v;
-      else if (zero_pad && n < kMaxWidth) outb[r * kLD + n] = 0.f;
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 16 * rt + 4 * (lane >> 4) + i;
+        const float v = act_fwd(acc[rt][t][i] + b, act, p, inv_p) * scale;
+        // (behind the skip concatenation the columns past N belong to the encoding, written by the caller)
+        if (ok) outb[r * kLD + n] = v;
+        else if (zero_pad && n < kMaxWidth) outb[r * kLD + n] = 0.f;
+      }
     }
   }
 }
 
+template <int RT>
 __device__ __forceinline__ void run_hidden(const RowsLayer& L, const float* in, float* outb, int wave, int lane, int act, float p,
                                            float inv_p, float scale, bool zero_pad) {
   switch (L.TPW) {
-    case 1: hidden_layer<1>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
-    case 2: hidden_layer<2>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
-    case 3: hidden_layer<3>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
-    case 4: hidden_layer<4>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
-    default: hidden_layer<8>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    case 1: hidden_layer<1, RT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    case 2: hidden_layer<2, RT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    case 3: hidden_layer<3, RT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    case 4: hidden_layer<4, RT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    default: hidden_layer<8, RT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
   }
 }
 
 // x [P,3] -> out [P,n_out] (n_out <= 16): positional encoding (+ per-frame code) -> hidden layers -> last layer, one launch.
-// keep: every hidden activation tile is also written to acts[l] ([P16, ld_act] per layer) for mlp_rows_vjp_kernel.
+// A workgroup owns kR = 16 RT rows.  keep: every hidden activation tile is also written to acts[l] ([P32, ld_act] per layer) for
+// mlp_rows_vjp_kernel.
+template <int RT>
 __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, const float* __restrict__ x,
                                                                 const float* __restrict__ cond, int64_t ld_cond,
                                                                 const int64_t* __restrict__ cond_index, int64_t P, int n_out,
                                                                 float* __restrict__ out, int64_t ldo, float* __restrict__ acts,
                                                                 int64_t ld_act, int64_t act_stride, int keep) {
+  constexpr int kR = 16 * RT;
   extern __shared__ float smem[];
   float* buf0 = smem;
-  float* buf1 = smem + kRows * kLD;
-  float* pe = smem + 2 * kRows * kLD;            // [16][kPeLD] weighted gamma(x), unscaled
-  float* xs = pe + kRows * kPeLD;                // [16][4]
-  float* red = xs + kRows * 4;                   // [4 waves][64 lanes][4] partial sums of the last layer
+  float* buf1 = smem + kR * kLD;
+  float* pe = smem + 2 * kR * kLD;               // [kR][kPeLD] weighted gamma(x), unscaled
+  float* xs = pe + kR * kPeLD;                   // [kR][4]
+  float* red = xs + kR * 4;                      // [4 waves][64 lanes][4] partial sums of the last layer
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t row0 = (int64_t)blockIdx.x * kRows;
+  const int64_t row0 = (int64_t)blockIdx.x * kR;
   const int L = a.multires, nf = 1 + 2 * L, d_pe = 3 * nf;
   const int n = a.n_layers;
 
-  if (tid < kRows * 3) {
+  if (tid < kR * 3) {
     const int r = tid / 3, c = tid - 3 * r;
     xs[r * 4 + c] = (row0 + r < P) ? x[(row0 + r) * 3 + c] : 0.f;
   }
   __syncthreads();
   // ---- input tile: [gamma(x) | code[frame] | zeros up to the chunk boundary]
-  for (int e = tid; e < kRows * nf; e += kThreads) {
+  for (int e = tid; e < kR * nf; e += kThreads) {
     const int r = e / nf, f = e - r * nf;
     const float x0 = xs[r * 4], x1 = xs[r * 4 + 1], x2 = xs[r * 4 + 2];
     float v0, v1, v2;
@@ -209,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
   }
   {
     const int fill = a.fwd[0].KC * 16 - d_pe;     // code columns + zero padding
-    for (int e = tid; e < kRows * fill; e += kThreads) {
+    for (int e = tid; e < kR * fill; e += kThreads) {
       const int r = e / fill, c = e - r * fill;
       float v = 0.f;
       if (c < a.cond_dim && row0 + r < P) v = cond[(cond_index ? cond_index[row0 + r] : 0) * ld_cond + c];
@@ -222,10 +247,10 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
   const float p = a.act_param, inv_p = p != 0.f ? 1.f / p : 0.f;
   for (int l = 0; l + 1 < n; ++l) {
     const bool skip_next = (l + 1 == a.skip_layer);
-    run_hidden(a.fwd[l], in, ob, wave, lane, a.hidden_act, p, inv_p, skip_next ? kInvSqrt2 : 1.f, !skip_next);
+    run_hidden<RT>(a.fwd[l], in, ob, wave, lane, a.hidden_act, p, inv_p, skip_next ? kInvSqrt2 : 1.f, !skip_next);
     const int width = a.dims[l + 1];              // = N (+ d_pe behind the skip)
     if (skip_next) {
-      for (int e = tid; e < kRows * d_pe; e += kThreads) {
+      for (int e = tid; e < kR * d_pe; e += kThreads) {
         const int r = e / d_pe, c = e - r * d_pe;
         ob[r * kLD + a.fwd[l].N + c] = pe[r * kPeLD + c] * kInvSqrt2;
       }
@@ -234,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
       const int padded = a.fwd[l + 1].KC * 16;     // the next layer reads whole chunks: zero what the tiles did not cover
       const int covered = skip_next ? width : ((a.fwd[l].N + 15) / 16) * 16;
       const int extra = padded - covered;
-      for (int e = tid; e < kRows * extra; e += kThreads) {
+      for (int e = tid; e < kR * extra; e += kThreads) {
         const int r = e / extra, c = e - r * extra;
         ob[r * kLD + covered + c] = 0.f;
       }
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
     if (keep) {
       float* dst = acts + (int64_t)l * act_stride + row0 * ld_act;
       const int w4 = (width + 3) / 4;
-      for (int e = tid; e < kRows * w4; e += kThreads) {
+      for (int e = tid; e < kR * w4; e += kThreads) {
         const int r = e / w4, c = (e - r * w4) * 4;
         *reinterpret_cast<float4*>(dst + (int64_t)r * ld_act + c) = *reinterpret_cast<const float4*>(ob + r * kLD + c);
       }
@@ -251,26 +276,28 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
     float* t = in; in = ob; ob = t;
   }
   // ---- last layer, n_out <= 16 outputs: ONE column tile, its chunks dealt to the four waves, partial sums through LDS
-  {
-    const RowsLayer& Ll = a.fwd[n - 1];
+  const RowsLayer& Ll = a.fwd[n - 1];
+  const int KC = Ll.KC, per = (KC + 3) / 4;
+  const int c0 = wave * per, c1 = (c0 + per < KC) ? c0 + per : KC;
+  const f32x4* wpl = reinterpret_cast<const f32x4*>(Ll.Wp) + lane;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int KC = Ll.KC, per = (KC + 3) / 4;
-    const int c0 = wave * per, c1 = (c0 + per < KC) ? c0 + per : KC;
-    const float* arow = in + (lane & 15) * kLD + 4 * (lane >> 4);
-    const f32x4* wp = reinterpret_cast<const f32x4*>(Ll.Wp) + lane;
+    const float* arow = in + (16 * rt + (lane & 15)) * kLD + 4 * (lane >> 4);
     for (int c = c0; c < c1; ++c) {
-      const f32x4 bv = wp[(int64_t)c * 64];
+      const f32x4 bv = wpl[(int64_t)c * 64];
       const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * c);
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
     }
+    if (rt) __syncthreads();                       // (the partial sums of the previous row tile have been read)
     *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = acc;
     __syncthreads();
     if (wave == 0) {
       const int nn = lane & 15;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = 4 * (lane >> 4) + i;
+        const int r = 16 * rt + 4 * (lane >> 4) + i;
         float v = red[lane * 4 + i] + red[(64 + lane) * 4 + i];
         v += red[(128 + lane) * 4 + i];
         v += red[(192 + lane) * 4 + i];
@@ -288,71 +315,82 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
 // g <- dZ . W for the wave's column tiles, then the NEXT (earlier) layer's activation gradient applied in the epilogue:
 //   dZ_prev[r][c] = g[r][c] * act'(y_scale * y_prev[r][c]) * out_scale   for c < n_act (columns of the activation),
 //   park[r][c - n_act] = g[r][c] / sqrt2                                  for n_act <= c < n_act + d_pe (skip connection),
-// written to the other LDS buffer (zeros in the tile padding).  y_prev comes from the forward pass's workspace.
-template <int TPW>
+// written to the other LDS buffer (zeros in the tile padding).  y_prev comes from the forward pass's workspace; it is requested
+// before the product so that it travels under the MFMAs.
+template <int TPW, int RT>
 __device__ __forceinline__ void reverse_layer(const RowsLayer& L, const float* __restrict__ in, float* __restrict__ outb,
                                               float* __restrict__ park, const float* __restrict__ yprev, int64_t ld_act, int n_act,
                                               int d_park, int wave, int lane, int act, float p, float y_scale, float out_scale) {
-  f32x4 acc[TPW];
-  float yv[TPW][4];
+  f32x4 acc[RT][TPW];
+  float yv[RT][TPW][4];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int c = (wave * TPW + t) * 16 + (lane & 15);
+  for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) yv[t][i] = (yprev && c < n_act) ? yprev[(int64_t)(4 * (lane >> 4) + i) * ld_act + c] : 0.f;
+    for (int t = 0; t < TPW; ++t) {
+      acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int c = (wave * TPW + t) * 16 + (lane & 15);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        yv[rt][t][i] = (yprev && c < n_act) ? yprev[(int64_t)(16 * rt + 4 * (lane >> 4) + i) * ld_act + c] : 0.f;
+    }
   }
-  tile_mma<TPW>(in, L.KC, L.Wp, L.KC, wave, lane, acc);
+  tile_mma<TPW, RT>(in, L.KC, L.Wp, L.KC, wave, lane, acc);
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int c = (wave * TPW + t) * 16 + (lane & 15);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 4 * (lane >> 4) + i;
-      const float g = acc[t][i];
-      if (c < n_act) {
-        outb[r * kLD + c] = yprev ? g * act_grad(yv[t][i] * y_scale, act, p) * out_scale : g;
-      } else {
-        if (c < n_act + d_park) park[r * kPeLD + (c - n_act)] = g * kInvSqrt2;
-        if (c < kMaxWidth) outb[r * kLD + c] = 0.f;
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 16 * rt + 4 * (lane >> 4) + i;
+        const float g = acc[rt][t][i];
+        if (c < n_act) {
+          outb[r * kLD + c] = yprev ? g * act_grad(yv[rt][t][i] * y_scale, act, p) * out_scale : g;
+        } else {
+          if (c < n_act + d_park) park[r * kPeLD + (c - n_act)] = g * kInvSqrt2;
+          if (c < kMaxWidth) outb[r * kLD + c] = 0.f;
+        }
       }
     }
   }
 }
 
+template <int RT>
 __device__ __forceinline__ void run_reverse(const RowsLayer& L, const float* in, float* outb, float* park, const float* yprev,
                                             int64_t ld_act, int n_act, int d_park, int wave, int lane, int act, float p,
                                             float y_scale, float out_scale) {
   switch (L.TPW) {
-    case 1: reverse_layer<1>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
-    case 2: reverse_layer<2>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
-    case 3: reverse_layer<3>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
-    case 4: reverse_layer<4>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
-    default: reverse_layer<8>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    case 1: reverse_layer<1, RT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    case 2: reverse_layer<2, RT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    case 3: reverse_layer<3, RT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    case 4: reverse_layer<4, RT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    default: reverse_layer<8, RT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
   }
 }
 
 // gx [P,3] = J(x)^T g_out through the layers in reverse, from the activations mlp_rows_fwd_kernel(keep) left in `acts`.
 // g_out NULL: ones on a scalar output (the cotangent of every ray is row 0 of the last weight).
+template <int RT>
 __global__ __launch_bounds__(kThreads) void mlp_rows_vjp_kernel(RowsArgs a, const float* __restrict__ x, int64_t P, int n_out,
                                                                 const float* __restrict__ g_out, int64_t ldg,
                                                                 float* __restrict__ gx, const float* __restrict__ acts,
                                                                 int64_t ld_act, int64_t act_stride) {
+  constexpr int kR = 16 * RT;
   extern __shared__ float smem[];
   float* buf0 = smem;
-  float* buf1 = smem + kRows * kLD;
-  float* park = smem + 2 * kRows * kLD;          // [16][kPeLD] gradient of the encoding that entered through the skip
-  float* xs = park + kRows * kPeLD;              // [16][4]
+  float* buf1 = smem + kR * kLD;
+  float* park = smem + 2 * kR * kLD;             // [kR][kPeLD] gradient of the encoding that entered through the skip
+  float* xs = park + kR * kPeLD;                 // [kR][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t row0 = (int64_t)blockIdx.x * kRows;
+  const int64_t row0 = (int64_t)blockIdx.x * kR;
   const int L = a.multires, d_pe = 3 * (1 + 2 * L);
   const int n = a.n_layers;
   const float p = a.act_param;
-  if (tid < kRows * 3) {
+  if (tid < kR * 3) {
     const int r = tid / 3, c = tid - 3 * r;
     xs[r * 4 + c] = (row0 + r < P) ? x[(row0 + r) * 3 + c] : 0.f;
   }
-  for (int e = tid; e < kRows * kPeLD; e += kThreads) park[e] = 0.f;
+  for (int e = tid; e < kR * kPeLD; e += kThreads) park[e] = 0.f;
   const float* yt = acts + row0 * ld_act;        // this tile's rows of every stored activation
   float* in = buf0;
   float* ob = buf1;
@@ -365,7 +403,8 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_vjp_kernel(RowsArgs a, cons
     const float* yprev = yt + (int64_t)l * act_stride;
     if (!g_out) {
       const int width = (a.dims[n - 1] + 15) / 16 * 16;
-      for (int e = tid; e < kRows * width; e += kThreads) {
+      __syncthreads();                             // (park has been cleared)
+      for (int e = tid; e < kR * width; e += kThreads) {
         const int r = e / width, c = e - r * width;
         float v = 0.f;
         if (c < a.dims[n - 1]) {
@@ -378,14 +417,14 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_vjp_kernel(RowsArgs a, cons
       __syncthreads();
     } else {
       // stage the cotangent tile (zero-padded to one chunk per 16 outputs), multiply by the last weight
-      const int kc = a.bwd[n - 1].KC;             // chunks of the packed last layer that hold outputs < n_out
-      for (int e = tid; e < kRows * kc * 16; e += kThreads) {
+      const int kc = a.bwd[n - 1].KC;             // chunks of the packed last layer
+      for (int e = tid; e < kR * kc * 16; e += kThreads) {
         const int r = e / (kc * 16), c = e - r * (kc * 16);
         ob[r * kLD + c] = (c < n_out && row0 + r < P) ? g_out[(row0 + r) * ldg + c] : 0.f;
       }
       __syncthreads();
-      run_reverse(a.bwd[n - 1], ob, in, park, yprev, ld_act, n_act, skip_here ? d_pe : 0, wave, lane, a.hidden_act, p, y_scale,
-                  o_scale);
+      run_reverse<RT>(a.bwd[n - 1], ob, in, park, yprev, ld_act, n_act, skip_here ? d_pe : 0, wave, lane, a.hidden_act, p, y_scale,
+                      o_scale);
       __syncthreads();
     }
   }
@@ -394,24 +433,15 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_vjp_kernel(RowsArgs a, cons
     const bool skip_here = (l == a.skip_layer);   // layer l's input = [act(z_{l-1}) / sqrt2 | gamma / sqrt2]
     const int n_act = a.rows[l - 1];
     const float* yprev = yt + (int64_t)(l - 1) * act_stride;
-    run_reverse(a.bwd[l], in, ob, park, yprev, ld_act, n_act, skip_here ? d_pe : 0, wave, lane, a.hidden_act, p,
-                skip_here ? kSqrt2 : 1.f, skip_here ? kInvSqrt2 : 1.f);
-    {
-      const int padded = a.bwd[l - 1].KC * 16;     // zero what the column tiles of this layer did not cover
-      const int covered = a.bwd[l].TPW * 64 < kMaxWidth ? a.bwd[l].TPW * 64 : kMaxWidth;
-      const int extra = padded - covered;
-      for (int e = tid; e < kRows * extra; e += kThreads) {
-        const int r = e / extra, c = e - r * extra;
-        ob[r * kLD + covered + c] = 0.f;
-      }
-    }
+    run_reverse<RT>(a.bwd[l], in, ob, park, yprev, ld_act, n_act, skip_here ? d_pe : 0, wave, lane, a.hidden_act, p,
+                    skip_here ? kSqrt2 : 1.f, skip_here ? kInvSqrt2 : 1.f);
     __syncthreads();
     float* t = in; in = ob; ob = t;
   }
   // ---- first layer: gradient of [gamma(x) | code]; only the encoding's columns flow to x
-  run_reverse(a.bwd[0], in, ob, park, nullptr, ld_act, d_pe, 0, wave, lane, RECMV_ACT_NONE, 0.f, 1.f, 1.f);
+  run_reverse<RT>(a.bwd[0], in, ob, park, nullptr, ld_act, d_pe, 0, wave, lane, RECMV_ACT_NONE, 0.f, 1.f, 1.f);
   __syncthreads();
-  if (tid < kRows * 3) {
+  if (tid < kR * 3) {
     const int r = tid / 3, c = tid - 3 * r;
     if (row0 + r < P) {
       const float xc = xs[r * 4 + c];
@@ -530,10 +560,19 @@ void fill_args(const recmv_mlp* m, const float* packed, RowsArgs* a) {
   for (int i = 0; i < 32; ++i) a->pe_w[i] = m->pe_weights[i];
 }
 
-constexpr size_t kFwdLds = (size_t)(2 * kRows * kLD + kRows * kPeLD + kRows * 4 + 4 * 64 * 4) * sizeof(float);
-constexpr size_t kVjpLds = (size_t)(2 * kRows * kLD + kRows * kPeLD + kRows * 4) * sizeof(float);
+inline size_t fwd_lds(int rt) { return (size_t)(2 * 16 * rt * kLD + 16 * rt * kPeLD + 16 * rt * 4 + 4 * 64 * 4) * sizeof(float); }
+inline size_t vjp_lds(int rt) { return (size_t)(2 * 16 * rt * kLD + 16 * rt * kPeLD + 16 * rt * 4) * sizeof(float); }
 
 inline int64_t pad16(int64_t v) { return (v + 15) / 16 * 16; }
+inline int64_t pad32(int64_t v) { return (v + 31) / 32 * 32; }
+
+// Row tiles per workgroup: 16 rows while one round of workgroups covers the rows (lowest latency), 32 rows past that — or whatever
+// recmv_set_mlp_rows_tile says (2 = every weight byte from L2 feeds twice the FLOP and a pass takes half the CUs).
+int g_rows_rt = 0;       // 0 = by row count
+inline int pick_rt(int64_t P) {
+  if (g_rows_rt == 1 || g_rows_rt == 2) return g_rows_rt;
+  return P <= (int64_t)16 * kNumCU ? 1 : 2;
+}
 
 struct RowsLayout {
   int64_t ld_act, act_stride, bytes;
@@ -544,7 +583,7 @@ RowsLayout rows_layout(const recmv_mlp* m, int64_t P) {
   int64_t maxw = 16;
   for (int l = 1; l < m->n_layers; ++l) maxw = m->dims[l] > maxw ? m->dims[l] : maxw;
   L.ld_act = pad16(maxw);
-  L.act_stride = pad16(P) * L.ld_act;
+  L.act_stride = pad32(P) * L.ld_act;
   L.bytes = (int64_t)(m->n_layers - 1) * L.act_stride * 4;
   return L;
 }
@@ -555,6 +594,12 @@ RowsLayout rows_layout(const recmv_mlp* m, int64_t P) {
 using namespace recmv;
 
 extern "C" int recmv_mlp_rows_supported(const recmv_mlp* m) { return rows_supported(m); }
+
+extern "C" int recmv_set_mlp_rows_tile(int row_tiles) {
+  RECMV_REQUIRE(row_tiles >= 0 && row_tiles <= 2, "set_mlp_rows_tile: 0 (by row count), 1 (16 rows) or 2 (32 rows)");
+  g_rows_rt = row_tiles;
+  return RECMV_OK;
+}
 
 extern "C" int64_t recmv_mlp_pack_bytes(const recmv_mlp* m) {
   if (!rows_supported(m)) return 0;
@@ -614,12 +659,18 @@ extern "C" int recmv_mlp_rows_forward(const recmv_mlp* m, const void* packed, co
   fill_args(m, (const float*)packed, &a);
   static bool attr_set = false;
   if (!attr_set) {
-    RECMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_rows_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)kFwdLds));
+    RECMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_rows_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)fwd_lds(1)));
+    RECMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_rows_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)fwd_lds(2)));
     attr_set = true;
   }
-  hipLaunchKernelGGL(mlp_rows_fwd_kernel, dim3((unsigned)ceil_div(P, kRows)), dim3(kThreads), kFwdLds, (hipStream_t)stream, a, x, cond,
-                     ld_cond, cond_index, P, n_out, out, ldo, (float*)workspace, L.ld_act, L.act_stride, keep);
+  if (pick_rt(P) == 1)
+    hipLaunchKernelGGL(mlp_rows_fwd_kernel<1>, dim3((unsigned)ceil_div(P, 16)), dim3(kThreads), fwd_lds(1), (hipStream_t)stream, a, x,
+                       cond, ld_cond, cond_index, P, n_out, out, ldo, (float*)workspace, L.ld_act, L.act_stride, keep);
+  else
+    hipLaunchKernelGGL(mlp_rows_fwd_kernel<2>, dim3((unsigned)ceil_div(P, 32)), dim3(kThreads), fwd_lds(2), (hipStream_t)stream, a, x,
+                       cond, ld_cond, cond_index, P, n_out, out, ldo, (float*)workspace, L.ld_act, L.act_stride, keep);
   return check_launch("mlp_rows_forward");
 }
 
@@ -642,11 +693,17 @@ extern "C" int recmv_mlp_rows_vjp_input(const recmv_mlp* m, const void* packed, 
   fill_args(m, (const float*)packed, &a);
   static bool attr_set = false;
   if (!attr_set) {
-    RECMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_rows_vjp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)kVjpLds));
+    RECMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_rows_vjp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)vjp_lds(1)));
+    RECMV_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_rows_vjp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)vjp_lds(2)));
     attr_set = true;
   }
-  hipLaunchKernelGGL(mlp_rows_vjp_kernel, dim3((unsigned)ceil_div(P, kRows)), dim3(kThreads), kVjpLds, (hipStream_t)stream, a, x, P,
-                     n_out, g_out, ldg, gx, (const float*)workspace, L.ld_act, L.act_stride);
+  if (pick_rt(P) == 1)
+    hipLaunchKernelGGL(mlp_rows_vjp_kernel<1>, dim3((unsigned)ceil_div(P, 16)), dim3(kThreads), vjp_lds(1), (hipStream_t)stream, a, x, P,
+                       n_out, g_out, ldg, gx, (const float*)workspace, L.ld_act, L.act_stride);
+  else
+    hipLaunchKernelGGL(mlp_rows_vjp_kernel<2>, dim3((unsigned)ceil_div(P, 32)), dim3(kThreads), vjp_lds(2), (hipStream_t)stream, a, x, P,
+                       n_out, g_out, ldg, gx, (const float*)workspace, L.ld_act, L.act_stride);
   return check_launch("mlp_rows_vjp_input");
 }

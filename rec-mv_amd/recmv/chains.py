@@ -14,9 +14,14 @@ import torch
 
 from . import _lib as L
 
-# Passes of at most this many rows run as ONE launch of the row-tile kernels (csrc/mlp_rows.hip); above it a 16-row tile re-reads
-# the weights too often and the per-layer kernels win.  RECMV_MLP_ROWS=0 keeps the per-layer chains everywhere (the A/B switch).
-MLP_ROWS_MAX = int(os.environ.get("RECMV_MLP_ROWS_MAX", "6144"))
+# Passes of MLP_ROWS_MIN..MLP_ROWS_MAX rows run as ONE launch of the row-tile kernels (csrc/mlp_rows.hip): a workgroup owns 16 rows,
+# so up to 4 096 rows are one round of workgroups on the 256 CUs whatever the row count — below the minimum the per-layer kernels
+# (whose time shrinks with the rows) are faster, above the maximum a second round of workgroups starts and they win again
+# (tools/mlp_rows_bench.py, profiles/r04_mlp_rows_bench_*.txt).  RECMV_MLP_ROWS=0 keeps the per-layer chains everywhere (A/B switch).
+MLP_ROWS_MIN = int(os.environ.get("RECMV_MLP_ROWS_MIN", "2304"))
+MLP_ROWS_MAX = int(os.environ.get("RECMV_MLP_ROWS_MAX", "4096"))
+if os.environ.get("RECMV_MLP_ROWS_RT"):        # rows per workgroup / 16 (recmv_set_mlp_rows_tile): 1, 2, or 0 = by row count
+    L.check(L.lib().recmv_set_mlp_rows_tile(int(os.environ["RECMV_MLP_ROWS_RT"])), "set_mlp_rows_tile")
 
 
 def _rows_enabled():
@@ -76,7 +81,7 @@ class MlpChain:
         self._rows_last = {}          # slot -> did the last forward(keep=True) take the row-tile path?
 
     def _use_rows(self, P, n_out, split_row):
-        return (self._rows_ok and 0 < P <= MLP_ROWS_MAX and n_out <= 16 and (split_row is None or not self.has_second)
+        return (self._rows_ok and max(MLP_ROWS_MIN, 1) <= P <= MLP_ROWS_MAX and n_out <= 16 and (split_row is None or not self.has_second)
                 and _rows_enabled())
 
     def _pack(self, dev):

@@ -211,8 +211,8 @@ def test_root_finder(nets):
     assert err.max().item() < 2e-4, err.max().item()
 
 
-@pytest.mark.parametrize("P", [1, 15, 16, 1000, 3072, 5003])
-def test_row_tile_mlp_equals_the_per_layer_chain(nets, P, monkeypatch):
+@pytest.mark.parametrize("P,row_tiles", [(1, 1), (15, 2), (16, 1), (33, 2), (1000, 0), (3072, 1), (3072, 2), (5003, 0)])
+def test_row_tile_mlp_equals_the_per_layer_chain(nets, P, row_tiles, monkeypatch):
     """csrc/mlp_rows.hip — ONE launch per pass, the activations of a 16-ray tile resident in LDS across all layers — against the
     per-layer launch chain of csrc/mlp_chain.hip on the same descriptor: the SDF net's value and input gradient (softplus(100),
     skip connection at layer 4, annealed encoding; model/network.py:98-133) and the deformer's offset MLP with its VJP (ReLU,
@@ -220,6 +220,10 @@ def test_row_tile_mlp_equals_the_per_layer_chain(nets, P, monkeypatch):
     order: agreement to f32 rounding (1e-5 of the largest entry; softplus(100) amplifies pre-activation rounding 100x in the
     gradient).  Row counts around the 16-row tile and the loop's sizes; a ray's result does not depend on its tile."""
     import recmv.chains as chains
+    monkeypatch.setattr(chains, "MLP_ROWS_MIN", 1)
+    monkeypatch.setattr(chains, "MLP_ROWS_MAX", 1 << 20)
+    from recmv import _lib as L
+    L.check(L.lib().recmv_set_mlp_rows_tile(row_tiles), "rows tile")      # 16- and 32-row workgroups; 0 = by row count
     sdf, tr = nets["sdf"], nets["tr"]
     gen = torch.Generator().manual_seed(P)
     x = (torch.rand(P, 3, generator=gen) - 0.5).mul(1.4).to(DEV)
@@ -253,6 +257,7 @@ def test_row_tile_mlp_equals_the_per_layer_chain(nets, P, monkeypatch):
         f2 = ch.forward(xs, n_out=1, keep=True, slot="t")
         g2 = ch.vjp_input(xs, None, slot="t")
         assert torch.equal(f2[5:], a[0][:-5]) and torch.equal(g2[5:], a[1][:-5])
+    L.check(L.lib().recmv_set_mlp_rows_tile(0), "rows tile")
 
 
 def test_root_finder_compaction_changes_no_ray(nets):

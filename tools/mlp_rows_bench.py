@@ -29,11 +29,14 @@ def main():
         frame = torch.randint(0, 3, (P,), device=DEV)
         g3 = torch.randn(P, 3, device=DEV)
         row = ["P=%5d" % P]
-        for rows in (1, 0):
-            os.environ["RECMV_MLP_ROWS"] = str(rows)
+        for rows in (1, 2, 0):
+            os.environ["RECMV_MLP_ROWS"] = str(min(rows, 1))
+            if rows:
+                from recmv import _lib as L
+                L.lib().recmv_set_mlp_rows_tile(rows)
             os.environ["RECMV_MLP_ROWS_MAX"] = "100000"
             import recmv.chains as chains
-            chains.MLP_ROWS_MAX = 100000
+            chains.MLP_ROWS_MAX, chains.MLP_ROWS_MIN = 100000, 1
             ch = sdf.chain(sdf._pe_weights(RATIO), need_t=True)
             ct = tr.prepare_explicit(conds, ratio=RATIO)
 
@@ -47,7 +50,7 @@ def main():
 
             for name, fn, fl in (("sdf", sdf_pair, flop_sdf), ("offset", tr_pair, flop_tr)):
                 sec, how = bench._graph_time(fn)
-                row.append("%s[%s] %7.1f us %5.1f TF/s" % (name, "rows " if rows else "chain", sec * 1e6, 2 * fl * P / sec / 1e12))
+                row.append("%s[%s] %7.1f us %5.1f TF/s" % (name, ("rows%d" % (16 * rows)) if rows else "chain", sec * 1e6, 2 * fl * P / sec / 1e12))
         print("   ".join(row), flush=True)
 
 

@@ -1,0 +1,87 @@
+"""Interleaved A/B of runtime switches on ONE evolving scene: after the settle phase the configurations take turns in blocks of a
+few iterations (the scene drifts slowly, neighbouring blocks see nearly the same meshes and ray counts), so that the comparison does
+not depend on where a chaotic settle phase lands for each build ("the scene of the line moves with the code").
+
+    python tools/ab_interleaved.py rows          # the row-tile MLP passes: off / 16-row / 32-row workgroups
+"""
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(REPO / "rec-mv_amd"), str(REPO)]
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def rows_cfg(on, lo=2304, hi=4096, rt=0):
+    def apply():
+        import recmv.chains as chains
+        from recmv import _lib as L
+        os.environ["RECMV_MLP_ROWS"] = "1" if on else "0"
+        chains.MLP_ROWS_MIN, chains.MLP_ROWS_MAX = lo, hi
+        L.check(L.lib().recmv_set_mlp_rows_tile(rt), "rows tile")
+    return apply
+
+
+CONFIGS = {
+    "rows": [("per-layer chains", rows_cfg(False)), ("rows 16, 2304..4096", rows_cfg(True, 2304, 4096, 1)),
+             ("rows 16, 1024..4096", rows_cfg(True, 1024, 4096, 1)), ("rows 32, 1500..8192", rows_cfg(True, 1500, 8192, 2)),
+             ("rows 16 <= 4096 / 32 <= 8192, from 2304", rows_cfg(True, 2304, 8192, 0))],
+}
+
+
+def main():
+    which = sys.argv[1]
+    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    block = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    from recmv.hocon import ConfigFactory
+    from recmv.loop import HotLoop
+    torch.set_num_threads(8)
+    dev = torch.device("cuda", 0)
+    conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    cfgs = CONFIGS[which]
+    cfgs[0][1]()
+    loop = HotLoop(conf, dev, stage="coarse", curves=True, **bench.HOTLOOP_KW)
+    it = 0
+    for _ in range(240):
+        loop.step(it)
+        it += 1
+    torch.cuda.synchronize()
+    acc = {name: [] for name, _ in cfgs}
+    rays = {name: [] for name, _ in cfgs}
+    for r in range(rounds):
+        for name, apply in cfgs:
+            apply()
+            if loop.forward_time % loop.remesh_intersect > loop.remesh_intersect - block - 2:
+                loop.forward_time = 1                       # keep the re-mesh out of the blocks (same for every configuration)
+            loop.step(it)
+            it += 1
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            n_r = 0
+            for _ in range(block):
+                _, nr = loop.step(it)
+                n_r += int(nr)
+                it += 1
+            e1.record()
+            torch.cuda.synchronize()
+            acc[name].append((time.perf_counter() - t0) * 1e3 / block)
+            rays[name].append(n_r / block)
+    print("# %d rounds x %d iterations per configuration, interleaved on one scene (settled 240 iterations on the first configuration); "
+          "ms per iteration (wall), mean / min, rays per iteration; MC vertices at the end %s" % (
+              rounds, block, [int(v.shape[0]) for v in loop.garment_vs]))
+    base = sum(acc[cfgs[0][0]]) / rounds
+    for name, _ in cfgs:
+        v = acc[name]
+        print("%-44s %8.2f ms  (min %7.2f)  %+5.1f %%   rays %.0f   per round: %s" % (
+            name, sum(v) / len(v), min(v), (sum(v) / len(v) / base - 1) * 100, sum(rays[name]) / len(v), " ".join("%.1f" % x for x in v)))
+
+
+if __name__ == "__main__":
+    main()

@@ -76,9 +76,9 @@ class KernelEvents:
 
     MIN_FLOPS = 4.0e9     # launches below 4 GFLOP (the ray path's ~20 us kernels) are counted, not bracketed
 
-    def begin(self):
+    def begin(self, min_flops=None):
         from recmv import _lib as L
-        L.check(L.lib().recmv_profile_begin(self.MIN_FLOPS), "profile_begin")
+        L.check(L.lib().recmv_profile_begin(self.MIN_FLOPS if min_flops is None else min_flops), "profile_begin")
 
     def end(self):
         import ctypes as C
@@ -93,6 +93,9 @@ class KernelEvents:
             if un > 0:
                 small[name] = dict(launches=int(un), gflop=round(ufl / 1e9, 1))
         self.small = small
+        b2 = (C.c_double * 2)()
+        L.check(L.lib().recmv_profile_busy(C.cast(b2, C.c_void_p)), "profile_busy")
+        self.busy = (float(b2[0]), float(b2[1]))          # union of the bracketed intervals, first start -> last end [s]
         return out
 
 
@@ -399,6 +402,50 @@ def config2_leg(loop, it, allreduce, world, device, steps=6):
             "rays_converged_fraction": round(conv / max(rays, 1), 4), "_steps_run": n}
 
 
+def high_convergence_leg(loop, it, allreduce, world, device, sync, steps=10, lr_scale=0.1):
+    """The headline iteration in the regime of a capture late in its optimisation, where the networks move slowly and the explicit
+    meshes stay valid between two re-meshes: the main optimiser's learning rate scaled by `lr_scale` for the leg, a re-mesh in the
+    untimed first step, then `steps` timed steps.  On the headline scene (fresh nets, Adam at 1e-4) under half of the rays still
+    converge 15 iterations after a re-mesh and the render phases are under-loaded; here nearly every ray reaches them."""
+    import torch.distributed as tdist
+    from recmv import dist as rdist
+    old = [g['lr'] for g in loop.optimizer.param_groups]
+    for g in loop.optimizer.param_groups:
+        g['lr'] = g['lr'] * lr_scale
+    n = 0
+    try:
+        loop.forward_time = 0                       # the leg starts on freshly extracted meshes
+        loop.step(it + n, allreduce)
+        n += 1
+        rdist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        rays = conv = 0
+        per_step = []
+        for _ in range(steps):
+            _, r = loop.step(it + n, allreduce)
+            n += 1
+            rays += int(r)
+            c = sum(loop.info.get('rays_converged', []))
+            conv += c
+            per_step.append(round(c / max(int(r), 1), 3))
+        sync()
+        rdist.barrier()
+        dt = time.perf_counter() - t0
+    finally:
+        for g, lr in zip(loop.optimizer.param_groups, old):
+            g['lr'] = lr
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        dt = float(t[0])
+    return {"workload": "configs[1] as in `value`, main optimiser's learning rate x %g for the leg (the slow-moving networks of a capture "
+                        "late in its optimisation), re-mesh in the untimed first step, no re-mesh inside the %d timed steps" % (lr_scale, steps),
+            "steps": steps, "value": round(steps * world / dt, 4), "unit": "iters/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "rays_per_iter": round(rays / steps, 1), "rays_converged_fraction": round(conv / max(rays, 1), 4),
+            "rays_converged_fraction_per_step": per_step, "mc_vertices": [int(v.shape[0]) for v in loop.garment_vs], "_steps_run": n}
+
+
 def whole_step_matrix_rate(roofline, steps, ms_per_step):
     """Σ matrix FLOP of one iteration ÷ its duration, as a fraction of the f32 MFMA peak — from the fields of the `roofline`
     block itself: the event-timed variants (launches x average duration x achieved rate) plus the launches too short to
@@ -586,6 +633,7 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
     elapsed = time.perf_counter() - t0
     gs = prof.end() if prof else {}
     small_launches = prof.small if prof else None
+    busy_timed = prof.busy if prof else None
     alt = None
     if not args.no_alt_mode:
         # the same loop in the OTHER matrix mode, a short extra run outside the timed region (not part of `value`)
@@ -621,7 +669,7 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
             loop.step(it, allreduce)
             it += 1
             sync()
-            prof.begin()
+            prof.begin(min_flops=0.0)            # every MFMA launch bracketed here, the ray path's ~20 us products too
             for _ in range(max(2, min(5, args.steps))):
                 loop.step(it, allreduce)
                 it += 1
@@ -737,6 +785,38 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                     "note": "the same kernel in a short pass with the iteration in the reference's serial order on one "
                             "stream (RECMV_SERIAL=1), i.e. alone on the device; in the timed region the ray pipeline and "
                             "the curve branch run beside it on other streams and share the CUs with it"}
+            # the kernels with the most device time next to the dominant one, each with its own rate and share of the step: the
+            # large products from their brackets in the timed region; the ray path's 64 x 32 product (too short to bracket there:
+            # doing so costs 7 % of the step) from the launches COUNTED in the timed region x its event-timed duration in the
+            # serial-order pass, where every launch is bracketed
+            fc = []
+            for k, v in gs.items():
+                fc.append({"kernel": "recmv::" + k, "launches": v["launches"], "avg_launch_us": round(v["avg_us"], 2),
+                           "achieved": round(v["flops"] / v["seconds"] / 1e12, 3),
+                           "frac": round(v["flops"] / v["seconds"] / MFMA_F32_PEAK, 4),
+                           "share_of_step": round(v["seconds"] / elapsed, 3), "timing": "HIP events around every launch in the timed region"})
+            for k, v in (small_launches or {}).items():
+                sv = (gs_serial or {}).get(k)
+                if not sv or v["launches"] < 100:
+                    continue
+                small_in_serial = sv["launches"]
+                us = sv["avg_us"]
+                ach = sv["flops"] / sv["seconds"]
+                fc.append({"kernel": "recmv::" + k + " (its launches under 4 GFLOP)", "launches": v["launches"], "avg_launch_us": round(us, 2),
+                           "achieved": round(ach / 1e12, 3), "frac": round(ach / MFMA_F32_PEAK, 4),
+                           "share_of_step": round(v["launches"] * us * 1e-6 / elapsed, 3),
+                           "timing": "launches counted in the timed region x the kernel's HIP-event duration in the serial-order pass "
+                                     "(%d launches bracketed there, alone on the device)" % small_in_serial})
+            fc.sort(key=lambda e: -e["share_of_step"])
+            line["roofline"]["first_class"] = fc
+            if busy_timed and busy_timed[1] > 0:
+                line["busy_fraction_timed_region"] = {
+                    "mfma_launches_over_4_gflop": round(busy_timed[0] / elapsed, 4),
+                    "union_s": round(busy_timed[0], 4), "elapsed_s": round(elapsed, 4),
+                    "note": "union of the HIP-event intervals of every bracketed MFMA launch (all streams, one time axis) / the timed "
+                            "region: the share of the step in which at least one large product was running.  A LOWER bound of the busy "
+                            "fraction: the ray path's short products, the samplers, rasterisers and element-wise kernels are not "
+                            "bracketed; profiles/r04_bench_kernel_trace.txt has the union over ALL kernels from the rocprofv3 trace"}
         step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)] if marks else []
         plain = [m for k, m in enumerate(step_ms) if k not in remesh_steps]
         with_r = [step_ms[k] for k in remesh_steps if k < len(step_ms)]
@@ -773,12 +853,22 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                 export_state(loop, state, loop.frame_batch(it), it)
                 line["cpu_baseline"] = cpu_baseline(args.conf, state)
             log("CPU baseline done")
-    # the second workload leg LAST: it re-meshes on its own pyramid, and everything above describes the main workload's meshes
+    # the extra workload legs LAST: they re-mesh, and everything above describes the main workload's meshes
     leg2 = None
     if not args.no_config2:
         leg2 = config2_leg(loop, it, allreduce, world, device)
         it += leg2.pop("_steps_run")
+    leg_hc = None
+    if not args.no_config2 and on_gpu:
+        leg_hc = high_convergence_leg(loop, it, allreduce, world, device, sync)
+        it += leg_hc.pop("_steps_run")
     if rank == 0:
+        if leg_hc:
+            rm = line.get("remesh") or {}
+            if rm.get("remesh_extra_ms") is not None:
+                ms = leg_hc["ms_per_step"] + rm["remesh_extra_ms"] / rm["period_iters"]
+                leg_hc["iters_per_sec_at_reference_cadence"] = round(world * 1e3 / ms, 4)
+            line["high_convergence"] = leg_hc
         if leg2:
             line["config2"] = leg2
         print(json.dumps(line), flush=True)

@@ -504,6 +504,9 @@ int recmv_gather_rows(const float* table, int64_t ldt, const int64_t* index, flo
  * ---------------------------------------------------------------------------------------------- */
 int recmv_profile_begin(double min_flops);
 int recmv_profile_end(double* out, int n_variants);
+/* After recmv_profile_end: out2[0] = seconds in which at least ONE bracketed launch was running (union of the event intervals of all
+ * streams on one time axis), out2[1] = seconds from the first bracketed start to the last bracketed end. */
+int recmv_profile_busy(double* out2);
 
 #ifdef __cplusplus
 }

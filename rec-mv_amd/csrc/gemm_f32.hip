@@ -23,6 +23,7 @@
 #include <type_traits>
 #include <vector>
 #include "common.h"
+#include <algorithm>
 
 namespace recmv {
 namespace {
@@ -1345,6 +1346,7 @@ struct Profiler {
   double untimed[14][2] = {};      // [variant][launches, flops]
   std::vector<LaunchRec> recs;
   std::vector<hipEvent_t> pool;
+  double busy_union_s = 0.0, busy_span_s = 0.0;   // of the last recmv_profile_end: union of the bracketed intervals, first start -> last end
   std::mutex mu;        // autograd's backward thread launches too
   hipEvent_t get() {
     std::lock_guard<std::mutex> lk(mu);
@@ -1704,6 +1706,13 @@ extern "C" int recmv_profile_begin(double min_flops) {
   return RECMV_OK;
 }
 
+extern "C" int recmv_profile_busy(double* out2) {
+  RECMV_REQUIRE(out2, "profile_busy: NULL");
+  out2[0] = g_prof.busy_union_s;
+  out2[1] = g_prof.busy_span_s;
+  return RECMV_OK;
+}
+
 extern "C" int recmv_profile_end(double* out, int n_variants) {
   g_prof.on = false;
   RECMV_REQUIRE(out && n_variants >= 9, "profile_end: need room for 9 variants");
@@ -1714,6 +1723,11 @@ extern "C" int recmv_profile_end(double* out, int n_variants) {
     out[5 * slot(v) + 3] += g_prof.untimed[v][0];
     out[5 * slot(v) + 4] += g_prof.untimed[v][1];
   }
+  // every bracket also as an interval on one time axis (the first recorded event is the origin; events of different streams of a
+  // device share a clock): the union of the intervals is the time in which at least one bracketed MFMA kernel was running
+  std::vector<std::pair<double, double>> iv;
+  iv.reserve(g_prof.recs.size());
+  hipEvent_t origin = g_prof.recs.empty() ? nullptr : g_prof.recs.front().a;
   for (auto& r : g_prof.recs) {
     RECMV_HIP_TRY(hipEventSynchronize(r.b));
     float ms = 0.f;
@@ -1721,9 +1735,31 @@ extern "C" int recmv_profile_end(double* out, int n_variants) {
     out[5 * slot(r.variant) + 0] += 1.0;
     out[5 * slot(r.variant) + 1] += (double)ms * 1e-3;
     out[5 * slot(r.variant) + 2] += r.flops;
+    float t0 = 0.f;
+    if (r.a != origin && hipEventElapsedTime(&t0, origin, r.a) != hipSuccess) t0 = -1.f;
+    if (t0 >= 0.f) iv.emplace_back((double)t0 * 1e-3, (double)(t0 + ms) * 1e-3);
+  }
+  for (auto& r : g_prof.recs) {
     g_prof.pool.push_back(r.a);
     g_prof.pool.push_back(r.b);
   }
   g_prof.recs.clear();
+  g_prof.busy_union_s = g_prof.busy_span_s = 0.0;
+  if (!iv.empty()) {
+    std::sort(iv.begin(), iv.end());
+    double lo = iv[0].first, hi = iv[0].second, first = iv[0].first, last = iv[0].second;
+    for (size_t i = 1; i < iv.size(); ++i) {
+      if (iv[i].first > hi) {
+        g_prof.busy_union_s += hi - lo;
+        lo = iv[i].first;
+        hi = iv[i].second;
+      } else if (iv[i].second > hi) {
+        hi = iv[i].second;
+      }
+      if (iv[i].second > last) last = iv[i].second;
+    }
+    g_prof.busy_union_s += hi - lo;
+    g_prof.busy_span_s = last - first;
+  }
   return RECMV_OK;
 }

@@ -56,7 +56,7 @@ class Pointclouds:
         return torch.cat(self.features, 0)
 
 
-def main(large_pose=False, remesh=False, single=False, trajectory=0):
+def main(large_pose=False, remesh=False, single=False, trajectory=0, remesh_period=30):
     """`single`: ONE one-piece garment — capture `leyang_jump` = ['dress'] with `train.is_upper_bottom` (configs/female_large_pose/
     leyang_jump*.conf): the union region `datas['upper_bottom']` supervises it (:1894-1905), the deformer code holds body + one
     garment (:670-676), four feature lines (neck, cuffs, hem), no curve-aware disc.
@@ -164,7 +164,7 @@ def main(large_pose=False, remesh=False, single=False, trajectory=0):
                                  deformer=comp, netRender=rn,
                                  sdfShrinkRadius=0.0, body_vs=st['body_v'], body_fs=st['body_f'], tmpBodyVs=st['body_v'],
                                  tmpBodyFs=st['body_f'], inter_free_curve=ref, fl_names=line_names, maskRender=MaskRender(),
-                                 dataset=dataset, forward_time=1, remesh_intersect=30, remesh_time=0., root=None,
+                                 dataset=dataset, forward_time=1, remesh_intersect=remesh_period, remesh_time=0., root=None,
                                  dctnull=Uref.DCTNullSpace(10, 30), angThred=cam0.angThreshold(0.5),
                                  garment_type='leyang_jump' if single else 'female-3-casual', isfine=False)
     if single:                                             # the reference's own split of the per-frame deformer code (:668-675)
@@ -334,12 +334,42 @@ def _trajectory(KLASS, fake, datas, opt, root, T, Sref, names):
         res['canon_v_' + tag], res['canon_f_' + tag] = v.detach(), f
         res['canon_moved_' + tag] = torch.tensor(fc.chamfer_vertices(v, vs0[('body', 'u', 'b').index(tag)]))
         print("canonical %s: %d vertices, %d faces" % (tag, v.shape[0], f.shape[0]))
-    save(os.environ.get("TRAJ_NAME", "trajectory"), **res)
+    return res
+
+
+def trajectory_fixture(name="trajectory", iters=None, remesh_period=30):
+    """trajectory.npz (35 iterations, the config's re-mesh period of 30) and trajectory_short.npz (14 iterations, re-mesh period 10:
+    the same structure inside the window in which the reference's two runs still agree to rounding): the reference's loop run TWICE — with 4 and with 1 sgemm threads, i.e. two summation orders of the same
+    arithmetic — so that the fixture carries the reference's OWN run-to-run envelope next to its results: the optimisation is a
+    chaotic map (Adam on 2 M parameters, rays that enter or leave the converged set), rounding differences grow, and what another
+    implementation can be held to is the north_star's end-to-end bound (canonical-mesh Chamfer <= 1e-4) plus agreement at rounding
+    level while the two reference runs still agree with each other."""
+    iters = fc.TRAJ_ITERS if iters is None else iters
+    torch.set_num_threads(4)
+    a = main(trajectory=iters, remesh_period=remesh_period)
+    torch.set_num_threads(1)
+    b = main(trajectory=iters, remesh_period=remesh_period)
+    a['remesh_period'] = torch.tensor(remesh_period)
+    la, lb = a['losses'], b['losses']
+    a['self_loss_rel_dev'] = (la - lb).abs() / la.abs()
+    a['self_rays_equal'] = (a['rays'] == b['rays']).all(dim=1)
+    for tag in ('body', 'u', 'b'):
+        a['self_canon_chamfer_' + tag] = torch.tensor(fc.chamfer_vertices(a['canon_v_' + tag], b['canon_v_' + tag]))
+    for tag in ('u', 'b'):
+        a['self_explicit_chamfer_' + tag] = torch.tensor(fc.chamfer_vertices(a['final_verts_' + tag], b['final_verts_' + tag]))
+        a['self_faces_equal_' + tag] = torch.tensor(tuple(a['final_faces_' + tag].shape) == tuple(b['final_faces_' + tag].shape)
+                                                   and bool(torch.equal(a['final_faces_' + tag], b['final_faces_' + tag])))
+    print("reference against itself (4 vs 1 threads): loss deviation", [round(float(v), 6) for v in a['self_loss_rel_dev']])
+    print({k: v.tolist() for k, v in a.items() if k.startswith('self_') and k != 'self_loss_rel_dev'})
+    save(name, **a)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "trajectory":     # (minutes of host time: generated on its own)
-        main(trajectory=fc.TRAJ_ITERS)
+        trajectory_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "trajectory_short":
+        trajectory_fixture("trajectory_short", fc.TRAJ_SHORT_ITERS, fc.TRAJ_SHORT_REMESH)
         sys.exit(0)
     main()
     main(large_pose=True)

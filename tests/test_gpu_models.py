@@ -245,10 +245,13 @@ def test_row_tile_mlp_equals_the_per_layer_chain(nets, P, row_tiles, monkeypatch
         return f, gf, d, gd, f_only
 
     a, b = run(True), run(False)
+    # (the row-tile kernels always multiply in f32; under RECMV_GEMM_MODE=1 the per-layer chain sums six bf16 piece products and
+    # drops those below 2^-25: two different roundings of the same products, 3x the bound)
+    bound = 3e-5 if os.environ.get("RECMV_GEMM_MODE") == "1" else 1e-5
     for name, u, v in zip(("sdf value", "sdf input gradient", "offset MLP", "offset MLP vjp", "sdf value (no keep)"), a, b):
         scale = float(v.abs().max())
         err = float((u - v).abs().max())
-        assert err <= 1e-5 * scale + 1e-7, (name, P, err, scale)
+        assert err <= bound * scale + 1e-7, (name, P, err, scale)
     assert torch.equal(a[0], a[4])
     if P >= 1000:       # the same rays in other tiles (shifted by 5 rows): bit-identical per ray
         monkeypatch.setenv("RECMV_MLP_ROWS", "1")

@@ -147,6 +147,15 @@ int recmv_mc_run(const float* sdf, int64_t nx, int64_t ny, int64_t nz, float iso
                  void* workspace, int64_t workspace_bytes,
                  float* vertices, int64_t vertex_capacity, int64_t* faces, int64_t face_capacity,
                  int32_t* counts_device, void* stream);
+/* The same for up to 4 volumes of ONE lattice size in one set of four launches (grid y = volume): the three nets of a re-mesh —
+ * body + two garments, engineer/networks/OptimGarmentNetwork.py:581-618 calls MCGpu.mc_gpu once per net — share every launch; the
+ * passes after the volume stream work on kilobytes and are launch-latency bound.  sdf / workspaces / vertices / faces /
+ * counts_device: HOST arrays of n device pointers (every volume its own workspace of recmv_mc_workspace_bytes); capacities per
+ * volume; results per volume exactly those of recmv_mc_run. */
+int recmv_mc_run_batch(int n, const float* const* sdf, int64_t nx, int64_t ny, int64_t nz, float iso, float xstep, float ystep,
+                       float zstep, float xmin, float ymin, float zmin, void* const* workspaces, int64_t workspace_bytes,
+                       float* const* vertices, const int64_t* vertex_capacity, int64_t* const* faces,
+                       const int64_t* face_capacity, int32_t* const* counts_device, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * E'. Seg3dLossless bookkeeping on the device (csrc/seg3d.hip) — the per-level steps of

@@ -119,7 +119,7 @@ __device__ __forceinline__ int tri_count(unsigned long long word) {
 
 // ------------------------------------------------------------------------------------------- K0
 // bits[w] bit b = (sdf[64 w + b] < iso).  A wave turns 64 words (4096 floats) per trip.
-__global__ __launch_bounds__(kBlk) void mc_inside_kernel(const float* __restrict__ sdf, int64_t total, float iso,
+__device__ __forceinline__ void mc_inside_body(const float* __restrict__ sdf, int64_t total, float iso,
                                                          unsigned long long* __restrict__ bits, int64_t nword) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t wave = (int64_t)blockIdx.x * (kBlk / kWave) + threadIdx.x / kWave;
@@ -197,7 +197,7 @@ __device__ __forceinline__ void row_bits(const unsigned long long* __restrict__ 
 }
 
 // Workgroup q classifies segments [q*kScanBlk, (q+1)*kScanBlk), one per lane, and leaves their sums in part[][q].
-__global__ __launch_bounds__(kScanBlk) void mc_classify_kernel(const unsigned long long* __restrict__ bits, int NX,
+__device__ __forceinline__ void mc_classify_body(const unsigned long long* __restrict__ bits, int NX,
                                                                int NY, int NZ, int S, int64_t nseg, int64_t npart,
                                                                unsigned int* __restrict__ cnt, McRec* __restrict__ rec,
                                                                unsigned int* __restrict__ part) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kScanBlk) void mc_classify_kernel(const unsigned lo
 
 // ------------------------------------------------------------------------------------------- K2
 // Block q scans segments [q*kScanChunk, (q+1)*kScanChunk); its base = sum of the K1 partial sums before the chunk.
-__global__ __launch_bounds__(kScanBlk) void mc_scan_kernel(const unsigned int* __restrict__ cnt, int64_t nseg,
+__device__ __forceinline__ void mc_scan_body(const unsigned int* __restrict__ cnt, int64_t nseg,
                                                            int64_t npart, const unsigned int* __restrict__ part,
                                                            McRec* __restrict__ rec, unsigned int* __restrict__ act,
                                                            unsigned int* __restrict__ total) {
@@ -378,7 +378,7 @@ __device__ __forceinline__ int vertex_id(const NbrRec& r, int l, int dir) {
   return (int)(r.voff + rank);
 }
 
-__global__ __launch_bounds__(kBlk) void mc_emit_kernel(const float* __restrict__ sdf, int NX, int NY, int NZ,
+__device__ __forceinline__ void mc_emit_body(const float* __restrict__ sdf, int NX, int NY, int NZ,
                                                        float iso, int S, int64_t nseg,
                                                        const McRec* __restrict__ rec,
                                                        const unsigned int* __restrict__ act,
@@ -510,6 +510,66 @@ __global__ __launch_bounds__(kBlk) void mc_emit_kernel(const float* __restrict__
   }
 }
 
+
+// ------------------------------------------------------------------------------------------- launch forms
+// One volume per launch (grid x), or up to kMcMaxBatch volumes of ONE lattice size per launch (grid y = volume): the three nets of a
+// re-mesh (body + two garments, OptimGarmentNetwork.py:581-618) share every launch — the passes after K0 work on kilobytes and are
+// launch-latency bound, so three volumes take hardly longer than one.
+constexpr int kMcMaxBatch = 4;
+struct McBatch {
+  const float* sdf[kMcMaxBatch];
+  char* ws[kMcMaxBatch];
+  float* vertices[kMcMaxBatch];
+  long long* faces[kMcMaxBatch];
+  int64_t vcap[kMcMaxBatch], fcap[kMcMaxBatch];
+};
+
+__global__ __launch_bounds__(kBlk) void mc_inside_kernel(const float* __restrict__ sdf, int64_t total, float iso,
+                                                         unsigned long long* __restrict__ bits, int64_t nword) {
+  mc_inside_body(sdf, total, iso, bits, nword);
+}
+__global__ __launch_bounds__(kScanBlk) void mc_classify_kernel(const unsigned long long* __restrict__ bits, int NX, int NY, int NZ,
+                                                               int S, int64_t nseg, int64_t npart, unsigned int* __restrict__ cnt,
+                                                               McRec* __restrict__ rec, unsigned int* __restrict__ part) {
+  mc_classify_body(bits, NX, NY, NZ, S, nseg, npart, cnt, rec, part);
+}
+__global__ __launch_bounds__(kScanBlk) void mc_scan_kernel(const unsigned int* __restrict__ cnt, int64_t nseg, int64_t npart,
+                                                           const unsigned int* __restrict__ part, McRec* __restrict__ rec,
+                                                           unsigned int* __restrict__ act, unsigned int* __restrict__ total) {
+  mc_scan_body(cnt, nseg, npart, part, rec, act, total);
+}
+__global__ __launch_bounds__(kBlk) void mc_emit_kernel(const float* __restrict__ sdf, int NX, int NY, int NZ, float iso, int S,
+                                                       int64_t nseg, const McRec* __restrict__ rec,
+                                                       const unsigned int* __restrict__ act, const unsigned int* __restrict__ total,
+                                                       float xstep, float ystep, float zstep, float xmin, float ymin, float zmin,
+                                                       float* __restrict__ vertices, int64_t vcap, long long* __restrict__ faces,
+                                                       int64_t fcap) {
+  mc_emit_body(sdf, NX, NY, NZ, iso, S, nseg, rec, act, total, xstep, ystep, zstep, xmin, ymin, zmin, vertices, vcap, faces, fcap);
+}
+
+__global__ __launch_bounds__(kBlk) void mc_inside_batch_kernel(McBatch b, McLayout L, float iso) {
+  const int v = blockIdx.y;
+  mc_inside_body(b.sdf[v], L.nvox, iso, (unsigned long long*)(b.ws[v] + L.off_bits), L.nword);
+}
+__global__ __launch_bounds__(kScanBlk) void mc_classify_batch_kernel(McBatch b, McLayout L, int NX, int NY, int NZ) {
+  char* ws = b.ws[blockIdx.y];
+  mc_classify_body((const unsigned long long*)(ws + L.off_bits), NX, NY, NZ, L.S, L.nseg, L.npart, (unsigned int*)(ws + L.off_cnt),
+                   (McRec*)(ws + L.off_rec), (unsigned int*)(ws + L.off_part));
+}
+__global__ __launch_bounds__(kScanBlk) void mc_scan_batch_kernel(McBatch b, McLayout L) {
+  char* ws = b.ws[blockIdx.y];
+  mc_scan_body((const unsigned int*)(ws + L.off_cnt), L.nseg, L.npart, (const unsigned int*)(ws + L.off_part), (McRec*)(ws + L.off_rec),
+               (unsigned int*)(ws + L.off_act), (unsigned int*)(ws + L.off_total));
+}
+__global__ __launch_bounds__(kBlk) void mc_emit_batch_kernel(McBatch b, McLayout L, int NX, int NY, int NZ, float iso, float xstep,
+                                                             float ystep, float zstep, float xmin, float ymin, float zmin) {
+  const int v = blockIdx.y;
+  const char* ws = b.ws[v];
+  mc_emit_body(b.sdf[v], NX, NY, NZ, iso, L.S, L.nseg, (const McRec*)(ws + L.off_rec), (const unsigned int*)(ws + L.off_act),
+               (const unsigned int*)(ws + L.off_total), xstep, ystep, zstep, xmin, ymin, zmin, b.vertices[v], b.vcap[v], b.faces[v],
+               b.fcap[v]);
+}
+
 }  // namespace
 }  // namespace recmv
 
@@ -638,5 +698,60 @@ extern "C" int recmv_mc_run(const float* sdf, int64_t nx, int64_t ny, int64_t nz
                       bound > 0 ? bound : 1, vertices, vertex_capacity, faces, face_capacity, s);
   if (rc) return rc;
   RECMV_HIP_TRY(hipMemcpyAsync(counts_device, (char*)workspace + L.off_total, 12, hipMemcpyDeviceToDevice, s));
+  return RECMV_OK;
+}
+
+extern "C" int recmv_mc_run_batch(int n, const float* const* sdf, int64_t nx, int64_t ny, int64_t nz, float iso, float xstep,
+                                  float ystep, float zstep, float xmin, float ymin, float zmin, void* const* workspaces,
+                                  int64_t workspace_bytes, float* const* vertices, const int64_t* vertex_capacity,
+                                  int64_t* const* faces, const int64_t* face_capacity, int32_t* const* counts_device,
+                                  void* stream) {
+  RECMV_REQUIRE(n >= 1 && n <= kMcMaxBatch, "mc_run_batch: 1..%d volumes per call, got %d", kMcMaxBatch, n);
+  RECMV_REQUIRE(sdf && workspaces && vertices && vertex_capacity && faces && face_capacity && counts_device,
+                "mc_run_batch: NULL argument array");
+  McLayout L;
+  McBatch b;
+  memset(&b, 0, sizeof(b));
+  int64_t bound = 1;
+  for (int v = 0; v < n; ++v) {
+    int rc = mc_check("mc_run_batch", sdf[v], nx, ny, nz, workspaces[v], workspace_bytes, &L);
+    if (rc) return rc;
+    RECMV_REQUIRE(counts_device[v], "mc_run_batch: NULL counts_device[%d]", v);
+    RECMV_REQUIRE(vertex_capacity[v] >= 0 && face_capacity[v] >= 0 && (vertices[v] || vertex_capacity[v] == 0) &&
+                      (faces[v] || face_capacity[v] == 0), "mc_run_batch: bad output buffers of volume %d", v);
+    for (int u = 0; u < v; ++u) RECMV_REQUIRE(workspaces[u] != workspaces[v], "mc_run_batch: volumes %d and %d share a workspace", u, v);
+    b.sdf[v] = sdf[v];
+    b.ws[v] = (char*)workspaces[v];
+    b.vertices[v] = vertices[v];
+    b.faces[v] = (long long*)faces[v];
+    b.vcap[v] = vertex_capacity[v];
+    b.fcap[v] = face_capacity[v];
+    const int64_t m = face_capacity[v] > vertex_capacity[v] ? face_capacity[v] : vertex_capacity[v];
+    bound = m > bound ? m : bound;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (L.nseg == 0) {
+    for (int v = 0; v < n; ++v) RECMV_HIP_TRY(hipMemsetAsync(counts_device[v], 0, 12, s));
+    return RECMV_OK;
+  }
+  int64_t g0 = ceil_div(ceil_div(L.nword + 2, kWave), kBlk / kWave);
+  if (g0 > kNumCU * 8 / n) g0 = kNumCU * 8 / n;
+  hipLaunchKernelGGL(mc_inside_batch_kernel, dim3((int)g0, n), dim3(kBlk), 0, s, b, L, iso);
+  int rc = check_launch("mc_inside(batch)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mc_classify_batch_kernel, dim3((int)L.npart, n), dim3(kScanBlk), 0, s, b, L, (int)nx, (int)ny, (int)nz);
+  rc = check_launch("mc_classify(batch)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mc_scan_batch_kernel, dim3((int)L.nchunk, n), dim3(kScanBlk), 0, s, b, L);
+  rc = check_launch("mc_scan(batch)");
+  if (rc) return rc;
+  int64_t g3 = ceil_div(bound, kBlk);
+  g3 = g3 < 1 ? 1 : (g3 > 4096 ? 4096 : g3);
+  hipLaunchKernelGGL(mc_emit_batch_kernel, dim3((int)g3, n), dim3(kBlk), 0, s, b, L, (int)nx, (int)ny, (int)nz, iso, xstep, ystep, zstep,
+                     xmin, ymin, zmin);
+  rc = check_launch("mc_emit(batch)");
+  if (rc) return rc;
+  for (int v = 0; v < n; ++v)
+    RECMV_HIP_TRY(hipMemcpyAsync(counts_device[v], (char*)workspaces[v] + L.off_total, 12, hipMemcpyDeviceToDevice, s));
   return RECMV_OK;
 }

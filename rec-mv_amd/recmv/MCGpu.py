@@ -97,3 +97,68 @@ def mc_gpu(sdfs, xstep=1.0, ystep=1.0, zstep=1.0, xmin=0.0, ymin=0.0, zmin=0.0, 
                                           V, L.ptr(faces), F, st), "mc_gpu/emit")
         _last_sizes[key] = (V, F)
     return [vertices, faces]
+
+
+def mc_gpu_multi(volumes, xstep=1.0, ystep=1.0, zstep=1.0, xmin=0.0, ymin=0.0, zmin=0.0, fTargetValue=0.0):
+    """`mc_gpu` for several volumes of ONE lattice size — the body net and the garment nets of a re-mesh
+    (OptimGarmentNetwork.py:581-618 calls MCGpu.mc_gpu once per net) — in ONE set of four launches (recmv_mc_run_batch: grid y =
+    volume) and ONE counter read-back.  Per volume the result is exactly `mc_gpu`'s.  Volumes without a size guess yet (first
+    extraction of a grid) or more than four of them take the per-volume route."""
+    vols = list(volumes)
+    ok = (1 < len(vols) <= 4 and all(isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.float32 and v.dim() == 3
+                                     and v.is_contiguous() and v.shape == vols[0].shape and v.device == vols[0].device for v in vols)
+          and min(vols[0].shape) > 0)
+    dev = vols[0].device if ok else None
+    dev_id = vols[0].get_device() if ok else -1
+    nx, ny, nz = (vols[0].shape if ok else (0, 0, 0))
+    keys = [(dev_id, nx, ny, nz, i) for i in range(len(vols))]
+    if not ok or not (0 <= dev_id < 8) or any(k not in _last_sizes for k in keys):
+        out = []
+        for i, v in enumerate(vols):
+            r = mc_gpu(v, xstep, ystep, zstep, xmin, ymin, zmin, fTargetValue)
+            if ok and r:
+                _last_sizes[keys[i]] = (int(r[0].shape[0]), int(r[1].shape[0]))
+            out.append(r)
+        return out
+    lib = L.lib()
+    n = len(vols)
+    with L.device_guard(dev):
+        nbytes = int(lib.recmv_mc_workspace_bytes(nx, ny, nz))
+        st = torch.cuda.current_stream(dev)
+        wss = []
+        for i in range(n):
+            key = (dev_id, st.cuda_stream, 'multi', i)
+            ws = _workspaces.get(key)
+            if ws is None or ws.numel() < nbytes:
+                ws = _workspaces[key] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+            wss.append(ws)
+        caps = [tuple(int(g * 1.25) + 4096 for g in _last_sizes[k]) for k in keys]
+        vbufs = [torch.empty((c[0], 3), dtype=torch.float32, device=dev) for c in caps]
+        fbufs = [torch.empty((c[1], 3), dtype=torch.int64, device=dev) for c in caps]
+        counts_dev = torch.empty((n, 3), dtype=torch.int32, device=dev)
+        PtrArr, I64Arr = C.c_void_p * n, C.c_int64 * n
+        geom = (float(fTargetValue), float(xstep), float(ystep), float(zstep), float(xmin), float(ymin), float(zmin))
+        L.check(lib.recmv_mc_run_batch(n, PtrArr(*[v.data_ptr() for v in vols]), nx, ny, nz, *geom,
+                                       PtrArr(*[w.data_ptr() for w in wss]), nbytes, PtrArr(*[b.data_ptr() for b in vbufs]),
+                                       I64Arr(*[c[0] for c in caps]), PtrArr(*[b.data_ptr() for b in fbufs]),
+                                       I64Arr(*[c[1] for c in caps]), PtrArr(*[counts_dev[i].data_ptr() for i in range(n)]),
+                                       L.stream_ptr(dev)), "mc_gpu_multi/run")
+        key_p = ('multi', dev_id)
+        host = _pinned.get(key_p)
+        if host is None or host.numel() < 3 * n:
+            host = _pinned[key_p] = torch.zeros(12, dtype=torch.int32).pin_memory()
+        host[:3 * n].copy_(counts_dev.view(-1), non_blocking=True)
+        st.synchronize()
+        sizes = host[:3 * n].view(n, 3).tolist()
+        out = []
+        for i, (V, F, A) in enumerate(sizes):
+            if V <= caps[i][0] and F <= caps[i][1]:
+                vertices, faces = vbufs[i][:V], fbufs[i][:F]
+            else:                                   # the surface outgrew the margin: emit this volume again, exact sizes
+                vertices = torch.empty((V, 3), dtype=torch.float32, device=dev)
+                faces = torch.empty((F, 3), dtype=torch.int64, device=dev)
+                L.check(lib.recmv_mc_emit(L.ptr(vols[i]), nx, ny, nz, *geom, L.ptr(wss[i]), wss[i].numel(), A, L.ptr(vertices), V,
+                                          L.ptr(faces), F, L.stream_ptr(dev)), "mc_gpu_multi/emit")
+            _last_sizes[keys[i]] = (V, F)
+            out.append([vertices, faces])
+    return out

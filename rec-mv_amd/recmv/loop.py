@@ -510,13 +510,16 @@ class HotLoop:
         engine.balance_value = balance_value
         # the body's and the garments' pyramids run level by level in lockstep (Seg3dLossless.forward_multi)
         volumes = engine.forward_multi([query_of(net) for net in nets])
-        pts, faces = [], []
-        for sdfs in volumes:
-            v, f = MCGpu.mc_gpu(sdfs[0, 0].permute(2, 1, 0).contiguous(), engine.spacing_x, engine.spacing_y,
-                                engine.spacing_z, engine.bx, engine.by, engine.bz, balance_value)
-            pts.append(v)
-            faces.append(f)
-        return pts, faces
+        vols = [sdfs[0, 0].permute(2, 1, 0).contiguous() for sdfs in volumes]
+        # all nets' extractions in one set of launches and one counter read-back (MCGpu.mc_gpu_multi; on the CPU port and for a
+        # grid's first extraction: one mc_gpu per net, the reference's form)
+        multi = getattr(MCGpu, 'mc_gpu_multi', None) if vols[0].is_cuda else None
+        if multi is not None:
+            res = multi(vols, engine.spacing_x, engine.spacing_y, engine.spacing_z, engine.bx, engine.by, engine.bz, balance_value)
+        else:
+            res = [MCGpu.mc_gpu(v, engine.spacing_x, engine.spacing_y, engine.spacing_z, engine.bx, engine.by, engine.bz,
+                                balance_value) for v in vols]
+        return [r[0] for r in res], [r[1] for r in res]
 
     def marching_cube_update(self, ratio):
         """OptimGarmentNetwork.py:678-740 (openmesh vertex->face tables are never read by the loop: dropped)."""

@@ -360,6 +360,33 @@ def test_mc_full_size_257_properties():
     assert mesh_invariants(v1.cpu(), f1.cpu()) == 2
 
 
+@pytest.mark.parametrize("shape", [(33, 41, 25), (65, 65, 65), (129, 97, 70)])
+def test_mc_three_volumes_in_one_launch_set_equal_three_extractions(shape):
+    """MCGpu.mc_gpu_multi / recmv_mc_run_batch — the body's and the garments' volumes of a re-mesh through ONE set of four launches
+    (grid y = volume) — against one MCGpu.mc_gpu per volume (OptimGarmentNetwork.py:581-618): vertices and faces bit-identical per
+    volume; a surface that outgrows its capacity guess between two calls takes the exact-size emit of its own volume; the first call
+    of a grid (no guess yet) is the per-volume route."""
+    from recmv import MCGpu
+    gen = torch.Generator().manual_seed(sum(shape))
+    ax = [torch.linspace(-1, 1, n) for n in shape]
+    X, Y, Z = torch.meshgrid(*ax, indexing="ij")
+
+    def vol(r, wob):
+        return (torch.sqrt(X ** 2 + (0.8 * Y) ** 2 + Z ** 2) - r + wob * torch.sin(9 * X) * torch.cos(7 * Z)
+                + 0.01 * torch.randn(shape, generator=gen)).contiguous().to(DEV)
+
+    geom = (2. / shape[0], 2. / shape[1], 2. / shape[2], -1., -1., -1., 0.0)
+    first = [vol(0.5, 0.02), vol(0.6, 0.03), vol(0.3, 0.0)]
+    second = [vol(0.52, 0.02), vol(0.9, 0.05), vol(0.31, 0.0)]          # the middle surface grows by far more than the 25 % margin
+    MCGpu._last_sizes.clear()
+    for vols in (first, second, first):
+        got = MCGpu.mc_gpu_multi(vols, *geom)
+        for v3, (v, f) in zip(vols, got):
+            want_v, want_f = MCGpu.mc_gpu(v3, *geom)
+            assert torch.equal(v, want_v) and torch.equal(f, want_f) and v.shape[0] > 50
+    assert MCGpu.mc_gpu_multi([first[0]], *geom)[0][0].shape == got[0][0].shape          # a single volume: the per-volume route
+
+
 # ------------------------------------------------------------------------------------------ GEMM / PE
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 3, 39), (257, 512, 39), (300, 473, 512), (1000, 257, 512),
                                    (129, 130, 167), (4096, 512, 512), (77, 3, 512), (640, 512, 289), (6144, 512, 512),

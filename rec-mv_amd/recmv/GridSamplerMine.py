@@ -80,11 +80,21 @@ def dbackward(grad_output_input, grad_output_grid, input, grid, grad_output, int
     return grad_input, grad_grid, ggo
 
 
+def current_mode():
+    """The sampler mode in force (recmv_set_sampler_mode): 0 record-coalesced lanes, 1 the reference's summation order."""
+    lib = L.lib()
+    prev = lib.recmv_set_sampler_mode(0)
+    lib.recmv_set_sampler_mode(prev)
+    return int(prev)
+
+
 class exact_order:
     """`with GridSamplerMine.exact_order():` — backward / double backward sum their channels in the reference's order (one lane per
     point, GridSamplerMineKernel.cu:333-914; bit-equal to the oracle) instead of the default record-coalesced lanes (same terms,
     lane butterfly; within a few ulp of sum |terms|).  `recmv_set_sampler_mode` of the C ABI; RECMV_SAMPLER_EXACT=1 sets it for a
-    whole process."""
+    whole process.  The autograd Functions of MCAcc.grid_sampler_mine record the mode at FORWARD time and apply it to their backward /
+    double backward, so wrapping the forward call is enough.  (The switch itself is process-global: not for concurrent use from several
+    threads with different modes.)"""
 
     def __init__(self, exact=True):
         self.mode = 1 if exact else 0

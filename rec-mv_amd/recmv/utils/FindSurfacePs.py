@@ -187,6 +187,9 @@ class _RootState:
                             k.capture_end()
                         keep = _RootState._pools[self.stream.cuda_stream] = (pool, k, k_t)
                     pool = keep[0]
+                    if self.stream == torch.cuda.default_stream(self.p.device):
+                        raise RuntimeError("RECMV_ROOT_GRAPH=1: a root finder on the legacy default stream cannot be captured "
+                                           "(RECMV_SERIAL=1 puts the first garment there); run it on a side stream")
                     g = torch.cuda.CUDAGraph()
                     g.capture_begin(pool=pool, capture_error_mode="thread_local")
                     try:
@@ -316,6 +319,8 @@ def _optimize_explicit_all(cam_pos, rays_list, initTmpPs_list, batch_inds_list, 
     # loss), only the others get side streams: HIP spreads streams over 4 hardware queues, and a fifth stream shares one — with one
     # side stream per garment the curve branch's stream sat behind a root finder's 38 ms of launches (tools/phase_overlap.py)
     streams = [main] + _streams(dev, len(initTmpPs_list) - 1)
+    if os.environ.get('RECMV_ROOT_GRAPH', '0') == '1' and main == torch.cuda.default_stream(dev):
+        streams = _streams(dev, len(initTmpPs_list))       # (a capture cannot start on the legacy default stream)
     # everything the garments share (weight-normed weights and their transposes, posed skeleton, chain descriptors) is
     # produced BEFORE the side streams fork: on the main stream right here, or — `after` given — earlier by the caller
     # (prepare_root_finder), in which case the side streams wait for the caller's events / streams only and start while

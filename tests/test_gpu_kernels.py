@@ -122,6 +122,35 @@ def _sampler_exact_backward_checks(oracle, dtype, cl, inp, grid, go, gi_o, gg_o)
     assert a2_g is None and torch.equal(b2_g.cpu(), b2_o) and torch.equal(c2_g.cpu(), c2_o)
 
 
+def test_sampler_exact_order_around_the_forward_call_governs_backward_and_double_backward(oracle):
+    """`with GridSamplerMine.exact_order():` around the FORWARD of the autograd Function is enough: the mode is recorded in the
+    context and applied when autograd launches backward / double backward later, outside the block (the switch itself is a process
+    global).  Channels-last skinning-like volume with a frozen buffer, grad_grid only: the record-coalesced default differs from the
+    oracle in the last bits, the exact order is bit-equal."""
+    from recmv import GridSamplerMine
+    from recmv.MCAcc.grid_sampler_mine import GridSamplerMine3dFunction
+    inp, grid = _sampler_case(torch.float32, C=24, dims=(9, 13, 11), P=4099, channels_last=True, seed=7)
+    go = torch.randn(1, 24, 1, 1, 4099, generator=torch.Generator().manual_seed(1))
+    _, gg_o = oracle.gs3d_backward(inp, grid, go)
+    ggG = torch.randn(grid.shape, generator=torch.Generator().manual_seed(3))
+    _, b_o, c_o = oracle.gs3d_dbackward(None, ggG, inp, grid, go, need_grad_input=False)
+    vol = gpu(inp)
+    results = {}
+    for exact in (True, False):
+        g = gpu(grid).requires_grad_(True)
+        go_g = gpu(go).requires_grad_(True)
+        with GridSamplerMine.exact_order(exact):
+            out = GridSamplerMine3dFunction.apply(vol, g)
+        assert GridSamplerMine.current_mode() == 0                      # outside the block: the default again
+        (gg,) = torch.autograd.grad(out, g, go_g, create_graph=True)    # backward Function, launched outside the block
+        b, c = torch.autograd.grad(gg, (g, go_g), gpu(ggG))             # double backward
+        results[exact] = (gg.detach().cpu(), b.cpu(), c.cpu())
+    assert all(torch.equal(x, y) for x, y in zip(results[True], (gg_o, b_o, c_o)))
+    assert not all(torch.equal(x, y) for x, y in zip(results[False], (gg_o, b_o, c_o))), "the default is the other lane order"
+    for x, y in zip(results[False], (gg_o, b_o, c_o)):
+        assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max())
+
+
 @pytest.mark.parametrize("C", [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 20])
 def test_sampler_backward_record_lanes_within_tolerance(oracle, C):
     """The DEFAULT backward / double backward for grad_grid-only requests on a channels-last f32 volume (what the loop asks: the

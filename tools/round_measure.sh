@@ -1,6 +1,6 @@
 # Round-end evidence on one MI355X box: PMC passes over bench.py (-> profiles/rNN_pmc_loop.json), the kernel trace of the bench
 # command, the driver's bench command, the GPU suite.   bash tools/round_measure.sh r03 <commit sha>
-R=${1:-r03}; SHA=${2:-unknown}
+R=${1:-r04}; SHA=${2:-unknown}
 REPO=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -590,6 +590,8 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
     # the loop's host side only launches kernels; torch's intra-op pool (one thread per core: 256 here) makes every
     # small CPU op (index bookkeeping, the ray sampler's host RNG) pay a fork/join of the whole pool
     torch.set_num_threads(min(8, os.cpu_count() or 1) if on_gpu else int(os.environ.get("OMP_NUM_THREADS", "2")))
+    # (no rank-0-first stage here: a collective that waits longer than this is a desynchronised job — fail within minutes, not hours)
+    os.environ.setdefault("RECMV_DIST_TIMEOUT_S", "900")
     rank, local_rank, world = rdist.init_distributed()
     if on_gpu:
         assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"

@@ -97,7 +97,7 @@ def test_one_whole_iteration_with_the_remesh_inside_on_gpu_matches_the_reference
     import forward_case as fwc
     with cc.host_draws():
         _report("whole iteration with the re-mesh inside, on the GPU",
-                fwc.run(cc.load("forward_remesh"), DEV, rtol=3e-4, rtol_loss=1e-4, rtol_grad=1e-3, rtol_cam=5e-2,
+                fwc.run(cc.load("forward_remesh"), DEV, rtol=3e-4, rtol_loss=1e-4, rtol_grad=1e-3, rtol_cam=2.5e-2,
                         inputs=cc.load("forward"), remesh=True))
 
 

@@ -48,3 +48,24 @@ def test_whole_step_matrix_rate_is_a_function_of_the_line():
     assert w["achieved"] == round(w["matrix_tflop_per_step"] / line["ms_per_step"] * 1e3, 2) or abs(
         w["achieved"] - w["matrix_tflop_per_step"] / line["ms_per_step"] * 1e3) < 0.05
     print(w)
+
+
+def test_round_4_driver_line_carries_the_new_blocks():
+    """profiles/r04_bench_line_driver_command.json: the kernels with the most device time as first-class entries (rate consistent with
+    the 157.3 TFLOP/s divisor, shares of the step), the busy fraction from the event brackets, the high-convergence leg (>= 80 % of the
+    rays converging), configs[2], the alternative matrix mode — and the 2-rank line the launcher produced on a GPU box."""
+    d = json.loads((PROFILES / "r04_bench_line_driver_command.json").read_text().strip().splitlines()[-1])
+    fc = d["roofline"]["first_class"]
+    names = [e["kernel"] for e in fc]
+    assert any("gemm_nt_narrow_kernel" in n for n in names) and any("gemm_tn_occ_kernel" in n for n in names)
+    for e in fc:
+        assert e["frac"] == pytest.approx(e["achieved"] / 157.3, abs=2e-3) and 0 <= e["share_of_step"] < 0.6 and e["launches"] > 0
+    assert fc == sorted(fc, key=lambda e: -e["share_of_step"])
+    b = d["busy_fraction_timed_region"]
+    assert 0.3 < b["mfma_launches_over_4_gflop"] < 1.0 and b["union_s"] <= b["elapsed_s"]
+    hc = d["high_convergence"]
+    assert hc["rays_converged_fraction"] >= 0.8 and hc["value"] > 0 and "error" not in hc
+    assert d["config2"]["rays_converged_fraction"] == 1.0 and d["alt_mode"]["gemm_mode"] == "bf16x6"
+    assert "r04_pmc_loop.json" in d["roofline"]["traffic_source"] or "r03_pmc_loop.json" in d["roofline"]["traffic_source"]
+    two = json.loads((PROFILES / "r04_bench_line_2ranks_one_gpu_launcher.json").read_text().strip().splitlines()[-1])
+    assert two["n_gpus"] == 2 and two["config"]["replicas_bit_identical"] is True and len(two["config"]["per_rank_ms_per_step"]) == 2

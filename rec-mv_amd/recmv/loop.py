@@ -1140,12 +1140,18 @@ class HotLoop:
         TmpVs = self.garment_vs[g_i]
         nonmnfld = utils.sample_points(torch.cat([init_ps, _host_subset(TmpVs, surface_sample_points)], dim=0), 1.8, 0.01)
         nonmnfld.requires_grad_()
-        pred = net(nonmnfld, ratio, jet=True, features=False)
-        grad = net.gradient(nonmnfld, pred)
-        grad_loss = ((grad.norm(2, dim=-1) - 1) ** 2).mean()                           # eikonal :1118
-        self.info['{}_grad_loss'.format(name)] = grad_loss.detach()
-        total_loss = total_loss + grad_loss * conf.get_float('grad_weight')
+        # The eikonal points and (below) the converged rays go through THIS net with the same parameters: one jet pass over both
+        # row blocks instead of two (rows are independent; the reference evaluates the net twice, :1113 and :1166) — the ray
+        # block's nine layers of small launches, forward and backward, ride along in the launches of the eikonal block.  The pass
+        # is issued once the converged rays are known; RECMV_MERGE_JETS=0 keeps the two passes (A/B).
+        merge = os.environ.get('RECMV_MERGE_JETS', '1') != '0'
+        grad_loss = None
+        if not merge:
+            pred = net(nonmnfld, ratio, jet=True, features=False)
+            grad = net.gradient(nonmnfld, pred)
+            grad_loss = ((grad.norm(2, dim=-1) - 1) ** 2).mean()                       # eikonal :1118
         d_cond = d_cond_list[g_i + 1]
+        def_term = None
         if 'def_regu' in conf and conf.get_float('def_regu.weight') > 0.:               # :1135-1155
             pts = torch.cat([init_ps, _host_subset(TmpVs, surface_sample_points)], dim=0)
             pts = torch.cat([pts, utils.sample_points(pts, 1.8, 0.01, 0)], dim=0).view(1, -1, 3).expand(N, -1, 3)
@@ -1155,7 +1161,7 @@ class HotLoop:
             s = torch.log(singular_values_3x3(Jacobs))
             def_loss = utils.GMRobustError((s * s).sum(1), conf.get_float('def_regu.c'), True).mean()
             self.info['def_{}_loss'.format(name)] = def_loss.detach()
-            total_loss = total_loss + def_loss * conf.get_float('def_regu.weight')
+            def_term = def_loss * conf.get_float('def_regu.weight')
         # the reference gates on rayInfo[1] > 0 via .item(); the gate is kept but read once per garment
         host = getattr(self, '_ray_valid_host', None)
         if host is not None:
@@ -1164,6 +1170,7 @@ class HotLoop:
         else:
             n_valid = int(self._ray_valid[g_i])
         self.info.setdefault('rays_converged', []).append(n_valid)
+        sdfs = nx = rend_feat = None
         if n_valid > 0:
             # rows of the converged rays: their count is on the host already, so ONE index list of known size serves the five
             # gathers (`x[check]` would read its own count back five times: a host round trip each, in the middle of a phase the
@@ -1175,10 +1182,28 @@ class HotLoop:
             self.batch_inds[g_i] = batch_inds.index_select(0, idx)
             self.col_inds[g_i] = col_inds.index_select(0, idx)
             self.row_inds[g_i] = row_inds.index_select(0, idx)
+        if grad_loss is None:
+            if n_valid > 0:
+                n0 = nonmnfld.shape[0]
+                both = torch.cat([nonmnfld, self.TmpPs[g_i]], dim=0)
+                pred_all = net(both, ratio, jet=True)
+                feat_all = net.rendcond
+                grad_all = net.gradient(both, pred_all)
+                grad, sdfs, nx, rend_feat = grad_all[:n0], pred_all[n0:], grad_all[n0:], feat_all[n0:]
+            else:
+                pred = net(nonmnfld, ratio, jet=True, features=False)
+                grad = net.gradient(nonmnfld, pred)
+            grad_loss = ((grad.norm(2, dim=-1) - 1) ** 2).mean()                       # eikonal :1118
+        self.info['{}_grad_loss'.format(name)] = grad_loss.detach()
+        total_loss = total_loss + grad_loss * conf.get_float('grad_weight')
+        if def_term is not None:
+            total_loss = total_loss + def_term
+        if n_valid > 0:
             p, b = self.TmpPs[g_i], self.batch_inds[g_i]
-            sdfs = net(p, ratio, jet=True)
-            rend_feat = net.rendcond
-            nx = net.gradient(p, sdfs)           # = autograd.grad(sdfs, p, ones, create_graph=True) (:1169-1172)
+            if sdfs is None:
+                sdfs = net(p, ratio, jet=True)
+                rend_feat = net.rendcond
+                nx = net.gradient(p, sdfs)       # = autograd.grad(sdfs, p, ones, create_graph=True) (:1169-1172)
             onx = nx.detach()
             nx = nx / nx.norm(dim=1, keepdim=True)
             defconds = [d_cond, [poses, trans]]

@@ -1152,16 +1152,14 @@ class HotLoop:
             grad_loss = ((grad.norm(2, dim=-1) - 1) ** 2).mean()                       # eikonal :1118
         d_cond = d_cond_list[g_i + 1]
         def_term = None
+        def_pts = None
         if 'def_regu' in conf and conf.get_float('def_regu.weight') > 0.:               # :1135-1155
             pts = torch.cat([init_ps, _host_subset(TmpVs, surface_sample_points)], dim=0)
             pts = torch.cat([pts, utils.sample_points(pts, 1.8, 0.01, 0)], dim=0).view(1, -1, 3).expand(N, -1, 3)
-            pts = pts.contiguous().requires_grad_()
-            defVs = self.deformer.defs[0](pts, d_cond, ratio=ratio, offset_type=name, jet=True)
-            Jacobs = utils.compute_Jacobian(pts, defVs, True, True)
-            s = torch.log(singular_values_3x3(Jacobs))
-            def_loss = utils.GMRobustError((s * s).sum(1), conf.get_float('def_regu.c'), True).mean()
-            self.info['def_{}_loss'.format(name)] = def_loss.detach()
-            def_term = def_loss * conf.get_float('def_regu.weight')
+            def_pts = pts.contiguous().requires_grad_()
+            if not (merge and torch.device(dev).type == 'cuda'):
+                def_term = HotLoop._def_regu_term(self, name, def_pts, self.deformer.defs[0](def_pts, d_cond, ratio=ratio, offset_type=name,
+                                                                                    jet=True))
         # the reference gates on rayInfo[1] > 0 via .item(); the gate is kept but read once per garment
         host = getattr(self, '_ray_valid_host', None)
         if host is not None:
@@ -1182,6 +1180,16 @@ class HotLoop:
             self.batch_inds[g_i] = batch_inds.index_select(0, idx)
             self.col_inds[g_i] = col_inds.index_select(0, idx)
             self.row_inds[g_i] = row_inds.index_select(0, idx)
+        if def_pts is not None and def_term is None:
+            # the regulariser's points and the converged rays through the offset MLP as ONE jet pass too (same net, same code table;
+            # the reference calls it at :1143 and again inside compute_cardinal_rays :1176): the rays' block is parked on the net and
+            # served to the composite deformer's call below
+            tr = self.deformer.defs[0]
+            if n_valid > 0 and hasattr(tr, 'jet_two_blocks'):
+                defVs_r = tr.jet_two_blocks(def_pts, d_cond, self.TmpPs[g_i], self.batch_inds[g_i], ratio['deformerRatio'], name)
+            else:
+                defVs_r = tr(def_pts, d_cond, ratio=ratio, offset_type=name, jet=True)
+            def_term = HotLoop._def_regu_term(self, name, def_pts, defVs_r)
         if grad_loss is None:
             if n_valid > 0:
                 n0 = nonmnfld.shape[0]
@@ -1258,6 +1266,15 @@ class HotLoop:
             self.__dict__.setdefault('_prop_pre', {})[g_i] = (
                 p, onx, grad_d_p.detach() if grad_d_p is not None else None, _param_versions(net, self.deformer))
         return total_loss
+
+    def _def_regu_term(self, name, pts, defVs):
+        """The deformation regulariser (:1135-1155) from the offset MLP's output at `pts` (its Jacobian carried by the jet pass)."""
+        conf = self.conf
+        Jacobs = utils.compute_Jacobian(pts, defVs, True, True)
+        s = torch.log(singular_values_3x3(Jacobs))
+        def_loss = utils.GMRobustError((s * s).sum(1), conf.get_float('def_regu.c'), True).mean()
+        self.info['def_{}_loss'.format(name)] = def_loss.detach()
+        return def_loss * conf.get_float('def_regu.weight')
 
     def dct_poses_loss(self, poses, trans, frame_ids, N):
         if not (poses.requires_grad or trans.requires_grad) or self.conf.get_float('dct_weight') <= 0.:

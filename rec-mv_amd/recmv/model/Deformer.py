@@ -233,6 +233,12 @@ class MLPTranslator(nn.Module):
 def _translator_forward_jet(self, ps, conds, batch_inds, ratio, offset_type):
     """forward() with the Jacobian d out / d ps carried along (one C call): out._recmv_jac = (ps, I + J_offset)."""
     from ..chains import mlp_jet
+    pf = self.__dict__.pop('_jet_prefetch', None)
+    if pf is not None and pf[0] is ps and pf[2] is conds and pf[3] == ratio:
+        # these very points went through the net a moment ago as the second row block of jet_two_blocks()
+        out = pf[1]
+        self.offset[offset_type] = out - ps[..., :3]
+        return out
     ws = None if ratio is None else ([0.] * (self.multires * 2) if ratio <= 0 else
                                      annealing_weights(self.multires, ratio))
     flat = ps.reshape(-1, 3)
@@ -255,6 +261,35 @@ def _translator_forward_jet(self, ps, conds, batch_inds, ratio, offset_type):
     self.offset[offset_type] = out - ps[..., :3]
     out._recmv_jac = (ps, J + torch.eye(3, device=ps.device, dtype=J.dtype).view(1, 3, 3))
     return out
+
+
+def _translator_jet_two_blocks(self, pts, conds, ps, batch_inds, ratio, offset_type):
+    """ONE jet pass over two row blocks that go through this net with the same parameters and the same code table: `pts` [N, n, 3]
+    (frame-major blocks: row block i takes code i — forward(pts, conds, jet=True)) and `ps` [m, 3] with `batch_inds` (forward(ps,
+    conds, batch_inds, jet=True)).  Returns the first block's output (its Jacobian attached for utils.compute_Jacobian(pts, out));
+    the second block's output is parked and served to the next jet call on `ps` (CompositeDeformer.forward on the converged rays)."""
+    from ..chains import mlp_jet
+    ws = None if ratio is None else ([0.] * (self.multires * 2) if ratio <= 0 else
+                                     annealing_weights(self.multires, ratio))
+    cond2d = conds.reshape(-1, self.feature_vector_size)
+    n1 = pts.shape[0] * pts.shape[1]
+    cidx = torch.cat([torch.arange(cond2d.shape[0], device=pts.device).repeat_interleave(pts.shape[1]), batch_inds.view(-1)])
+    flat = torch.cat([pts.reshape(-1, 3), ps.reshape(-1, 3)], dim=0)
+    nl = self.num_layers - 1
+    lins = [getattr(self, "lin" + str(l)) for l in range(nl)]
+    Ws = [lin.weight for lin in lins]
+    bs = [lin.bias for lin in lins]
+    dims = [Ws[0].shape[1]] + [W.shape[0] for W in Ws]
+    y, J = mlp_jet(flat, cond2d, cidx.contiguous(), Ws, bs, dims, self.multires, ws, self.feature_vector_size, -1,
+                   ops.ACT_RELU, 0.0, True, 3, cond_blocks=0)
+    J = J + torch.eye(3, device=pts.device, dtype=J.dtype).view(1, 3, 3)
+    out1 = y[:n1].view(pts.shape)
+    out1._recmv_jac = (pts, J[:n1])
+    out2 = y[n1:].view(ps.shape)
+    out2._recmv_jac = (ps, J[n1:])
+    self.offset[offset_type] = out1 - pts[..., :3]
+    self.__dict__['_jet_prefetch'] = (ps, out2, conds, ratio)
+    return out1
 
 
 def _translator_chain(self, ratio):
@@ -309,6 +344,7 @@ def _cached_t(module, l, W):
 
 MLPTranslator.prepare_explicit = lambda self, cond, **kwargs: _translator_chain(self, kwargs['ratio']['deformerRatio'])
 MLPTranslator._forward_jet = _translator_forward_jet
+MLPTranslator.jet_two_blocks = _translator_jet_two_blocks
 MLPTranslator.forward_explicit = _translator_explicit
 MLPTranslator.backward_input = _translator_backward_input
 

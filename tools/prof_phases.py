@@ -46,21 +46,24 @@ def main():
         kj = ki
         busy, n = 0, 0
         per = collections.Counter()
+        pern = collections.Counter()
         while kj < len(kernels) and kernels[kj][1] <= re_:
             d = kernels[kj][2] - kernels[kj][1]
             busy += d
             n += 1
             per[short(kernels[kj][0])] += d
+            pern[short(kernels[kj][0])] += 1
             kj += 1
         ki = kj
         if seen[name] <= skip:
             continue
-        a = agg.setdefault(name, dict(count=0, wall=0, busy=0, launches=0, per=collections.Counter()))
+        a = agg.setdefault(name, dict(count=0, wall=0, busy=0, launches=0, per=collections.Counter(), pern=collections.Counter()))
         a["count"] += 1
         a["wall"] += re_ - rs
         a["busy"] += busy
         a["launches"] += n
         a["per"].update(per)
+        a["pern"].update(pern)
     print(f"# {path}  (first {skip} occurrence(s) of every phase skipped)")
     print(f"# {'phase':<22} {'n':>4} {'wall_ms/occ':>12} {'gpu_busy_ms/occ':>16} {'busy%':>6} {'launches/occ':>13}   top kernels (ms/occ)")
     for name, a in agg.items():
@@ -68,6 +71,8 @@ def main():
         top = ", ".join(f"{k.strip()}={v / c / 1e6:.2f}" for k, v in a["per"].most_common(14))
         print(f"{name[6:]:<22} {c:>4d} {a['wall'] / c / 1e6:>12.2f} {a['busy'] / c / 1e6:>16.2f} "
               f"{100.0 * a['busy'] / max(a['wall'], 1):>6.1f} {a['launches'] / c:>13.0f}   {top}")
+        if len(sys.argv) > 4 and sys.argv[4] == "counts":
+            print("    launches/occ by kernel: " + ", ".join(f"{k.strip()} x{v / c:.0f}" for k, v in a["pern"].most_common(30)))
 
 
 if __name__ == "__main__":

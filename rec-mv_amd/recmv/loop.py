@@ -1097,15 +1097,17 @@ class HotLoop:
         d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
         dev = self.device
         # The garments' terms are independent chains of small launches (jets on a few thousand points, the colour net, a tail of
-        # element-wise work) — forward AND backward, since autograd runs every node on the stream of its forward.  With
-        # RECMV_RENDER_STREAMS=1 the second garment's chain goes to the root finder's side stream (no new hardware queue), forked
-        # behind everything queued so far and joined before the sum (the host draws its random numbers in the same order either
-        # way, and every garment's terms are summed on their own first: the value does not depend on the schedule).  OFF by
-        # default: measured slower, 110-112 against 108 ms per iteration — the phase is paced by the host's read-backs (subset
-        # sizes, converged-ray counts), not by the device chain (tools/phase_overlap.py, profiles/r03_phase_overlap.txt).
+        # element-wise work) — forward AND backward, since autograd runs every node on the stream of its forward — and the backward
+        # of this loss is the tail of the iteration, one stream of dependent launches after both chains have joined.  The second
+        # garment's chain goes to the root finder's side stream (no new hardware queue), forked behind everything queued so far and
+        # joined before the sum (the host draws its random numbers in the same order either way, every garment's terms are summed
+        # on their own first, and the shared parameters' gradients are accumulated in the engine's order: 40 iterations bit-identical
+        # to the one-stream order and from run to run, tools/determinism_probe.py).  Round 3 measured this slower (the phase was
+        # paced by host read-backs then); with those gone and one jet pass per net it is worth 3-4 % of the iteration
+        # (tools/ab_interleaved.py render_streams, profiles/r04_ab_render_streams.txt).  RECMV_RENDER_STREAMS=0: one stream (A/B).
         side = None
         if (torch.device(dev).type == 'cuda' and self.garment_size > 1 and os.environ.get('RECMV_SERIAL') != '1'
-                and os.environ.get('RECMV_RENDER_STREAMS', '0') == '1'):
+                and os.environ.get('RECMV_RENDER_STREAMS', '1') != '0'):
             from .utils.FindSurfacePs import _streams
             base = torch.cuda.current_stream(dev)
             side = _streams(torch.device(dev), self.garment_size - 1)

@@ -1410,6 +1410,10 @@ class HotLoop:
     def propagateTmpPsGrad(self, frame_ids, ratio):
         """Implicit differentiation of the surface point p(theta, phi, z, cam) — OptimGarmentNetwork.py:2159-2313.
         The reference `return`s (not `continue`s) at the first garment without valid rays (:2165); kept."""
+        if (self.garment_size == 2 and os.environ.get('RECMV_PROP_JOINT', '1') != '0'
+                and all(self.TmpPs[g] is not None and self.TmpPs[g].grad is not None and self.TmpPs[g].is_cuda for g in range(2))
+                and HotLoop._propagate_joint(self, frame_ids, ratio)):
+            return
         for g_i in range(self.garment_size):
             name = self.garment_names[g_i]
             if self.TmpPs[g_i] is None or self.TmpPs[g_i].grad is None:
@@ -1477,6 +1481,82 @@ class HotLoop:
                 targets.append(c)
                 grads.append((-temp.sum(0)).view_as(c))
             _inject_gradients(targets, grads)
+
+    def _propagate_joint(self, frame_ids, ratio):
+        """propagateTmpPsGrad for BOTH garments as one block of rows wherever they share the arithmetic: the 3 x 3 algebra of the
+        implicit differentiation, the camera rays, and the pass through the deformer (one offset MLP and one skinner for both; a
+        row's code comes from the garments' code tables stacked) with ONE reverse sweep for the deformer's parameters and the
+        per-frame tensors.  The garment nets stay one pass each.  Same terms as the per-garment loop below (the sums over the two
+        garments' rows of the shared tensors' gradients are formed in one product instead of two and an add); half the launches of
+        a phase that sits in the host-paced tail of the iteration.  Returns False (nothing done) unless both garments' jets are at
+        hand from the render loss."""
+        G = 2
+        pre = getattr(self, '_prop_pre', {})
+        ps = [self.TmpPs[g] for g in range(G)]
+        for g in range(G):
+            h = pre.get(g)
+            if (h is None or h[0] is not ps[g] or h[2] is None
+                    or h[3] != _param_versions(self.garment_nets[g], self.deformer)):
+                return False
+        dev = ps[0].device
+        d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, dev)
+        cameras = self._cameras()
+        n = [int(p.shape[0]) for p in ps]
+        grad_l_p = torch.cat([p.grad for p in ps], dim=0)
+        col = torch.cat([self.col_inds[g] for g in range(G)]).view(-1, 1)
+        row = torch.cat([self.row_inds[g] for g in range(G)]).view(-1, 1)
+        v = cameras.view_rays(torch.cat([col, row, torch.ones_like(col)], dim=-1).float())
+        c = cameras.cam_pos()
+        grad_f_p = torch.cat([pre[g][1] for g in range(G)], dim=0)
+        grad_d_p = torch.cat([pre[g][2] for g in range(G)], dim=0)
+        vd = v.detach()
+        zeros = torch.zeros_like(vd[:, 0])
+        v_cross = torch.stack([torch.stack([zeros, -vd[:, 2], vd[:, 1]], -1),
+                               torch.stack([vd[:, 2], zeros, -vd[:, 0]], -1),
+                               torch.stack([-vd[:, 1], vd[:, 0], zeros], -1)], dim=1)       # [v]_x
+        a1 = (v_cross.unsqueeze(-1) * grad_d_p.unsqueeze(-3)).sum(-2)                       # v_cross @ J
+        b = torch.cat([grad_f_p.view(-1, 1, 3), a1], dim=1)                                 # [P,4,3]
+        btb = (b.unsqueeze(-1) * b.unsqueeze(-2)).sum(1)                                    # b^T b
+        btb_inv, check = Fast3x3Minv(btb.contiguous())
+        for g, name in enumerate(self.garment_names[:G]):
+            ck = check[:n[0]] if g == 0 else check[n[0]:]
+            self.info['{}_invInfo'.format(name)] = (ck.numel(), ck.sum())
+        rhs_1 = (btb_inv.unsqueeze(-1) * b.permute(0, 2, 1).unsqueeze(-3)).sum(-2)           # [P,3,4]
+        rhs_1 = (grad_l_p.view(-1, 3, 1) * rhs_1).sum(1, keepdim=True)                      # [P,1,4]
+        targets, grads = [], []
+        off = 0
+        for g in range(G):
+            net = self.garment_nets[g]
+            params = [q for q in net.parameters() if q.requires_grad]
+            if params:                     # frozen in the large-pose stage (OptimGarmentNetwork_Large_Pose.py:440-452)
+                pg = torch.autograd.grad(net(ps[g], ratio), params, -rhs_1[off:off + n[g], :, 0])
+                targets += params
+                grads += list(pg)
+            off += n[g]
+        params = [q for q in self.deformer.parameters() if q.requires_grad]
+        N = int(poses.shape[0])
+        b_all = torch.cat([self.batch_inds[g] for g in range(G)])
+        cidx = torch.cat([self.batch_inds[g] + N * g for g in range(G)])
+        tables = [d_cond_list[1 + g] for g in range(G)]
+        d = self.deformer(torch.cat(ps, dim=0), [torch.cat(tables, dim=0), [poses, trans]], b_all, ratio=ratio,
+                          offset_type=self.garment_names[G - 1], cond_index=cidx)
+        temp = -(rhs_1[:, :, -3:].transpose(1, 2) * v_cross).sum(1)                          # rhs[1:4] @ (-[v]_x)
+        opt_defconds = [t for t in tables + [poses, trans] if t.requires_grad]
+        pg = torch.autograd.grad(d, params + opt_defconds, temp)
+        targets += params + opt_defconds
+        grads += list(pg)
+        if v.requires_grad:
+            dc = d.detach() - c.detach().view(1, 3)
+            dc_cross = torch.stack([torch.stack([zeros, -dc[:, 2], dc[:, 1]], -1),
+                                    torch.stack([dc[:, 2], zeros, -dc[:, 0]], -1),
+                                    torch.stack([-dc[:, 1], dc[:, 0], zeros], -1)], dim=1)
+            targets.append(v)
+            grads.append((rhs_1[:, :, -3:].transpose(1, 2) * dc_cross).sum(1))
+        if c.requires_grad:
+            targets.append(c)
+            grads.append((-temp.sum(0)).view_as(c))
+        _inject_gradients(targets, grads)
+        return True
 
     # ------------------------------------------------------------------------------------------ one step
     def iters_per_epoch(self):

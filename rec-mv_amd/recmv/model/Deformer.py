@@ -210,7 +210,10 @@ class MLPTranslator(nn.Module):
             else:
                 ps = self.embed_fn(ps, annealing_weights(self.multires, ratio))
         if batch_inds is not None:
-            x = torch.cat([ps, ops.gather_rows(conds, batch_inds)], dim=1)       # deterministic backward
+            # `cond_index` (extension): row of the code table per point where it is not the frame index — the rows of several
+            # garments in one block take their codes from the garments' tables stacked (row = frame + N * garment)
+            cidx = kwargs.get('cond_index')
+            x = torch.cat([ps, ops.gather_rows(conds, batch_inds if cidx is None else cidx)], dim=1)       # deterministic backward
         else:
             x = torch.cat([ps, conds.view(-1, 1, self.feature_vector_size).expand(
                 -1, ps.shape[1], self.feature_vector_size)], dim=-1).view(-1, ps.shape[-1] + self.feature_vector_size)

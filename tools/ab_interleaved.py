@@ -37,6 +37,8 @@ def env_cfg(**kw):
 CONFIGS = {
     "render_streams": [("render-loss terms of both garments on the ray stream", env_cfg(RECMV_RENDER_STREAMS="0")),
                        ("second garment's render-loss terms on a side stream", env_cfg(RECMV_RENDER_STREAMS="1"))],
+    "prop_joint": [("propagateTmpPsGrad garment by garment", env_cfg(RECMV_PROP_JOINT="0")),
+                   ("propagateTmpPsGrad for both garments as one block of rows", env_cfg(RECMV_PROP_JOINT="1"))],
     "jets": [("two jet passes per net (RECMV_MERGE_JETS=0)", env_cfg(RECMV_MERGE_JETS="0")),
              ("one jet pass per net over eikonal points + converged rays", env_cfg(RECMV_MERGE_JETS="1"))],
     "rows": [("per-layer chains", rows_cfg(False)), ("rows 16, 2304..4096", rows_cfg(True, 2304, 4096, 1)),

@@ -788,8 +788,9 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
             g = gs[dom]
             ach = g["flops"] / g["seconds"]
             tr = pmc_traffic(dom + (" bf16x6" if args.gemm_mode == "bf16x6" else ""))
-            line["roofline"] = {"kernel": "recmv::" + dom + " (MFMA layer: GEMM + bias + activation epilogue; matrix mode " +
-                                          args.gemm_mode + ")",
+            what = ("weight-gradient product dW = dZ^T X, deterministic split-K, its reduction pass not included" if "gemm_tn" in dom
+                    else "MFMA layer: GEMM + bias + activation epilogue")
+            line["roofline"] = {"kernel": "recmv::" + dom + " (" + what + "; matrix mode " + args.gemm_mode + ")",
                                 "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": MFMA_F32_PEAK / 1e12,
                                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), "traffic": tr.get("traffic_bytes_per_launch") if tr else None,
                                 "traffic_source": tr.get("traffic_source") if tr else None,

@@ -59,7 +59,8 @@ def _compile(src: Path, force: bool, verbose: bool, hdr_mtime: float) -> Path:
             and obj.stat().st_mtime > hdr_mtime):
         return obj
     tmp = obj.with_suffix(f".o.tmp{os.getpid()}")
-    cmd = [hipcc(), *COMMON_FLAGS, "-c", str(src), "-o", str(tmp)]
+    extra = os.environ.get("RECMV_HIPCC_EXTRA", "").split()      # e.g. -DRECMV_ROWS_TIMING for tools/mlp_rows_clock.py
+    cmd = [hipcc(), *COMMON_FLAGS, *extra, "-c", str(src), "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -28,19 +28,36 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 256;          // 4 waves: one quarter of a layer's output columns each
+constexpr int kWaves = 8;              // two waves per SIMD: one issues MFMAs while the other waits for its weight fragments
+constexpr int kThreads = 64 * kWaves;  // each wave owns an eighth of a layer's output columns
 constexpr int kLD = 520;               // LDS row stride in floats (= 8 mod 64, >= 512 + 8)
 constexpr int kMaxWidth = 512;
 constexpr int kPeLD = 52;              // gamma(x) rows kept for the skip connection (3 + 6 * 8 = 51 max)
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 constexpr float kSqrt2 = 1.41421356237309504880f;
 
+// -DRECMV_ROWS_TIMING: thread 0 of workgroup 0 stamps the 100 MHz wall clock at the phase boundaries of a pass (read back
+// through recmv_debug_rows_clock, tools/mlp_rows_clock.py).  Not part of the shipped build.
+#ifdef RECMV_ROWS_TIMING
+__device__ long long g_clk[512];
+__device__ int g_clk_n;
+#define ROWS_STAMP()                                                     \
+  do {                                                                   \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g_clk_n < 512) {          \
+      g_clk[g_clk_n] = (long long)wall_clock64();                        \
+      g_clk_n = g_clk_n + 1;                                             \
+    }                                                                    \
+  } while (0)
+#else
+#define ROWS_STAMP() do { } while (0)
+#endif
+
 struct RowsLayer {
   const float* Wp;       // packed weights: [tile][chunk][lane][4]
   const float* bias;     // forward only
   int32_t N;             // valid output columns
   int32_t KC;            // chunks of 16 inputs (= chunk stride of a tile in the packed array)
-  int32_t TPW;           // 16-column tiles per wave (1, 2, 3, 4 or 8)
+  int32_t TPW;           // 16-column tiles per wave (1 .. 4)
   int32_t pad_;
 };
 
@@ -55,28 +72,41 @@ struct RowsArgs {
   float pe_w[32];
 };
 
+// Softplus is the hot activation (SDF net, offset MLP): straight-line code, both branches of the small-t split evaluated and
+// selected, so that the epilogue of a tile is one basic block.  The formulas are those of gemm_f32.hip's epilogue.
+__device__ __forceinline__ float softplus_fwd(float z, float p, float inv_p) {
+  const float zb = z * p;
+  const float t = __expf(-fabsf(zb));
+  const float series = t * (1.f - t * (0.5f - t * (0.33333334f - 0.25f * t)));
+  const float lg = __log2f(1.f + t) * 0.69314718f;          // 1 + t in [1, 2]: the bare v_log_f32, no range fix-ups
+  const float l = t < 0.015625f ? series : lg;
+  const float y = (fmaxf(zb, 0.f) + l) * inv_p;
+  return zb > 20.f ? z : y;
+}
+
+__device__ __forceinline__ float softplus_grad(float y, float p) {   // sigmoid(beta z) = 1 - exp(-beta y), series below 1/64
+  const float t = p * y;
+  const float series = t * (1.f - t * (0.5f - t * (0.16666667f - 0.041666668f * t)));
+  const float e = 1.f - __expf(-t);
+  return t < 0.015625f ? series : e;
+}
+
+// ACT: a compile-time activation (RECMV_ACT_SOFTPLUS) or -1 = look at the run-time value.
+template <int ACT>
 __device__ __forceinline__ float act_fwd(float z, int act, float p, float inv_p) {
+  if (ACT == RECMV_ACT_SOFTPLUS) return softplus_fwd(z, p, inv_p);
   if (act == RECMV_ACT_RELU) return z > 0.f ? z : 0.f;
-  if (act == RECMV_ACT_SOFTPLUS) {       // the epilogue formula of gemm_f32.hip (torch semantics, hardware exp2 / log2)
-    const float zb = z * p;
-    const float t = __expf(-fabsf(zb));
-    const float series = t * (1.f - t * (0.5f - t * (0.33333334f - 0.25f * t)));
-    const float l = t < 0.015625f ? series : __logf(1.f + t);
-    const float y = (fmaxf(zb, 0.f) + l) * inv_p;
-    return zb > 20.f ? z : y;
-  }
+  if (act == RECMV_ACT_SOFTPLUS) return softplus_fwd(z, p, inv_p);
   if (act == RECMV_ACT_TANH) return tanhf(z);
   return z;
 }
 
+template <int ACT>
 __device__ __forceinline__ float act_grad(float y, int act, float p) {   // act'(z) through y = act(z) (mlp_chain.hip)
+  if (ACT == RECMV_ACT_SOFTPLUS) return softplus_grad(y, p);
   switch (act) {
     case RECMV_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-    case RECMV_ACT_SOFTPLUS: {               // sigmoid(beta z) = 1 - exp(-beta y): dact_y of gemm_f32.hip (series below 1/64)
-      const float t = p * y;
-      const float series = t * (1.f - t * (0.5f - t * (0.16666667f - 0.041666668f * t)));
-      return t < 0.015625f ? series : 1.f - __expf(-t);
-    }
+    case RECMV_ACT_SOFTPLUS: return softplus_grad(y, p);
     case RECMV_ACT_TANH: return 1.f - y * y;
     default: return 1.f;
   }
@@ -145,44 +175,69 @@ __device__ __forceinline__ void tile_mma(const float* __restrict__ A, int KC, co
 // ------------------------------------------------------------------------------------------------ forward
 // Epilogue of a hidden layer: bias + activation (+ 1/sqrt2 in front of the skip concatenation) from the accumulators into the
 // other LDS buffer; columns >= N (tile padding) are written as zeros unless the encoding follows there.
-template <int TPW, int RT>
+template <int TPW, int RT, int ACT>
 __device__ __forceinline__ void hidden_layer(const RowsLayer& L, const float* __restrict__ in, float* __restrict__ outb, int wave,
                                              int lane, int act, float p, float inv_p, float scale, bool zero_pad) {
   f32x4 acc[RT][TPW];
+  float bv[TPW];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the bias travels under the products (one clamped, unconditional load per column tile)
+  if (L.bias) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int n = (wave * TPW + t) * 16 + (lane & 15);
+      bv[t] = L.bias[n < L.N ? n : L.N - 1];
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) bv[t] = 0.f;
+  }
   tile_mma<TPW, RT>(in, L.KC, L.Wp, L.KC, wave, lane, acc);
+  ROWS_STAMP();
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int n = (wave * TPW + t) * 16 + (lane & 15);
     const bool ok = n < L.N;
-    const float b = (ok && L.bias) ? L.bias[n] : 0.f;
+    // (behind the skip concatenation the columns past N belong to the encoding, written by the caller)
+    const bool store = ok || (zero_pad && n < kMaxWidth);
+    float v[RT][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = 16 * rt + 4 * (lane >> 4) + i;
-        const float v = act_fwd(acc[rt][t][i] + b, act, p, inv_p) * scale;
-        // (behind the skip concatenation the columns past N belong to the encoding, written by the caller)
-        if (ok) outb[r * kLD + n] = v;
-        else if (zero_pad && n < kMaxWidth) outb[r * kLD + n] = 0.f;
+        const float y = act_fwd<ACT>(acc[rt][t][i] + bv[t], act, p, inv_p) * scale;
+        v[rt][i] = ok ? y : 0.f;
       }
     }
+    if (store) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) outb[(16 * rt + 4 * (lane >> 4) + i) * kLD + n] = v[rt][i];
+      }
+    }
+  }
+}
+
+template <int RT, int ACT>
+__device__ __forceinline__ void run_hidden_act(const RowsLayer& L, const float* in, float* outb, int wave, int lane, int act,
+                                               float p, float inv_p, float scale, bool zero_pad) {
+  switch (L.TPW) {
+    case 1: hidden_layer<1, RT, ACT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    case 2: hidden_layer<2, RT, ACT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    case 3: hidden_layer<3, RT, ACT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
+    default: hidden_layer<4, RT, ACT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
   }
 }
 
 template <int RT>
 __device__ __forceinline__ void run_hidden(const RowsLayer& L, const float* in, float* outb, int wave, int lane, int act, float p,
                                            float inv_p, float scale, bool zero_pad) {
-  switch (L.TPW) {
-    case 1: hidden_layer<1, RT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
-    case 2: hidden_layer<2, RT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
-    case 3: hidden_layer<3, RT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
-    case 4: hidden_layer<4, RT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
-    default: hidden_layer<8, RT>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad); break;
-  }
+  if (act == RECMV_ACT_SOFTPLUS) run_hidden_act<RT, RECMV_ACT_SOFTPLUS>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad);
+  else run_hidden_act<RT, -1>(L, in, outb, wave, lane, act, p, inv_p, scale, zero_pad);
 }
 
 // x [P,3] -> out [P,n_out] (n_out <= 16): positional encoding (+ per-frame code) -> hidden layers -> last layer, one launch.
@@ -200,12 +255,13 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
   float* buf1 = smem + kR * kLD;
   float* pe = smem + 2 * kR * kLD;               // [kR][kPeLD] weighted gamma(x), unscaled
   float* xs = pe + kR * kPeLD;                   // [kR][4]
-  float* red = xs + kR * 4;                      // [4 waves][64 lanes][4] partial sums of the last layer
+  float* red = xs + kR * 4;                      // [kWaves][64 lanes][4] partial sums of the last layer
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * kR;
   const int L = a.multires, nf = 1 + 2 * L, d_pe = 3 * nf;
   const int n = a.n_layers;
 
+  ROWS_STAMP();
   if (tid < kR * 3) {
     const int r = tid / 3, c = tid - 3 * r;
     xs[r * 4 + c] = (row0 + r < P) ? x[(row0 + r) * 3 + c] : 0.f;
@@ -242,12 +298,14 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
     }
   }
   __syncthreads();
+  ROWS_STAMP();
   float* in = buf0;
   float* ob = buf1;
   const float p = a.act_param, inv_p = p != 0.f ? 1.f / p : 0.f;
   for (int l = 0; l + 1 < n; ++l) {
     const bool skip_next = (l + 1 == a.skip_layer);
     run_hidden<RT>(a.fwd[l], in, ob, wave, lane, a.hidden_act, p, inv_p, skip_next ? kInvSqrt2 : 1.f, !skip_next);
+    ROWS_STAMP();
     const int width = a.dims[l + 1];              // = N (+ d_pe behind the skip)
     if (skip_next) {
       for (int e = tid; e < kR * d_pe; e += kThreads) {
@@ -265,6 +323,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
       }
     }
     __syncthreads();
+    ROWS_STAMP();
     if (keep) {
       float* dst = acts + (int64_t)l * act_stride + row0 * ld_act;
       const int w4 = (width + 3) / 4;
@@ -273,11 +332,12 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
         *reinterpret_cast<float4*>(dst + (int64_t)r * ld_act + c) = *reinterpret_cast<const float4*>(ob + r * kLD + c);
       }
     }
+    ROWS_STAMP();
     float* t = in; in = ob; ob = t;
   }
   // ---- last layer, n_out <= 16 outputs: ONE column tile, its chunks dealt to the four waves, partial sums through LDS
   const RowsLayer& Ll = a.fwd[n - 1];
-  const int KC = Ll.KC, per = (KC + 3) / 4;
+  const int KC = Ll.KC, per = (KC + kWaves - 1) / kWaves;
   const int c0 = wave * per, c1 = (c0 + per < KC) ? c0 + per : KC;
   const f32x4* wpl = reinterpret_cast<const f32x4*>(Ll.Wp) + lane;
 #pragma unroll
@@ -298,9 +358,9 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 16 * rt + 4 * (lane >> 4) + i;
-        float v = red[lane * 4 + i] + red[(64 + lane) * 4 + i];
-        v += red[(128 + lane) * 4 + i];
-        v += red[(192 + lane) * 4 + i];
+        float v = red[lane * 4 + i];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += red[(64 * w + lane) * 4 + i];
         if (nn < n_out && row0 + r < P) {
           if (Ll.bias) v += Ll.bias[nn];
           if (a.residual) v += xs[r * 4 + nn];
@@ -317,41 +377,65 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
 //   park[r][c - n_act] = g[r][c] / sqrt2                                  for n_act <= c < n_act + d_pe (skip connection),
 // written to the other LDS buffer (zeros in the tile padding).  y_prev comes from the forward pass's workspace; it is requested
 // before the product so that it travels under the MFMAs.
-template <int TPW, int RT>
+template <int TPW, int RT, int ACT>
 __device__ __forceinline__ void reverse_layer(const RowsLayer& L, const float* __restrict__ in, float* __restrict__ outb,
                                               float* __restrict__ park, const float* __restrict__ yprev, int64_t ld_act, int n_act,
                                               int d_park, int wave, int lane, int act, float p, float y_scale, float out_scale) {
   f32x4 acc[RT][TPW];
   float yv[RT][TPW][4];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int c = (wave * TPW + t) * 16 + (lane & 15);
+    for (int t = 0; t < TPW; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (yprev) {                                     // clamped, unconditional: one basic block of loads in front of the products
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        yv[rt][t][i] = (yprev && c < n_act) ? yprev[(int64_t)(16 * rt + 4 * (lane >> 4) + i) * ld_act + c] : 0.f;
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int c = (wave * TPW + t) * 16 + (lane & 15);
+        const int cc = c < n_act ? c : n_act - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yv[rt][t][i] = yprev[(int64_t)(16 * rt + 4 * (lane >> 4) + i) * ld_act + cc];
+      }
     }
+  } else {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yv[rt][t][i] = 0.f;
   }
   tile_mma<TPW, RT>(in, L.KC, L.Wp, L.KC, wave, lane, acc);
+  const bool has_y = yprev != nullptr;
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int c = (wave * TPW + t) * 16 + (lane & 15);
+    const bool in_act = c < n_act;
+    const bool in_park = !in_act && c < n_act + d_park;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 16 * rt + 4 * (lane >> 4) + i;
         const float g = acc[rt][t][i];
-        if (c < n_act) {
-          outb[r * kLD + c] = yprev ? g * act_grad(yv[rt][t][i] * y_scale, act, p) * out_scale : g;
-        } else {
-          if (c < n_act + d_park) park[r * kPeLD + (c - n_act)] = g * kInvSqrt2;
-          if (c < kMaxWidth) outb[r * kLD + c] = 0.f;
-        }
+        const float d = has_y ? g * act_grad<ACT>(yv[rt][t][i] * y_scale, act, p) * out_scale : g;
+        if (in_park) park[r * kPeLD + (c - n_act)] = g * kInvSqrt2;
+        if (c < kMaxWidth) outb[r * kLD + c] = in_act ? d : 0.f;
       }
     }
+  }
+}
+
+template <int RT, int ACT>
+__device__ __forceinline__ void run_reverse_act(const RowsLayer& L, const float* in, float* outb, float* park, const float* yprev,
+                                                int64_t ld_act, int n_act, int d_park, int wave, int lane, int act, float p,
+                                                float y_scale, float out_scale) {
+  switch (L.TPW) {
+    case 1: reverse_layer<1, RT, ACT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    case 2: reverse_layer<2, RT, ACT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    case 3: reverse_layer<3, RT, ACT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
+    default: reverse_layer<4, RT, ACT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
   }
 }
 
@@ -359,13 +443,10 @@ template <int RT>
 __device__ __forceinline__ void run_reverse(const RowsLayer& L, const float* in, float* outb, float* park, const float* yprev,
                                             int64_t ld_act, int n_act, int d_park, int wave, int lane, int act, float p,
                                             float y_scale, float out_scale) {
-  switch (L.TPW) {
-    case 1: reverse_layer<1, RT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
-    case 2: reverse_layer<2, RT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
-    case 3: reverse_layer<3, RT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
-    case 4: reverse_layer<4, RT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
-    default: reverse_layer<8, RT>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale); break;
-  }
+  if (act == RECMV_ACT_SOFTPLUS)
+    run_reverse_act<RT, RECMV_ACT_SOFTPLUS>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale);
+  else
+    run_reverse_act<RT, -1>(L, in, outb, park, yprev, ld_act, n_act, d_park, wave, lane, act, p, y_scale, out_scale);
 }
 
 // gx [P,3] = J(x)^T g_out through the layers in reverse, from the activations mlp_rows_fwd_kernel(keep) left in `acts`.
@@ -409,7 +490,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_vjp_kernel(RowsArgs a, cons
         float v = 0.f;
         if (c < a.dims[n - 1]) {
           const float g = a.W_last[c];
-          if (c < n_act) v = g * act_grad(yprev[(int64_t)r * ld_act + c] * y_scale, a.hidden_act, p) * o_scale;
+          if (c < n_act) v = g * act_grad<-1>(yprev[(int64_t)r * ld_act + c] * y_scale, a.hidden_act, p) * o_scale;
           else if (c < n_act + d_pe) park[r * kPeLD + (c - n_act)] = g * kInvSqrt2;
         }
         in[r * kLD + c] = v;
@@ -484,8 +565,8 @@ __global__ __launch_bounds__(kThreads) void mlp_pack_kernel(const float* __restr
 
 inline int tpw_for(int N) {
   const int tiles = (N + 15) / 16;
-  const int per = (tiles + 3) / 4;
-  return per <= 4 ? (per < 1 ? 1 : per) : 8;
+  const int per = (tiles + kWaves - 1) / kWaves;
+  return per < 1 ? 1 : (per > 4 ? 4 : per);
 }
 
 struct PackPlan {
@@ -495,7 +576,7 @@ struct PackPlan {
 };
 
 inline int64_t packed_floats(int N, int K, bool whole_tiles_only) {
-  const int tiles = whole_tiles_only ? (N + 15) / 16 : tpw_for(N) * 4;
+  const int tiles = whole_tiles_only ? (N + 15) / 16 : tpw_for(N) * kWaves;
   return (int64_t)tiles * ((K + 15) / 16) * 256;
 }
 
@@ -560,7 +641,7 @@ void fill_args(const recmv_mlp* m, const float* packed, RowsArgs* a) {
   for (int i = 0; i < 32; ++i) a->pe_w[i] = m->pe_weights[i];
 }
 
-inline size_t fwd_lds(int rt) { return (size_t)(2 * 16 * rt * kLD + 16 * rt * kPeLD + 16 * rt * 4 + 4 * 64 * 4) * sizeof(float); }
+inline size_t fwd_lds(int rt) { return (size_t)(2 * 16 * rt * kLD + 16 * rt * kPeLD + 16 * rt * 4 + kWaves * 64 * 4) * sizeof(float); }
 inline size_t vjp_lds(int rt) { return (size_t)(2 * 16 * rt * kLD + 16 * rt * kPeLD + 16 * rt * 4) * sizeof(float); }
 
 inline int64_t pad16(int64_t v) { return (v + 15) / 16 * 16; }
@@ -592,6 +673,21 @@ RowsLayout rows_layout(const recmv_mlp* m, int64_t P) {
 }  // namespace recmv
 
 using namespace recmv;
+
+#ifdef RECMV_ROWS_TIMING
+extern "C" int recmv_debug_rows_clock(long long* out, int cap, int reset) {
+  int n = 0;
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_clk_n), sizeof(int));
+  if (n > cap) n = cap;
+  if (n > 0) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * n);
+  if (reset) {
+    const int zero = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_clk_n), &zero, sizeof(int));
+  }
+  return n;
+}
+#endif
 
 extern "C" int recmv_mlp_rows_supported(const recmv_mlp* m) { return rows_supported(m); }
 

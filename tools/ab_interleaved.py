@@ -42,7 +42,7 @@ CONFIGS = {
     "jets": [("two jet passes per net (RECMV_MERGE_JETS=0)", env_cfg(RECMV_MERGE_JETS="0")),
              ("one jet pass per net over eikonal points + converged rays", env_cfg(RECMV_MERGE_JETS="1"))],
     "rows": [("per-layer chains", rows_cfg(False)), ("rows 16, 2304..4096", rows_cfg(True, 2304, 4096, 1)),
-             ("rows 16, 1024..4096", rows_cfg(True, 1024, 4096, 1)), ("rows 32, 1500..8192", rows_cfg(True, 1500, 8192, 2)),
+             ("rows 16, 3328..4096", rows_cfg(True, 3328, 4096, 1)),
              ("rows 16 <= 4096 / 32 <= 8192, from 2304", rows_cfg(True, 2304, 8192, 0))],
 }
 

@@ -6,21 +6,22 @@
 // those passes as one launch per layer: at 3 k rows a 512 x 512 layer is ONE round of workgroups, a third of its 22 us is
 // launch ramp / first operand tile / epilogue / drain, and the activations travel through L2 between every two launches.
 //
-// Here ONE launch evaluates a whole pass.  A workgroup (4 waves) owns a tile of 16 rays for all layers:
+// Here ONE launch evaluates a whole pass.  A workgroup (8 waves) owns a tile of 16 rays for all layers:
 //   * the tile's activations stay in LDS (two buffers of 16 x 520 floats, ping-pong; the row stride of 520 = 8 mod 64 makes
 //     every ds_read_b128 of an A fragment conflict-free for the 16x16x4 lane map), positional encoding, per-frame code
 //     gather, skip concatenation, bias, activation, residual and — in the reverse pass — the activation gradient and the
 //     encoding's VJP are all done on the tile in place;
 //   * the weights are streamed from L2 straight into MFMA B fragments: recmv_mlp_pack lays every layer out ONCE per weight
 //     version in fragment order (tile of 16 outputs x chunk of 16 inputs = 64 lanes x 16 bytes = one fully coalesced 1 KB
-//     wave load, zero-padded, so the loop has no guards), each wave owns a quarter of the layer's output columns and keeps
-//     the next chunk's fragments in flight under the 32 MFMAs (1 024 cycles) of the current one;
+//     wave load, zero-padded, so the loop has no guards), each wave owns an eighth of the layer's output columns and keeps
+//     the next chunk's fragments in flight under the 16 MFMAs of the current one (two waves per SIMD take turns on the pipe);
 //   * v_mfma_f32_16x16x4_f32: exact f32 products and accumulation (an fma chain) like the layer kernels of gemm_f32.hip;
 //     the k order inside a chunk differs from theirs, so results agree to rounding, not bitwise.  Rows are independent: a
 //     ray gets the same bits whatever tile it sits in.
-// With 16-row tiles every weight element fetched feeds 16 rows — 8 FLOP per byte from L2, 32 B/clk/CU at the matrix
-// pipe's full rate — which is why this form is for the few-thousand-row passes only; recmv_mlp_forward keeps the
-// per-layer kernels above RECMV_MLP_ROWS_MAX rows.
+// With 16-row tiles every weight element fetched feeds 16 rows — 8 FLOP per byte from L2 — and between two layers the workgroup
+// runs its epilogue and a barrier with the matrix pipe idle (profiles/r04_mlp_rows_clock.txt: products at 77 % of the pipe, 63 %
+// over a pass), which is why this form is for the few-thousand-row passes only; recmv_mlp_forward keeps the per-layer kernels
+// above RECMV_MLP_ROWS_MAX rows.
 #include "common.h"
 
 namespace recmv {
@@ -148,7 +149,7 @@ __device__ __forceinline__ void chunk_mma(const Frag<TPW, RT>& f, bool live, f32
 
 // Two register sets, the loop unrolled by two: the fragments of chunk c + 1 are REQUESTED before the MFMAs of chunk c are issued
 // (the scheduling barriers keep the compiler from sinking the requests behind the matrix instructions), so a set has a whole chunk
-// (4 * TPW * RT MFMAs, >= 1 000 cycles at TPW = 8) to arrive.  No exit between a request and its use (a load whose only use sits
+// (4 * TPW * RT MFMAs, 512 cycles at TPW = 4, while the SIMD's other wave issues its own) to arrive.  No exit between a request and its use (a load whose only use sits
 // behind a branch gets sunk behind that branch): the trip count is rounded up to a pair, a chunk past the end re-requests the last
 // one and multiplies it by a zero A fragment.  (A ring of four sets measured the same, profiles/r04_mlp_rows_bench_v2.txt.)
 template <int TPW, int RT>
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void mlp_rows_fwd_kernel(RowsArgs a, cons
     ROWS_STAMP();
     float* t = in; in = ob; ob = t;
   }
-  // ---- last layer, n_out <= 16 outputs: ONE column tile, its chunks dealt to the four waves, partial sums through LDS
+  // ---- last layer, n_out <= 16 outputs: ONE column tile, its chunks dealt to the waves, partial sums through LDS
   const RowsLayer& Ll = a.fwd[n - 1];
   const int KC = Ll.KC, per = (KC + kWaves - 1) / kWaves;
   const int c0 = wave * per, c1 = (c0 + per < KC) ? c0 + per : KC;

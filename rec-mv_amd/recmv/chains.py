@@ -15,12 +15,12 @@ import torch
 from . import _lib as L
 
 # Passes of MLP_ROWS_MIN..MLP_ROWS_MAX rows run as ONE launch of the row-tile kernels (csrc/mlp_rows.hip).  A workgroup owns 16 rows,
-# so up to 4 096 rows are one round of workgroups on the 256 CUs and a pass takes the same ~385 us (SDF value + input gradient)
-# whatever the row count, where the per-layer chain takes 277 us at 2 048 rows, 364 at 3 072 and 450 at 4 096
-# (profiles/r04_mlp_rows_bench_v3.txt): the window below is where one launch is also the faster one.  What bounds the row-tile form
-# is the rate at which ONE CU takes weight lines from L2 (~21 B/clk against the 32 B/clk a 16-row tile needs at the matrix pipe's
-# full rate; 32-row workgroups halve the need and the CUs in use, and lose on latency) — DESIGN.md §4.  RECMV_MLP_ROWS=0 keeps the
-# per-layer chains everywhere; RECMV_MLP_ROWS_MIN / _MAX move the window (tools/ab_interleaved.py rows).
+# so up to 4 096 rows are one round of workgroups on the 256 CUs and a pass takes the same ~350 us (SDF value + input gradient)
+# whatever the row count, where the per-layer chain takes 278 us at 2 048 rows, 362 at 3 072 and 449 at 4 096
+# (profiles/r04_mlp_rows_bench_v5.txt): the window below is where one launch is also the faster one.  A layer's products run at 77 %
+# of the matrix pipe; the epilogue and the barrier between two layers (~4 us, pipe idle: one workgroup per CU at these row counts)
+# bring a pass to 63 % (profiles/r04_mlp_rows_clock.txt).  RECMV_MLP_ROWS=0 keeps the per-layer chains everywhere;
+# RECMV_MLP_ROWS_MIN / _MAX move the window (tools/ab_interleaved.py rows).
 MLP_ROWS_MIN = int(os.environ.get("RECMV_MLP_ROWS_MIN", "3328"))
 MLP_ROWS_MAX = int(os.environ.get("RECMV_MLP_ROWS_MAX", "4096"))
 if os.environ.get("RECMV_MLP_ROWS_RT"):        # rows per workgroup / 16 (recmv_set_mlp_rows_tile): 1, 2, or 0 = by row count

@@ -47,6 +47,16 @@ int recmv_inv3x3_forward(const void* ms, void* invs, uint8_t* checks, int64_t n,
 int recmv_inv3x3_backward(const void* grads, const void* invs, void* outs, int64_t n, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * A2. Deformation regulariser of the render loss: value and gradient of GM(sum_i log^2 sigma_i(J)) per matrix.
+ *   replaces the host SVD + its autograd of OptimGarmentNetwork.py:1143-1155
+ *            (Jacobs.cpu() -> torch.svd -> log -> utils.GMRobustError(., def_regu.c, True), utils/utils.py:87-91).
+ * J: [P,3,3] contiguous f32 (Jacobian of the offset MLP at the sampled points).  y: [P] = 2 x / c^2 / (x / c^2 + 4) with
+ * x = sum_i log^2 sigma_i;  gJ: [P,3,3] = dy/dJ (singular values below 1e-10 are clamped there: value from the bound, no gradient).
+ * The caller takes the mean and scales gJ in its backward pass.
+ * ---------------------------------------------------------------------------------------------- */
+int recmv_def_regu(const float* J, int64_t P, float c, float* y, float* gJ, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * C. GridSamplerMine — 3-D trilinear sampler, padding=border, align_corners=False, with first and
  * second derivative.
  *   replaces GridSamplerMine.forward / backward / dbackward

@@ -261,3 +261,18 @@ def alpha_composite_backward(idx, alphas, features, grad_images, need_grad_featu
                                                _p(ga), _p(gf))
     assert rc == 0
     return ga, gf
+
+
+# ------------------------------------------------------------------------------- deformation regulariser
+def def_regu(J: torch.Tensor, c: float):
+    """(y [P], dy/dJ [P,3,3]) of the reference's deformation regulariser, the way the reference computes it
+    (OptimGarmentNetwork.py:1143-1155): host torch.svd of the Jacobians, log of the singular values, sum of squares through
+    utils.GMRobustError(x, c, True) = 2 x / c^2 / (x / c^2 + 4) (utils/utils.py:87-91); the gradient by autograd through the SVD.
+    Evaluated in float64 whatever the input precision (the checker of recmv_def_regu)."""
+    Jd = _cpu(J).double().detach().requires_grad_(True)
+    _, s, _ = torch.svd(Jd)
+    s = torch.log(s)
+    x = (s * s).sum(1)
+    y = 2. * x / (c * c) / (x / (c * c) + 4)
+    g, = torch.autograd.grad(y.sum(), Jd)
+    return y.detach(), g

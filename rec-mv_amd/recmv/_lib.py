@@ -68,6 +68,7 @@ def _declare(lib):
         "recmv_last_error": (C.c_char_p, []),
         "recmv_inv3x3_forward": (C.c_int, [vp, vp, vp, i64, i32, vp]),
         "recmv_inv3x3_backward": (C.c_int, [vp, vp, vp, i64, i32, vp]),
+        "recmv_def_regu": (C.c_int, [vp, i64, C.c_float, vp, vp, vp]),
         "recmv_grid_sample3d_forward": (C.c_int, [vp, T5, vp, T5, vp, T5, i32, i32, i32, vp]),
         "recmv_grid_sample3d_backward": (C.c_int, [vp, T5, vp, T5, vp, T5, vp, T5, vp, i32, i32, i32, vp]),
         "recmv_grid_sample3d_dbackward": (C.c_int, [vp, T5, vp, T5, vp, T5, vp, T5, vp, T5, vp, T5, vp, vp, T5,

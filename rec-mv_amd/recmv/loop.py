@@ -1273,8 +1273,13 @@ class HotLoop:
         """The deformation regulariser (:1135-1155) from the offset MLP's output at `pts` (its Jacobian carried by the jet pass)."""
         conf = self.conf
         Jacobs = utils.compute_Jacobian(pts, defVs, True, True)
-        s = torch.log(singular_values_3x3(Jacobs))
-        def_loss = utils.GMRobustError((s * s).sum(1), conf.get_float('def_regu.c'), True).mean()
+        if Jacobs.is_cuda and Jacobs.dtype == torch.float32 and os.environ.get('RECMV_FUSED_REGU', '1') != '0':
+            # value and dy/dJ per matrix from one launch (csrc/def_regu.hip) instead of ~90 torch launches forward + backward
+            from .ops import def_regu
+            def_loss = def_regu(Jacobs, conf.get_float('def_regu.c')).mean()
+        else:
+            s = torch.log(singular_values_3x3(Jacobs))
+            def_loss = utils.GMRobustError((s * s).sum(1), conf.get_float('def_regu.c'), True).mean()
         self.info['def_{}_loss'.format(name)] = def_loss.detach()
         return def_loss * conf.get_float('def_regu.weight')
 

@@ -479,6 +479,37 @@ def weight_norm(v, g):
     return g * (v / v.norm(dim=1, keepdim=True))
 
 
+class DefRegu(torch.autograd.Function):
+    """y [P] = GM(sum_i log^2 sigma_i(J)) per 3x3 Jacobian — the deformation regulariser of OptimGarmentNetwork.py:1143-1155
+    (host torch.svd + log + utils.GMRobustError there) — with dy/dJ from the same launch (recmv_def_regu, csrc/def_regu.hip):
+    the backward pass is one scaling."""
+
+    @staticmethod
+    def forward(ctx, J, c):
+        Jc = J.detach().contiguous()
+        P = Jc.shape[0]
+        y = torch.empty(P, dtype=torch.float32, device=J.device)
+        gJ = torch.empty_like(Jc)
+        with L.device_guard(J.device):
+            L.check(L.lib().recmv_def_regu(L.ptr(Jc), P, float(c), L.ptr(y), L.ptr(gJ), L.stream_ptr(J.device)), "def_regu")
+        ctx.save_for_backward(gJ)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        gJ, = ctx.saved_tensors
+        return gJ * gy.view(-1, 1, 1), None
+
+
+def def_regu(J, c):
+    """Per-matrix regulariser value (see DefRegu); f32 CUDA [P,3,3] only."""
+    L.require_cuda(J, "J")
+    if J.dtype != torch.float32 or J.dim() != 3 or J.shape[1:] != (3, 3):
+        raise RuntimeError("recmv.ops.def_regu: expected a float32 [P,3,3] tensor")
+    return DefRegu.apply(J, c)
+
+
 class LinearAct(torch.autograd.Function):
     """y = act(x @ W^T + b), one fused kernel forward; backward of any order on the same kernels."""
 

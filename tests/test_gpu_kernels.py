@@ -837,3 +837,58 @@ def test_gemm_nt_mulgrad_equals_product_then_activation_gradient(M, N, K):
     L.check(L.lib().recmv_gemm_nt_mulgrad(L.ptr(A), K, L.ptr(B), K, L.ptr(out), N, M, N, K, L.ptr(Y - 0.025), N, ops.ACT_RELU,
                                           0.0, 1.0, 1.0, L.stream_ptr(A.device)), "gemm_nt_mulgrad")
     assert torch.equal(out, prod * ((Y - 0.025) > 0).float())
+
+
+# ------------------------------------------------------------------------------------------ deformation regulariser
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,spread", [(1, 0.3), (255, 0.3), (256, 0.05), (70001, 0.3), (4099, 1e-3)])
+def test_def_regu_value_and_gradient_match_the_host_svd(P, spread):
+    """recmv_def_regu (Jacobi eigen-decomposition of J^T J, analytic gradient) against the reference's own route — torch.svd on
+    the host, log, GMRobustError, autograd — in float64 (oracle.def_regu).  Jacobians around the identity (where a deformer
+    lives: nearly repeated singular values, the closed form's worst case) and far from it; the gradient also through the
+    autograd Function the loop calls."""
+    from oracle import oracle as orc
+    from recmv import ops
+    g = torch.Generator().manual_seed(P)
+    J = torch.eye(3).view(1, 3, 3) + spread * torch.randn(P, 3, 3, generator=g)
+    if P > 300:
+        J[7] = torch.eye(3)                                   # exact identity: x = 0, gradient 0
+        J[8] = torch.diag(torch.tensor([2.0, 2.0, 0.5]))      # a repeated singular value away from 1
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+        J[9] = q                                              # a rotation: all singular values 1
+    c = 0.01
+    y_ref, g_ref = orc.def_regu(J, c)
+    Jg = gpu(J).requires_grad_(True)
+    y = ops.def_regu(Jg, c)
+    w = gpu(torch.rand(P, generator=g) + 0.5)
+    (y * w).sum().backward()
+    # y in [0, 2): an f32 rounding of log(sigma) (1.5e-7 absolute near sigma = 1) moves x = sum log^2 by 3e-7 |log sigma| and y by
+    # at most 0.5 / c^2 of that — a few 1e-6 at c = 0.01
+    torch.testing.assert_close(y.detach().cpu(), y_ref.float(), rtol=2e-3, atol=2e-5)
+    g_ref_w = (g_ref * w.cpu().double().view(-1, 1, 1)).float()
+    err = (Jg.grad.cpu() - g_ref_w).abs()
+    scale = g_ref_w.abs().amax(dim=(1, 2), keepdim=True)
+    # dy/dJ ~ log(sigma) / c^2: an absolute rounding of 1e-7 in log(sigma) is 1e-3 of gradient at c = 0.01
+    assert bool((err <= 2e-3 * scale + 4e-3).all()), float((err - 2e-3 * scale).max())
+    if P > 300:
+        assert float(y[7]) == 0.0 and float(Jg.grad[7].abs().max()) == 0.0
+        assert float(y[9]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_def_regu_matches_the_torch_closed_form_the_loop_used():
+    """Same term as the ~90-launch torch form it replaces (singular_values_3x3 + GMRobustError), value of the mean and gradient,
+    on Jacobians of the size the loop sees."""
+    from recmv import ops, utils
+    from recmv.loop import singular_values_3x3
+    g = torch.Generator().manual_seed(11)
+    J = gpu(torch.eye(3).view(1, 3, 3) + 0.2 * torch.randn(6000, 3, 3, generator=g))
+    a = J.clone().requires_grad_(True)
+    b = J.clone().requires_grad_(True)
+    la = ops.def_regu(a, 0.01).mean()
+    s = torch.log(singular_values_3x3(b))
+    lb = utils.GMRobustError((s * s).sum(1), 0.01, True).mean()
+    la.backward()
+    lb.backward()
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    assert float((a.grad - b.grad).abs().max()) <= 2e-3 * float(b.grad.abs().max())

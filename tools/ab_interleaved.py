@@ -39,6 +39,8 @@ CONFIGS = {
                        ("second garment's render-loss terms on a side stream", env_cfg(RECMV_RENDER_STREAMS="1"))],
     "prop_joint": [("propagateTmpPsGrad garment by garment", env_cfg(RECMV_PROP_JOINT="0")),
                    ("propagateTmpPsGrad for both garments as one block of rows", env_cfg(RECMV_PROP_JOINT="1"))],
+    "fused_regu": [("deformation regulariser in ~90 torch launches (closed-form singular values)", env_cfg(RECMV_FUSED_REGU="0")),
+                   ("deformation regulariser: value + gradient from one launch (csrc/def_regu.hip)", env_cfg(RECMV_FUSED_REGU="1"))],
     "jets": [("two jet passes per net (RECMV_MERGE_JETS=0)", env_cfg(RECMV_MERGE_JETS="0")),
              ("one jet pass per net over eikonal points + converged rays", env_cfg(RECMV_MERGE_JETS="1"))],
     "rows": [("per-layer chains", rows_cfg(False)), ("rows 16, 2304..4096", rows_cfg(True, 2304, 4096, 1)),
@@ -74,26 +76,26 @@ def main():
             loop.step(it)
             it += 1
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
-            e0.record()
-            n_r = 0
-            for _ in range(block):
-                _, nr = loop.step(it)
-                n_r += int(nr)
+            for _ in range(block):                           # every iteration timed on its own: an epoch's short last batch (one
+                t0 = time.perf_counter()                     # frame instead of three, ~75 ms) is dropped below instead of
+                _, nr = loop.step(it)                        # landing in one configuration's mean
+                torch.cuda.synchronize()
+                acc[name].append((time.perf_counter() - t0) * 1e3)
+                rays[name].append(int(nr))
                 it += 1
-            e1.record()
-            torch.cuda.synchronize()
-            acc[name].append((time.perf_counter() - t0) * 1e3 / block)
-            rays[name].append(n_r / block)
-    print("# %d rounds x %d iterations per configuration, interleaved on one scene (settled 240 iterations on the first configuration); "
-          "ms per iteration (wall), mean / min, rays per iteration; MC vertices at the end %s" % (
-              rounds, block, [int(v.shape[0]) for v in loop.garment_vs]))
-    base = sum(acc[cfgs[0][0]]) / rounds
+    all_rays = sorted(r for v in rays.values() for r in v)
+    full = 0.8 * all_rays[len(all_rays) // 2]
+    print("# %d rounds x %d iterations per configuration, interleaved on one scene (settled 240 iterations on the first configuration, "
+          "no re-mesh afterwards); ms per iteration (wall, synchronised after every iteration); iterations on an epoch's short last "
+          "batch (rays < %.0f) left out; MC vertices at the end %s" % (rounds, block, full, [int(v.shape[0]) for v in loop.garment_vs]))
+    kept = {name: [t for t, r in zip(acc[name], rays[name]) if r >= full] for name, _ in cfgs}
+    base = sum(kept[cfgs[0][0]]) / len(kept[cfgs[0][0]])
     for name, _ in cfgs:
-        v = acc[name]
-        print("%-44s %8.2f ms  (min %7.2f)  %+5.1f %%   rays %.0f   per round: %s" % (
-            name, sum(v) / len(v), min(v), (sum(v) / len(v) / base - 1) * 100, sum(rays[name]) / len(v), " ".join("%.1f" % x for x in v)))
+        v = sorted(kept[name])
+        mean = sum(v) / len(v)
+        print("%-44s mean %8.2f ms   median %7.2f   min %7.2f   %+5.1f %%   (%d iterations, rays %.0f)" % (
+            name, mean, v[len(v) // 2], v[0], (mean / base - 1) * 100, len(v),
+            sum(r for r in rays[name] if r >= full) / len(v)))
 
 
 if __name__ == "__main__":

@@ -123,3 +123,32 @@ def test_interp2x_equals_interpolate(oracle, dtype):
     F.interpolate(xx, size=(D, H, W), mode="trilinear", align_corners=True).backward(go)
     gi = oracle.interp2x_backward(go)
     torch.testing.assert_close(gi, xx.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_def_regu_oracle_against_the_reference_gm_output_and_finite_differences(oracle):
+    """oracle.def_regu (the checker of recmv_def_regu) pinned: (i) its Geman-McClure stage against the REFERENCE's own
+    utils.GMRobustError output stored in tests/golden/misc.npz (J = diag(e^sqrt(x), 1, 1) has sum log^2 sigma = x exactly),
+    (ii) its gradient against central differences of its own value in float64."""
+    import numpy as np
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "misc.npz")
+    x = torch.from_numpy(g["gm_x"]).double().abs().reshape(-1)
+    J = torch.zeros(x.numel(), 3, 3, dtype=torch.float64)
+    J[:, 0, 0] = torch.exp(torch.sqrt(x))
+    J[:, 1, 1] = 1.0
+    J[:, 2, 2] = 1.0
+    y, _ = oracle.def_regu(J, 0.01)
+    ref = torch.from_numpy(g["gm_true"]).double().reshape(-1)
+    keep = torch.from_numpy(g["gm_x"]).double().reshape(-1) >= 0          # (the fixture's x may be signed: GM(x, square) is not even)
+    torch.testing.assert_close(y[keep], ref[keep], rtol=1e-6, atol=1e-9)
+    gen = torch.Generator().manual_seed(3)
+    A = torch.eye(3, dtype=torch.float64) + 0.2 * torch.randn(5, 3, 3, generator=gen, dtype=torch.float64)
+    _, grad = oracle.def_regu(A, 0.3)
+    h = 1e-6
+    for i in range(3):
+        for j in range(3):
+            Ap, Am = A.clone(), A.clone()
+            Ap[:, i, j] += h
+            Am[:, i, j] -= h
+            fd = (oracle.def_regu(Ap, 0.3)[0] - oracle.def_regu(Am, 0.3)[0]) / (2 * h)
+            torch.testing.assert_close(grad[:, i, j], fd, rtol=1e-5, atol=1e-8)

@@ -488,6 +488,16 @@ def whole_step_matrix_rate(roofline, steps, ms_per_step):
             "note": "all MFMA launches of the timed region on rank 0 (every variant, both GEMM kernels) over the whole step time"}
 
 
+def frames_at(loop, it):
+    """Frames this rank takes in optimiser iteration `it`: batch_size, except at an epoch's last position (the reference's DataLoader
+    keeps the short last batch, HotLoop.iters_per_epoch) — an iteration on one frame instead of three is ~25 % cheaper."""
+    from recmv.loop import _n_frames
+    pos = it % loop.iters_per_epoch()
+    per_it = loop.batch_size * loop.world_size
+    n = max(min(per_it, _n_frames(loop.dataset) - pos * per_it), loop.world_size)
+    return min(len(range(loop.rank, n, loop.world_size)), loop.batch_size)
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -640,6 +650,7 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
     converged = 0
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if on_gpu else None
     remesh_steps = []
+    frames_hist = []
     rdist.barrier()
     sync()
     t0 = time.perf_counter()
@@ -648,6 +659,7 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
     for k in range(args.steps):
         if loop.forward_time % loop.remesh_intersect == 0:
             remesh_steps.append(k)
+        frames_hist.append(frames_at(loop, it))
         _, r = loop.step(it, allreduce)
         if marks:
             marks[k + 1].record()
@@ -780,6 +792,10 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                 "rays_per_iter": int(loop.info.get('rays_total', 0)),
                 "rays_converged_per_iter": round(converged / max(args.steps, 1), 1),
                 "settle_iters": args.settle_iters,
+                "short_batches_in_timed_region": "%d of %d steps on fewer than %d frames (an epoch's last position: %d frames / %d per "
+                                                 "step, kept like the reference's DataLoader)" % (
+                    sum(1 for f in frames_hist if f < loop.batch_size), len(frames_hist), loop.batch_size,
+                    loop.dataset.F if hasattr(loop.dataset, "F") else -1, loop.batch_size * world),
                 "surface_pixels_last_iter": loop.info.get('surface_pixels'),
             },
         }

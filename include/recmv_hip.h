@@ -239,6 +239,17 @@ int recmv_gemm_nt_mulgrad_seg(const float* A, int64_t lda, const float* B, const
  * issues the six bf16 MFMA products of weight >= 2^-18 with f32 accumulation (f32-level accuracy, up to 2.7x the f32
  * matrix rate).  Returns the previous mode. */
 int recmv_set_gemm_mode(int mode);
+int recmv_get_gemm_mode(void);
+/* bf16x6 mode, weights split ONCE: recmv_b3_split writes the three bf16 planes [3][N][Kp] (Kp = K rounded up to 32, zero-padded) of
+ * a weight matrix B [N][K] (row stride ldb, K % 8 == 0, 16-byte aligned rows) into `planes` (recmv_b3_planes_bytes(N, K) bytes,
+ * owned by the caller) and remembers them under B's address; the large bf16x6 products (recmv_gemm_nt and everything built on it,
+ * with this B, K and ldb, N rows or fewer) then read the pieces instead of splitting B's tile in every row tile — same pieces, same
+ * products, same order: bit-identical results.  The caller keeps B's contents unchanged while the entry exists and calls
+ * recmv_b3_forget(B) before B or `planes` is freed.  (The weights of the reference are nn.Linear parameters under weight_norm,
+ * model/network.py:49-86: re-normalised once per pass, read by every product of the pass.) */
+int64_t recmv_b3_planes_bytes(int64_t N, int64_t K);
+int recmv_b3_split(const float* B, int64_t ldb, int64_t N, int64_t K, void* planes, int64_t planes_bytes, void* stream);
+int recmv_b3_forget(const float* B);
 int64_t recmv_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb,
                   float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,

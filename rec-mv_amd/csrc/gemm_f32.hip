@@ -20,6 +20,7 @@
 // FLOPs: 2*M*N*K.  With K=N=512 the arithmetic intensity is 128 FLOP/B >> 157e12/8e12, so every layer
 // is MFMA-bound, not HBM-bound.
 #include <mutex>
+#include <unordered_map>
 #include <type_traits>
 #include <vector>
 #include "common.h"
@@ -568,13 +569,26 @@ void gemm_nt_occ_kernel(const float* __restrict__ A, int64_t lda, const float* _
 // slots (about 6 non-MFMA instructions per MFMA across the two co-resident waves), not by latency.
 __device__ __forceinline__ int b3_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-template <int T, bool AMUL>
+// PRE: the B operand (a weight matrix, re-read by every row tile of every launch of an optimiser step) arrives already split —
+// three bf16 planes [3][rows][Kp] (Kp = K rounded up to a K-tile, zero-padded) written once per weight version by
+// recmv_b3_split with the SAME split8 as the staging path, so the pieces, the products and their order are those of the in-loop
+// split (bit-identical results).  The B half of the split's VALU (44 per 8 elements) leaves the loop, which is bound by its issue
+// slots; a thread's three 16-byte plane chunks of K-tile kt + 2 are requested behind the LDS stores of tile kt + 1 and stored one
+// K-tile later.
+struct B3Pre {
+  const char* planes;        // first weight set
+  const char* planes2;       // second weight set (row-segmented launches), or NULL
+  int64_t plane_bytes, plane_bytes2;
+  int Kp;
+};
+
+template <int T, bool AMUL, bool PRE>
 __global__ __launch_bounds__(kBlk, 2) void gemm_nt_b3_kernel(const float* __restrict__ A, int64_t lda,
                                                              const float* __restrict__ B, int64_t ldb,
                                                              const float* __restrict__ bias, float* __restrict__ C,
                                                              int64_t ldc, int M, int N, int K, int act,
                                                              float act_param, float out_scale, int nbm, int nbn,
-                                                             bool c_vec, AMul am) {
+                                                             bool c_vec, AMul am, B3Pre pre) {
   constexpr int TBM = 64 * T, TBN = 64 * T, WT = 32 * T;
   constexpr int NI = TBM * 4 / kBlk;            // (row, 8-k chunk) items per thread and operand: 2 or 1
   constexpr int PLANE = TBM * 64;               // bytes of one plane of one operand tile
@@ -587,9 +601,13 @@ __global__ __launch_bounds__(kBlk, 2) void gemm_nt_b3_kernel(const float* __rest
   const int64_t logical = xcd_remap(blockIdx.x, (int64_t)nbm * nbn);
   const int tile_m = (int)(logical / nbn), tile_n = (int)(logical % nbn);
   const int m0 = tile_m * TBM, n0 = tile_n * TBN;
+  const char* planes = pre.planes;
+  int64_t plane_bytes = pre.plane_bytes;
   if (am.B2 && m0 >= am.split) {              // second weight set for the rows of the second net (see AMul)
     B = am.B2;
     bias = am.bias2;
+    planes = pre.planes2;
+    plane_bytes = pre.plane_bytes2;
   }
 
   f32x16 acc[T][T];
@@ -604,6 +622,7 @@ __global__ __launch_bounds__(kBlk, 2) void gemm_nt_b3_kernel(const float* __rest
   u32x4 sa[NI][3], sb[NI][3];
   const float* pa[NI];
   const float* pb[NI];
+  const char* pq[NI];
   const float* py[NI];
   int soff[NI];
 #pragma unroll
@@ -615,6 +634,7 @@ __global__ __launch_bounds__(kBlk, 2) void gemm_nt_b3_kernel(const float* __rest
     gn = gn < N ? gn : N - 1;
     pa[r] = A + (int64_t)gm * lda + ch * 8;
     pb[r] = B + (int64_t)gn * ldb + ch * 8;
+    if (PRE) pq[r] = planes + ((int64_t)gn * pre.Kp + ch * 8) * 2;
     if (AMUL) py[r] = am.Y + (int64_t)gm * am.ldy + ch * 8;
     soff[r] = b3_off(row, ch);
   }
@@ -657,6 +677,12 @@ __global__ __launch_bounds__(kBlk, 2) void gemm_nt_b3_kernel(const float* __rest
     }
   };
 #undef RECMV_KEEP4
+  auto load_b_pre = [&](int t) __attribute__((always_inline)) {      // pieces of K-tile t straight into the store registers
+#pragma unroll
+    for (int r = 0; r < NI; ++r)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) sb[r][p] = *reinterpret_cast<const u32x4*>(pq[r] + p * plane_bytes + (int64_t)t * (BK * 2));
+  };
   auto split_a = [&](auto set_c) __attribute__((always_inline)) {
     constexpr int S = decltype(set_c)::value;
 #pragma unroll
@@ -742,15 +768,15 @@ __global__ __launch_bounds__(kBlk, 2) void gemm_nt_b3_kernel(const float* __rest
       __builtin_amdgcn_sched_barrier(0);
       reads(0);
       split_a(S0{});
-      split_b();
+      if (!PRE) split_b();
       if (decltype(whole_c)::value || kt + 2 < nk) {
         load_a(S0{}, whole_c, kt + 2);
-        load_b(whole_c, kt + 2);
+        if (!PRE) load_b(whole_c, kt + 2);
       }
       mfmas();
       if (decltype(whole_c)::value) {
-        pattern(std::integral_constant<int, 8>{});
-        __builtin_amdgcn_sched_group_barrier(0x020, (AMUL ? 6 : 4) * NI, 0);
+        pattern(std::integral_constant<int, PRE ? 4 : 8>{});
+        __builtin_amdgcn_sched_group_barrier(0x020, ((AMUL ? 4 : 2) + (PRE ? 0 : 2)) * NI, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       reads(1);
@@ -759,15 +785,18 @@ __global__ __launch_bounds__(kBlk, 2) void gemm_nt_b3_kernel(const float* __rest
       __syncthreads();
       lstore();
       __syncthreads();
+      if (PRE && (decltype(whole_c)::value || kt + 2 < nk)) load_b_pre(kt + 2);
     };
     load_a(S0{}, No{}, 0);
-    load_b(No{}, 0);
+    if (PRE) load_b_pre(0);
+    else load_b(No{}, 0);
     split_a(S0{});
-    split_b();
+    if (!PRE) split_b();
     lstore();
     if (nk > 1) {
       load_a(S0{}, No{}, 1);
-      load_b(No{}, 1);
+      if (PRE) load_b_pre(1);
+      else load_b(No{}, 1);
     }
     __syncthreads();
     int kt = 0;
@@ -806,6 +835,27 @@ __global__ __launch_bounds__(kBlk, 2) void gemm_nt_b3_kernel(const float* __rest
       break;
     default:
       nt_epilogue<T, RECMV_ACT_NONE>(Cs, bias, C, ldc, M, N, m0, n0, act_param, out_scale, c_vec, AMUL ? AMul{nullptr, 0, 0, 0.f, 1.f, 1.f} : am);
+  }
+}
+
+// B [N][K] f32 (row stride ldb, K % 8 == 0) -> planes [3][N][Kp] bf16 (h, m, l of split8), zero beyond K.
+__global__ __launch_bounds__(kBlk) void b3_split_kernel(const float* __restrict__ B, int64_t ldb, int64_t N, int K, int Kp,
+                                                        char* __restrict__ planes) {
+  const int c8 = Kp / 8;
+  const int64_t items = N * c8, plane_bytes = N * (int64_t)Kp * 2;
+  for (int64_t e = (int64_t)blockIdx.x * kBlk + threadIdx.x; e < items; e += (int64_t)gridDim.x * kBlk) {
+    const int64_t row = e / c8;
+    const int k = (int)(e - row * c8) * 8;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (k < K) {                                    // (K % 8 == 0: a chunk is entirely inside or outside)
+      a = *reinterpret_cast<const float4*>(B + row * ldb + k);
+      b = *reinterpret_cast<const float4*>(B + row * ldb + k + 4);
+    }
+    const Pieces p = split8(a, b);
+    char* o = planes + (row * Kp + k) * 2;
+    *reinterpret_cast<u32x4*>(o) = __builtin_bit_cast(u32x4, p.h);
+    *reinterpret_cast<u32x4*>(o + plane_bytes) = __builtin_bit_cast(u32x4, p.m);
+    *reinterpret_cast<u32x4*>(o + 2 * plane_bytes) = __builtin_bit_cast(u32x4, p.l);
   }
 }
 
@@ -1453,23 +1503,51 @@ static int launch_nt_occ(const float* A, int64_t lda, const float* B, int64_t ld
   return check_launch("gemm_nt(occ)");
 }
 
-template <int T, bool AMUL>
-static int launch_nt_b3(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
-                        int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
-                        bool c_vec, const AMul& am, hipStream_t stream) {
+// Weight matrices whose bf16 planes exist (recmv_b3_split), by the address the products get them under.
+struct B3Entry {
+  const char* planes;
+  int64_t N, K, ldb, Kp;
+};
+static std::mutex g_b3_mu;
+static std::unordered_map<const float*, B3Entry> g_b3;
+static bool b3_lookup(const float* B, int64_t N, int64_t K, int64_t ldb, B3Entry* out) {
+  std::lock_guard<std::mutex> lock(g_b3_mu);
+  auto it = g_b3.find(B);
+  if (it == g_b3.end() || it->second.K != K || it->second.ldb != ldb || it->second.N < N) return false;
+  *out = it->second;
+  return true;
+}
+
+template <int T, bool AMUL, bool PRE>
+static int launch_nt_b3_as(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
+                           int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale, bool c_vec, const AMul& am,
+                           const B3Pre& pre, hipStream_t stream) {
   constexpr int lds_ops = 6 * 64 * T * 64, lds_c = 64 * T * (64 * T + 4) * 4;
   constexpr int lds = lds_ops > lds_c ? lds_ops : lds_c;
   static bool attr_set = false;
   if (!attr_set) {
-    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_b3_kernel<T, AMUL>,
+    RECMV_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_b3_kernel<T, AMUL, PRE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   const int nbm = (int)ceil_div(M, 64 * T), nbn = (int)ceil_div(N, 64 * T);
   ScopedLaunchTimer timer((T - 1) + 2 + 4 * (AMUL ? 1 : 0), 2.0 * M * N * K, stream);
-  hipLaunchKernelGGL((gemm_nt_b3_kernel<T, AMUL>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds, stream, A, lda,
-                     B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, c_vec, am);
+  hipLaunchKernelGGL((gemm_nt_b3_kernel<T, AMUL, PRE>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds, stream, A, lda,
+                     B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, c_vec, am, pre);
   return check_launch("gemm_nt(b3)");
+}
+
+template <int T, bool AMUL>
+static int launch_nt_b3(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
+                        int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
+                        bool c_vec, const AMul& am, hipStream_t stream) {
+  B3Entry e, e2;
+  if (b3_lookup(B, N, K, ldb, &e) && (!am.B2 || (b3_lookup(am.B2, N, K, ldb, &e2) && e2.Kp == e.Kp))) {
+    B3Pre pre = {e.planes, am.B2 ? e2.planes : nullptr, e.N * e.Kp * 2, am.B2 ? e2.N * e2.Kp * 2 : 0, (int)e.Kp};
+    return launch_nt_b3_as<T, AMUL, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, c_vec, am, pre, stream);
+  }
+  B3Pre none = {nullptr, nullptr, 0, 0, 0};
+  return launch_nt_b3_as<T, AMUL, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, c_vec, am, none, stream);
 }
 
 constexpr int kNarrowLds = 2 * (64 + 32) * LDK * 4;   // 27648 B
@@ -1539,6 +1617,39 @@ extern "C" int recmv_set_gemm_mode(int mode) {
   const int prev = g_gemm_mode;
   if (mode == 0 || mode == 1) g_gemm_mode = mode;
   return prev;
+}
+
+extern "C" int recmv_get_gemm_mode(void) { return g_gemm_mode; }
+
+extern "C" int64_t recmv_b3_planes_bytes(int64_t N, int64_t K) {
+  if (N <= 0 || K <= 0) return 0;
+  return 3 * N * (ceil_div(K, (int64_t)BK) * BK) * 2;
+}
+
+extern "C" int recmv_b3_split(const float* B, int64_t ldb, int64_t N, int64_t K, void* planes, int64_t planes_bytes, void* stream) {
+  RECMV_REQUIRE(B && planes, "b3_split: NULL pointer");
+  RECMV_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldb >= K && ldb % 4 == 0 && aligned16(B) && aligned16(planes),
+                "b3_split: needs K %% 8 == 0 and 16-byte aligned rows (N=%lld K=%lld ldb=%lld)", (long long)N, (long long)K,
+                (long long)ldb);
+  RECMV_REQUIRE(K < (1ll << 30) && N < (1ll << 31), "b3_split: size overflow");
+  const int64_t Kp = ceil_div(K, (int64_t)BK) * BK;
+  RECMV_REQUIRE(planes_bytes >= 3 * N * Kp * 2, "b3_split: planes buffer %lld < %lld bytes", (long long)planes_bytes,
+                (long long)(3 * N * Kp * 2));
+  hipLaunchKernelGGL(b3_split_kernel, dim3(stream_grid(N * (Kp / 8), kBlk)), dim3(kBlk), 0, (hipStream_t)stream, B, ldb, N, (int)K,
+                     (int)Kp, (char*)planes);
+  {
+    const int rc = check_launch("b3_split");
+    if (rc) return rc;
+  }
+  std::lock_guard<std::mutex> lock(g_b3_mu);
+  g_b3[B] = B3Entry{(const char*)planes, N, K, ldb, Kp};
+  return RECMV_OK;
+}
+
+extern "C" int recmv_b3_forget(const float* B) {
+  std::lock_guard<std::mutex> lock(g_b3_mu);
+  g_b3.erase(B);
+  return RECMV_OK;
 }
 
 extern "C" int recmv_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,

@@ -13,6 +13,8 @@ Jacobian — all built with create_graph=True) come from torch's autograd of tho
 from __future__ import annotations
 
 import ctypes as C
+import os
+import weakref
 
 import torch
 
@@ -28,6 +30,36 @@ def _ws_key(dev):
     return (dev.index, L.raw_stream(dev))
 
 
+def _forget_split(ptr):
+    try:
+        L.lib().recmv_b3_forget(ptr)
+    except Exception:                      # interpreter shutdown
+        pass
+
+
+def presplit(W):
+    """bf16x6 matrix mode only: split the weight matrix W [N,K] (contiguous, a fresh tensor per weight version — the output of the
+    weight normalisation or its transpose) into its three bf16 planes ONCE (recmv_b3_split) so that the large products read the
+    pieces instead of splitting W's tile again in every row tile of every launch.  The planes live on W (`_recmv_b3`) and the
+    registration ends with W (weakref.finalize -> recmv_b3_forget).  RECMV_B3_PRESPLIT=0 keeps the in-loop split (A/B)."""
+    lib = L.lib()
+    if (not W.is_cuda or W.dtype != torch.float32 or W.dim() != 2 or lib.recmv_get_gemm_mode() != 1
+            or os.environ.get('RECMV_B3_PRESPLIT', '1') == '0'):
+        return W
+    N, K = W.shape
+    if K % 8 != 0 or N < 64 or not W.is_contiguous() or W.data_ptr() % 16 != 0 or getattr(W, '_recmv_b3', None) is not None:
+        return W
+    planes = torch.empty(int(lib.recmv_b3_planes_bytes(N, K)), dtype=torch.uint8, device=W.device)
+    with L.device_guard(W.device):
+        L.check(lib.recmv_b3_split(L.ptr(W), K, N, K, L.ptr(planes), planes.numel(), L.stream_ptr(W.device)), "b3_split")
+    try:
+        W._recmv_b3 = planes
+        weakref.finalize(W, _forget_split, W.data_ptr())
+    except Exception:
+        lib.recmv_b3_forget(L.ptr(W))
+    return W
+
+
 def transposed(W):
     """Contiguous W^T, cached on the tensor object for as long as its data is unchanged.  The cache is shared by every
     stream that differentiates through W in an iteration (mask loss, curve branch, render loss): it keeps the event
@@ -37,7 +69,7 @@ def transposed(W):
         if hit[2] is not None and L.raw_stream(W.device) != hit[3]:
             torch.cuda.current_stream(W.device).wait_event(hit[2])
         return hit[1]
-    Wt = W.detach().t().contiguous()
+    Wt = presplit(W.detach().t().contiguous())
     ev = sid = None
     if W.is_cuda:
         ev = torch.cuda.Event()
@@ -456,7 +488,7 @@ class WeightNorm(torch.autograd.Function):
             L.check(L.lib().recmv_weight_norm_forward(L.ptr(v_c), L.ptr(g_c), L.ptr(W), L.ptr(norms), rows, cols,
                                                       L.stream_ptr(v.device)), "weight_norm")
         ctx.save_for_backward(v_c, g_c, norms)
-        return W
+        return presplit(W)
 
     @staticmethod
     @torch.autograd.function.once_differentiable

@@ -892,3 +892,51 @@ def test_def_regu_matches_the_torch_closed_form_the_loop_used():
     lb.backward()
     assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
     assert float((a.grad - b.grad).abs().max()) <= 2e-3 * float(b.grad.abs().max())
+
+
+# ------------------------------------------------------------------------------------------ bf16x6, weights split once
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(20000, 512, 512), (70001, 473, 512), (33000, 512, 168), (16400, 512, 40)])
+def test_bf16x6_presplit_weights_are_bit_identical_to_the_in_loop_split(bf16x6_mode, M, N, K):
+    """recmv_b3_split writes the SAME pieces the staging path of gemm_nt_b3_kernel forms in the loop (one split8), and the PRE
+    variant multiplies them in the same order: registering a weight matrix changes the time, not one bit of the product —
+    plain product, fused bias + softplus epilogue, the activation-gradient operand product, ragged M / N, a K tail, a weight
+    registered with more rows than the product uses; forgetting the entry goes back to the in-loop split."""
+    from recmv import _lib as L, ops
+    g = torch.Generator().manual_seed(M + N)
+    A = gpu(torch.randn(M, K, generator=g))
+    W = gpu(torch.randn(N, K, generator=g) / np.sqrt(K))
+    b = gpu(torch.randn(N, generator=g))
+    Y = gpu(torch.randn(M, K, generator=g))
+    base = [ops.gemm_nt(A, W), ops.gemm_nt(A, W, b, ops.ACT_SOFTPLUS, 100.0, 0.70710678), ops.gemm_nt(A, W[:N - 5])]
+    assert getattr(W, "_recmv_b3", None) is None
+    ops.presplit(W)
+    assert W._recmv_b3 is not None
+    again = [ops.gemm_nt(A, W), ops.gemm_nt(A, W, b, ops.ACT_SOFTPLUS, 100.0, 0.70710678), ops.gemm_nt(A, W[:N - 5])]
+    for x, y in zip(base, again):
+        assert torch.equal(x, y)
+    L.check(L.lib().recmv_b3_forget(L.ptr(W)), "forget")
+    assert torch.equal(ops.gemm_nt(A, W), base[0])
+
+
+@pytest.mark.gpu
+def test_bf16x6_presplit_rides_on_the_weight_norm_and_its_transpose(bf16x6_mode):
+    """In the bf16x6 mode every weight version gets its planes where it is made: the weight normalisation's output and the cached
+    transpose; the registration ends with the tensor (a new tensor at the same address starts unregistered)."""
+    from recmv import ops
+    g = torch.Generator().manual_seed(2)
+    v = gpu(torch.randn(512, 512, generator=g)).requires_grad_(True)
+    gg = gpu(torch.rand(512, 1, generator=g) + 0.5).requires_grad_(True)
+    W = ops.weight_norm(v, gg)
+    assert getattr(W, "_recmv_b3", None) is not None
+    Wt = ops.transposed(W)
+    assert getattr(Wt, "_recmv_b3", None) is not None
+    x = gpu(torch.randn(20000, 512, generator=g))
+    y = ops.gemm_nt(x, W.detach())
+    os.environ["RECMV_B3_PRESPLIT"] = "0"
+    try:
+        W2 = ops.weight_norm(v, gg)
+        assert getattr(W2, "_recmv_b3", None) is None
+        assert torch.equal(ops.gemm_nt(x, W2.detach()), y)
+    finally:
+        del os.environ["RECMV_B3_PRESPLIT"]

@@ -3,6 +3,7 @@ diff the outputs to find the first iteration / term that depends on scheduling.
 
     python tools/determinism_probe.py [iters] > a.txt ; python tools/determinism_probe.py [iters] > b.txt ; diff a.txt b.txt
 """
+import os
 import struct
 import sys
 from pathlib import Path
@@ -42,6 +43,20 @@ def main():
         for k, g in grads.items():
             if g is not None:
                 print("      grad %-23s %s" % (k, bits(g.double().abs().sum())))
+        if os.environ.get("RECMV_PROBE_ALL") == "1":      # every shared tensor's gradient, by position and shape
+            named = {}
+            for mod_name, mod in (("sdf0", loop.garment_nets[0]), ("sdf1", loop.garment_nets[1]), ("def", loop.deformer),
+                                  ("rend", loop.netRender)):
+                for n_, p_ in mod.named_parameters():
+                    named[id(p_)] = mod_name + "." + n_
+            for n_ in ("poses", "trans", "d_cond", "rendcond", "focal", "pp", "T"):
+                t_ = getattr(loop.dataset, n_, None)
+                if t_ is not None:
+                    named[id(t_)] = "dataset." + n_
+            for i, p_ in enumerate(loop.shared_parameters()):
+                g_ = p_.grad
+                print("      all %3d %-34s %-18s %s" % (i, named.get(id(p_), "?"), tuple(p_.shape),
+                                                       bits(g_.double().abs().sum()) if g_ is not None else "-"))
 
 
 if __name__ == "__main__":

@@ -43,6 +43,13 @@ def main():
         for k, g in grads.items():
             if g is not None:
                 print("      grad %-23s %s" % (k, bits(g.double().abs().sum())))
+        for g_i, t in enumerate(loop.TmpPs):                # the surface points, their gradients, the jets the implicit differentiation reads
+            if t is not None and t.grad is not None:
+                pre = getattr(loop, "_prop_pre", {}).get(g_i)
+                print("      TmpPs[%d] %-14s p %s grad %s jets %s %s" % (
+                    g_i, tuple(t.shape), bits(t.detach().double().abs().sum()), bits(t.grad.double().abs().sum()),
+                    bits(pre[1].double().abs().sum()) if pre is not None and pre[1] is not None else "-",
+                    bits(pre[2].double().abs().sum()) if pre is not None and pre[2] is not None else "-"))
         if os.environ.get("RECMV_PROBE_ALL") == "1":      # every shared tensor's gradient, by position and shape
             named = {}
             for mod_name, mod in (("sdf0", loop.garment_nets[0]), ("sdf1", loop.garment_nets[1]), ("def", loop.deformer),

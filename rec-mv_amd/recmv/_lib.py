@@ -16,7 +16,7 @@ _PKG = Path(__file__).resolve().parent.parent          # rec-mv_amd/
 LIB_PATH = _PKG / "lib" / "librecmv_hip.so"
 
 RECMV_OK = 0
-ABI_VERSION = 5          # include/recmv_hip.h; bumped when a signature changes (v5: second weight set + split_row in recmv_mlp)
+ABI_VERSION = 6          # include/recmv_hip.h; bumped when a signature changes (v5: second weight set + split_row in recmv_mlp; v6: recmv_def_regu, recmv_b3_*, recmv_mlp_rows_*, recmv_mc_run_batch added)
 F32, F64 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = 0, 1, 2, 3
 

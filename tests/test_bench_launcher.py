@@ -57,3 +57,29 @@ def test_gpus_2_launches_two_ranks_with_identical_replicas():
     assert abs(two["value"] - 2 * 1e3 / two["ms_per_step"]) < 1e-2 * two["value"]       # whole-job rate: N iterations per step time
     one = _line(["--gpus", "1"])
     assert one["n_gpus"] == 1 and one["config"]["per_rank_ms_per_step"] is None and one["config"]["replicas_bit_identical"] is None
+
+
+def test_frames_at_counts_the_short_last_batch_of_an_epoch():
+    """bench.frames_at: frames a rank takes in iteration `it` — batch_size except at an epoch's last position (64 frames, 3 per step:
+    every 22nd iteration has one frame), the same deal HotLoop.frame_batch_at makes, also when frames are sharded over ranks."""
+    import types
+    sys.path.insert(0, str(REPO))
+    import bench
+    from recmv.loop import iters_per_epoch
+
+    def fake(F, bs, world, rank):
+        loop = types.SimpleNamespace(batch_size=bs, world_size=world, rank=rank, dataset=types.SimpleNamespace(F=F))
+        loop.iters_per_epoch = lambda: iters_per_epoch(F, bs, world)
+        return loop
+    one = fake(64, 3, 1, 0)
+    assert one.iters_per_epoch() == 22
+    assert [bench.frames_at(one, it) for it in range(22)] == [3] * 21 + [1]
+    assert bench.frames_at(one, 22 + 5) == 3 and bench.frames_at(one, 43) == 1
+    two = [fake(64, 3, 2, r) for r in range(2)]
+    assert two[0].iters_per_epoch() == 11
+    assert [bench.frames_at(two[0], it) for it in range(11)] == [3] * 10 + [2]
+    assert [bench.frames_at(two[1], it) for it in range(11)] == [3] * 10 + [2]
+    # fewer remaining frames than ranks: the permutation wraps so that every rank still has one
+    three = [fake(10, 3, 3, r) for r in range(3)]            # 9 per step, 2 positions, the second holds 1 frame for 3 ranks
+    assert three[0].iters_per_epoch() == 2
+    assert [bench.frames_at(three[r], 1) for r in range(3)] == [1, 1, 1]

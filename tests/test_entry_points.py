@@ -241,3 +241,17 @@ def test_name_tables_equal_the_reference_module():
     want = json.loads((REPO / "tests" / "golden" / "constant_tables.json").read_text())
     for name, table in want.items():
         assert getattr(constant, name) == table, name
+
+
+def test_presplit_is_a_no_op_off_the_device_and_in_the_f32_mode():
+    """ops.presplit only acts on CUDA weight matrices in the bf16x6 matrix mode: everything else comes back untouched (no planes,
+    no registration), so the call sites in the weight normalisation and the transpose cache cost nothing in the default mode."""
+    import torch
+    from recmv import ops
+    W = torch.randn(64, 64)
+    assert ops.presplit(W) is W and getattr(W, "_recmv_b3", None) is None
+    v, g = torch.randn(8, 16), torch.rand(8, 1) + 0.5
+    Wn = ops.weight_norm(v, g)                                  # CPU route: plain torch
+    torch.testing.assert_close(Wn, g * v / v.norm(dim=1, keepdim=True))
+    with pytest.raises(RuntimeError):
+        ops.def_regu(torch.eye(3).view(1, 3, 3), 0.01)          # device-only entry point: fails loudly on a CPU tensor

@@ -158,6 +158,24 @@ int jet_check(const recmv_mlp* m) {
   return RECMV_OK;
 }
 
+// The tangent rows' code / padding columns are zeroed by this kernel instead of a hipMemsetAsync over the whole tangent block (whose
+// first d_pe columns posenc_jvp overwrites anyway): fewer bytes, and no runtime fill between this stream's kernels — in the bf16x6
+// matrix mode, with the two garments' chains on two streams, about one run of the loop in four parted from the others in the rows
+// this fill covers; with the kernel 8 runs of 8 were identical (profiles/r04_b3_presplit.txt).  RECMV_JET_FILL_KERNEL=0:
+// the hipMemsetAsync (A/B; bit-identical results when both work).
+__global__ __launch_bounds__(kBlk) void jet_zero_cols_kernel(float* __restrict__ p, int64_t ld, int64_t rows, int c0, int width) {
+  const int64_t total = rows * width;
+  for (int64_t e = (int64_t)blockIdx.x * kBlk + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlk) {
+    const int64_t r = e / width;
+    p[r * ld + c0 + (int)(e - r * width)] = 0.f;
+  }
+}
+
+inline bool jet_fill_kernel() {
+  static const bool v = [] { const char* e = getenv("RECMV_JET_FILL_KERNEL"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
 }  // namespace
 }  // namespace recmv
 
@@ -201,7 +219,13 @@ extern "C" int recmv_mlp_jet_forward(const recmv_mlp* m, const float* x, const f
                                  1.f, stream));
   if (m->cond_dim)
     RECMV_TRY(recmv_gather_rows(cond, ld_cond, cond_index, in + d_pe, L.ld_in, P, m->cond_dim, L.ld_in - d_pe, stream));
-  RECMV_HIP_TRY(hipMemsetAsync(in + P * L.ld_in, 0, (size_t)3 * P * L.ld_in * 4, s));
+  if (jet_fill_kernel() && L.ld_in > d_pe) {
+    hipLaunchKernelGGL(jet_zero_cols_kernel, dim3(stream_grid(3 * P * (L.ld_in - d_pe), kBlk)), dim3(kBlk), 0, s, in + P * L.ld_in,
+                       L.ld_in, 3 * P, d_pe, (int)(L.ld_in - d_pe));
+    RECMV_TRY(check_launch("mlp_jet_forward/zero"));
+  } else {
+    RECMV_HIP_TRY(hipMemsetAsync(in + P * L.ld_in, 0, (size_t)3 * P * L.ld_in * 4, s));
+  }
   for (int k = 0; k < 3; ++k)
     RECMV_TRY(recmv_posenc_jvp(x, 3, eye3 + 3 * k, 0, in + (int64_t)(k + 1) * P * L.ld_in, L.ld_in, P, m->multires,
                                m->pe_weights, stream));

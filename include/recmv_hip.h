@@ -88,6 +88,8 @@ int recmv_grid_sample3d_forward(const void* input, const recmv_tensor5* input_de
  * point with the channel loop in the reference's order (GridSamplerMineKernel.cu:333-914), bit-equal to the oracle.  Requests
  * with grad_input or ggI, f64, or other layouts always take the exact kernels.  Returns the previous mode. */
 int recmv_set_sampler_mode(int mode);
+/* The mode in force, read without changing it (ABI v7; GridSamplerMine.current_mode of the Python side reads it at forward time). */
+int recmv_get_sampler_mode(void);
 
 int recmv_grid_sample3d_backward(const void* input, const recmv_tensor5* input_desc,
                                  const void* grid, const recmv_tensor5* grid_desc,
@@ -240,6 +242,10 @@ int recmv_gemm_nt_mulgrad_seg(const float* A, int64_t lda, const float* B, const
  * matrix rate).  Returns the previous mode. */
 int recmv_set_gemm_mode(int mode);
 int recmv_get_gemm_mode(void);
+/* How the jet pass (recmv_mlp_jet_forward) zeroes the code / padding columns of its tangent rows: 1 (default) = a kernel over those
+ * columns only, 0 = hipMemsetAsync over the whole tangent block (rounds 1-4; the A/B of tools/loop_repro_inproc.py).  Same bits either
+ * way.  Process-global; RECMV_JET_FILL_KERNEL=0 sets 0 at load.  Returns the previous value.  (ABI v7) */
+int recmv_set_jet_fill(int use_kernel);
 /* bf16x6 mode, weights split ONCE: recmv_b3_split writes the three bf16 planes [3][N][Kp] (Kp = K rounded up to 32, zero-padded) of
  * a weight matrix B [N][K] (row stride ldb, K % 8 == 0, 16-byte aligned rows) into `planes` (recmv_b3_planes_bytes(N, K) bytes,
  * owned by the caller) and remembers them under B's address; the large bf16x6 products (recmv_gemm_nt and everything built on it,

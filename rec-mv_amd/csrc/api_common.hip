@@ -12,5 +12,5 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace recmv
 
-extern "C" int recmv_abi_version(void) { return 6; }
+extern "C" int recmv_abi_version(void) { return 7; }
 extern "C" const char* recmv_last_error(void) { return recmv::g_err; }

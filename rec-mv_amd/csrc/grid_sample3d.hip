@@ -792,3 +792,5 @@ extern "C" int recmv_set_sampler_mode(int mode) {
   if (mode >= 0 && mode <= 4) g_sampler_mode = mode;     // (2, 3, 4: forced lane splits, measurement only — tools/kernel_only.py)
   return prev;
 }
+
+extern "C" int recmv_get_sampler_mode(void) { return g_sampler_mode; }

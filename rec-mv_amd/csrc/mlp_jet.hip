@@ -171,9 +171,13 @@ __global__ __launch_bounds__(kBlk) void jet_zero_cols_kernel(float* __restrict__
   }
 }
 
+int g_jet_fill = -1;      // -1: not set yet (RECMV_JET_FILL_KERNEL decides at the first pass), 0: hipMemsetAsync, 1: kernel
 inline bool jet_fill_kernel() {
-  static const bool v = [] { const char* e = getenv("RECMV_JET_FILL_KERNEL"); return !(e && e[0] == '0'); }();
-  return v;
+  if (g_jet_fill < 0) {
+    const char* e = getenv("RECMV_JET_FILL_KERNEL");
+    g_jet_fill = !(e && e[0] == '0');
+  }
+  return g_jet_fill != 0;
 }
 
 }  // namespace
@@ -186,6 +190,12 @@ using namespace recmv;
     int rc__ = (expr);                 \
     if (rc__ != RECMV_OK) return rc__; \
   } while (0)
+
+extern "C" int recmv_set_jet_fill(int use_kernel) {
+  const int prev = jet_fill_kernel() ? 1 : 0;
+  g_jet_fill = use_kernel ? 1 : 0;
+  return prev;
+}
 
 extern "C" int64_t recmv_mlp_jet_workspace_bytes(const recmv_mlp* m, int64_t P) {
   if (!m || P <= 0 || m->n_layers < 1 || m->n_layers > RECMV_MLP_MAX_LAYERS) return 0;

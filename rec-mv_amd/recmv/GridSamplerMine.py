@@ -82,10 +82,7 @@ def dbackward(grad_output_input, grad_output_grid, input, grid, grad_output, int
 
 def current_mode():
     """The sampler mode in force (recmv_set_sampler_mode): 0 record-coalesced lanes, 1 the reference's summation order."""
-    lib = L.lib()
-    prev = lib.recmv_set_sampler_mode(0)
-    lib.recmv_set_sampler_mode(prev)
-    return int(prev)
+    return int(L.lib().recmv_get_sampler_mode())
 
 
 class exact_order:

@@ -16,7 +16,7 @@ _PKG = Path(__file__).resolve().parent.parent          # rec-mv_amd/
 LIB_PATH = _PKG / "lib" / "librecmv_hip.so"
 
 RECMV_OK = 0
-ABI_VERSION = 6          # include/recmv_hip.h; bumped when a signature changes (v5: second weight set + split_row in recmv_mlp; v6: recmv_def_regu, recmv_b3_*, recmv_mlp_rows_*, recmv_mc_run_batch added)
+ABI_VERSION = 7          # include/recmv_hip.h; bumped when a signature changes (v7: recmv_get_sampler_mode, recmv_set_jet_fill added; v5: second weight set + split_row in recmv_mlp; v6: recmv_def_regu, recmv_b3_*, recmv_mlp_rows_*, recmv_mc_run_batch added)
 F32, F64 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = 0, 1, 2, 3
 
@@ -96,6 +96,8 @@ def _declare(lib):
         "recmv_b3_split": (C.c_int, [vp, i64, i64, i64, vp, i64, vp]),
         "recmv_b3_forget": (C.c_int, [vp]),
         "recmv_set_sampler_mode": (C.c_int, [i32]),
+        "recmv_get_sampler_mode": (C.c_int, []),
+        "recmv_set_jet_fill": (C.c_int, [i32]),
         "recmv_gemm_tn_workspace_bytes": (i64, [i64, i64, i64]),
         "recmv_gemm_tn": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp, i64, vp]),
         "recmv_posenc_forward": (C.c_int, [vp, i64, vp, i64, i64, i64, i32, vp, f32, vp]),
@@ -226,6 +228,59 @@ class device_guard:
 
 def ptr(t) -> C.c_void_p:
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ---- values built once and read from several streams -----------------------------------------------------------------------------
+# The loop runs on four streams (main, ray pipeline, curve branch, second garment) and keeps lazily built per-weight-version state
+# on the modules (normalised weights, their transposes, posed skeletons, packed weights).  A value built on one stream is only
+# valid on another after that stream has waited for the producer: `publish()` records the event behind the producer's launches and
+# `acquire()` makes the CURRENT stream wait for it when it is a different one (a hit on the producing stream costs one integer
+# compare).  RECMV_CACHE_EVENTS=0 drops the waits (A/B for tools/loop_repro_inproc.py — the round-4 state of half of the caches).
+def publish(device):
+    """Token for a value whose producing launches have just been enqueued on the current stream of `device` (None on the host)."""
+    if device is None:
+        return None
+    device = torch.device(device)
+    if device.type != "cuda":
+        return None
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    return (ev, raw_stream(device), device)
+
+
+def acquire(token):
+    """Make the current stream wait for the producer of a published value (no-op on the producing stream / on the host)."""
+    if token is None:
+        return
+    ev, sid, device = token
+    if raw_stream(device) != sid and os.environ.get("RECMV_CACHE_EVENTS", "1") != "0":
+        torch.cuda.current_stream(device).wait_event(ev)
+
+
+# ---- RECMV_POISON=1: a detector for reads of memory nobody has written yet -----------------------------------------------------
+# Every workspace / output buffer the wrappers allocate with torch.empty goes through `scratch()`.  With RECMV_POISON=1 it is filled
+# with a signalling pattern (NaN for floats, 0x7f bytes for raw workspaces) on the allocating stream before the kernels that are
+# supposed to write it are enqueued: a kernel that reads a column nobody wrote, a fill that arrives after its reader, or a block
+# handed to another stream without a wait then shows as NaN in the loop's results EVERY run instead of as last-bit differences in
+# one run of four (whether a fresh block holds zeros or an earlier tensor's values depends on the allocator's history).
+def poison_on() -> bool:
+    return os.environ.get("RECMV_POISON", "0") == "1"
+
+
+def scratch(shape, dtype, device):
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if poison_on() and t.is_cuda and t.numel():
+        if t.dtype.is_floating_point:
+            t.fill_(float("nan"))
+        elif t.dtype == torch.uint8:
+            t.fill_(0xff)                                  # 0xffffffff words are NaN when read as floats
+        else:
+            t.fill_(-1)
+    return t
+
+
+def scratch_like(x):
+    return scratch(tuple(x.shape), x.dtype, x.device) if poison_on() else torch.empty_like(x)
 
 
 def desc5(t) -> Tensor5:

@@ -93,7 +93,7 @@ class MlpChain:
         st = torch.cuda.current_stream(dev)
         if self._packed is None:
             n = int(L.lib().recmv_mlp_pack_bytes(C.byref(self.m)))
-            self._packed = torch.empty(n, dtype=torch.uint8, device=dev)
+            self._packed = L.scratch(n, torch.uint8, dev)
             with L.device_guard(dev):
                 L.check(L.lib().recmv_mlp_pack(C.byref(self.m), L.ptr(self._packed), n, L.stream_ptr(dev)), "mlp_pack")
             self._packed_ev = torch.cuda.Event()
@@ -106,20 +106,22 @@ class MlpChain:
 
     def _rows_workspace(self, P, slot):
         need = int(L.lib().recmv_mlp_rows_workspace_bytes(C.byref(self.m), P))
-        ws = self._rows_ws.get(slot)
+        key = (slot, L.raw_stream(self.device))
+        ws = self._rows_ws.get(key)
         if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
-            self._rows_ws[slot] = ws
+            ws = L.scratch(max(need, 256), torch.uint8, self.device)
+            self._rows_ws[key] = ws
         return ws
 
     def _workspace(self, P, keep, slot=None):
         """Activation workspace; `slot` separates concurrent users of one chain (e.g. two garments evaluated on two
         streams through the same deformer MLP)."""
         need = int(L.lib().recmv_mlp_workspace_bytes(C.byref(self.m), P, keep))
-        ws = self._ws.get(slot)
+        key = (slot, L.raw_stream(self.device))       # a chain object is shared by the streams of an iteration: no shared scratch
+        ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
-            self._ws[slot] = ws
+            ws = L.scratch(max(need, 256), torch.uint8, self.device)
+            self._ws[key] = ws
         return ws
 
     def _split(self, split_row, P):
@@ -136,7 +138,7 @@ class MlpChain:
         self._split(split_row, P)
         n_out = self.rows_last if n_out is None else n_out
         if out is None:
-            out = torch.empty((P, n_out), dtype=torch.float32, device=x.device)
+            out = L.scratch((P, n_out), torch.float32, x.device)
         ld_cond = 0
         if cond is not None:
             assert cond.dtype == torch.float32 and cond.stride(-1) == 1 and cond.dim() == 2
@@ -167,7 +169,7 @@ class MlpChain:
         P = x.shape[0]
         self._split(split_row, P)
         n_out = (1 if g_out is None else g_out.shape[1]) if n_out is None else n_out
-        gx = torch.empty((P, 3), dtype=torch.float32, device=x.device)
+        gx = L.scratch((P, 3), torch.float32, x.device)
         ldg = 0
         if g_out is not None:
             assert g_out.dtype == torch.float32 and g_out.stride(1) == 1 and g_out.shape == (P, n_out)
@@ -204,12 +206,12 @@ def lbs_forward(ps, frame, A, trans, grid, cam=None, rays=None):
     """d [P,3] (and, with rays, (loss2 [P], angle [P], g_d [P,3])) — recmv_lbs_forward."""
     P, B = ps.shape[0], A.shape[0]
     dev = ps.device
-    d = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    d = L.scratch((P, 3), torch.float32, dev)
     loss2 = angle = g_d = None
     if rays is not None:
-        loss2 = torch.empty(P, dtype=torch.float32, device=dev)
-        angle = torch.empty(P, dtype=torch.float32, device=dev)
-        g_d = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        loss2 = L.scratch(P, torch.float32, dev)
+        angle = L.scratch(P, torch.float32, dev)
+        g_d = L.scratch((P, 3), torch.float32, dev)
     with L.device_guard(dev):
         L.check(L.lib().recmv_lbs_forward(L.ptr(ps), L.ptr(frame), P, L.ptr(A), L.ptr(trans), B, C.byref(grid),
                                           L.ptr(cam), L.ptr(rays), L.ptr(d), L.ptr(loss2), L.ptr(angle), L.ptr(g_d),
@@ -219,7 +221,7 @@ def lbs_forward(ps, frame, A, trans, grid, cam=None, rays=None):
 
 def lbs_vjp_input(ps, frame, A, grid, g_d):
     P, B = ps.shape[0], A.shape[0]
-    g_p = torch.empty((P, 3), dtype=torch.float32, device=ps.device)
+    g_p = L.scratch((P, 3), torch.float32, ps.device)
     with L.device_guard(ps.device):
         L.check(L.lib().recmv_lbs_vjp_input(L.ptr(ps), L.ptr(frame), P, L.ptr(A), B, C.byref(grid), L.ptr(g_d),
                                             L.ptr(g_p), L.stream_ptr(ps.device)), "lbs_vjp_input")
@@ -254,6 +256,7 @@ def _eye(device):
     t = _eye3.get(key)
     if t is None:
         t = torch.eye(3, dtype=torch.float32, device=device).contiguous()
+        torch.cuda.current_stream(device).synchronize()      # built once, read from every stream afterwards
         _eye3[key] = t
     return t
 
@@ -284,9 +287,9 @@ class MlpJet(torch.autograd.Function):
         n_j = cfg['n_j']
         n_out = Wd[-1].shape[0]
         lib = L.lib()
-        ws = torch.empty(int(lib.recmv_mlp_jet_workspace_bytes(C.byref(ch.m), P)), dtype=torch.uint8, device=dev)
-        y = torch.empty((P, n_out), dtype=torch.float32, device=dev)
-        tang = torch.empty((3 * P, n_j), dtype=torch.float32, device=dev)
+        ws = L.scratch(int(lib.recmv_mlp_jet_workspace_bytes(C.byref(ch.m), P)), torch.uint8, dev)
+        y = L.scratch((P, n_out), torch.float32, dev)
+        tang = L.scratch((3 * P, n_j), torch.float32, dev)
         cond_d = cond.detach() if cond is not None else None
         cidx = cfg['cond_index']
         ld_cond = cond_d.stride(0) if cond_d is not None else 0
@@ -315,15 +318,15 @@ class MlpJet(torch.autograd.Function):
         gy = gy.contiguous() if gy is not None else None
         gtang = gtang.contiguous() if gtang is not None else None
         Wd = ch._keep[0]
-        gWs = [torch.empty_like(Wd[l]) if need[3 + l] else None for l in range(n)]
-        gbs = [torch.empty(Wd[l].shape[0], dtype=torch.float32, device=dev)
+        gWs = [L.scratch_like(Wd[l]) if need[3 + l] else None for l in range(n)]
+        gbs = [L.scratch(Wd[l].shape[0], torch.float32, dev)
                if (ctx.has_bias[l] and need[3 + n + l]) else None for l in range(n)]
         gW_arr = (C.c_void_p * n)(*[g.data_ptr() if g is not None else None for g in gWs])
         gb_arr = (C.c_void_p * n)(*[g.data_ptr() if g is not None else None for g in gbs])
         want_cond = ctx.cond_shape is not None and need[2]
         ld_in = (cfg['dims'][0] + 3) // 4 * 4
-        g_in = torch.empty((4 * P, ld_in), dtype=torch.float32, device=dev) if want_cond else None
-        gx = torch.empty((P, 3), dtype=torch.float32, device=dev) if need[1] else None
+        g_in = L.scratch((4 * P, ld_in), torch.float32, dev) if want_cond else None
+        gx = L.scratch((P, 3), torch.float32, dev) if need[1] else None
         eye = _eye(dev)
         with L.device_guard(dev):
             L.check(lib.recmv_mlp_jet_backward(C.byref(ch.m), L.ptr(xd), L.ptr(eye), P, n_j, L.ptr(gy),
@@ -369,17 +372,17 @@ def lbs_vjp_params(ps, frame, A_shape, grid, g_d):
     from . import ops
     P, B = ps.shape[0], A_shape[0]
     dev = ps.device
-    W = torch.empty((P, 24), dtype=torch.float32, device=dev)
-    Q = torch.empty((P, B * 12), dtype=torch.float32, device=dev)
-    Gs = torch.empty((P, B * 3), dtype=torch.float32, device=dev)
+    W = L.scratch((P, 24), torch.float32, dev)
+    Q = L.scratch((P, B * 12), torch.float32, dev)
+    Gs = L.scratch((P, B * 3), torch.float32, dev)
     lib = L.lib()
     with L.device_guard(dev):
         L.check(lib.recmv_lbs_vjp_params_stage(L.ptr(ps), L.ptr(frame), P, B, C.byref(grid), L.ptr(g_d), L.ptr(W),
                                                L.ptr(Q), L.ptr(Gs), L.stream_ptr(dev)), "lbs_vjp_params_stage")
         gAm = ops.gemm_tn(W, Q)                                            # [24, B*12]
         need = int(lib.recmv_colsum_workspace_bytes(P, B * 3))
-        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
-        gt = torch.empty(B * 3, dtype=torch.float32, device=dev)
+        ws = L.scratch(max(need, 256), torch.uint8, dev)
+        gt = L.scratch(B * 3, torch.float32, dev)
         L.check(lib.recmv_colsum(L.ptr(Gs), B * 3, P, B * 3, L.ptr(gt), L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
                 "colsum")
     gA = torch.zeros(A_shape, dtype=torch.float32, device=dev)

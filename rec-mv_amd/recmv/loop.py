@@ -72,6 +72,8 @@ def singular_values_3x3(J):
     if const is None:
         const = _SV_CONST[key] = (torch.eye(3, device=J.device, dtype=J.dtype),
                                   torch.arange(2, device=J.device, dtype=J.dtype) * (2.0 * math.pi / 3.0))
+        if J.is_cuda:
+            torch.cuda.current_stream(J.device).synchronize()     # built once, read from every stream afterwards
     eye, shifts = const
     A = (J.transpose(-1, -2).unsqueeze(-1) * J.unsqueeze(-3)).sum(-2)        # J^T J without BLAS
     q = torch.diagonal(A, dim1=-2, dim2=-1).sum(-1) / 3.0                    # trace / 3
@@ -1132,6 +1134,9 @@ class HotLoop:
         if side is not None:
             for st in side:
                 base.wait_stream(st)
+            # what the side chains leave for the base stream (the sum below, the backward pass, propagateTmpPsGrad): their blocks
+            # belong to the side stream's pool, so the allocator has to know about the second reader
+            self._record_handover(base, losses[1:])
         total_loss = 0.
         for loss_g in losses:
             total_loss = total_loss + loss_g
@@ -1194,7 +1199,9 @@ class HotLoop:
             # the reference calls it at :1143 and again inside compute_cardinal_rays :1176): the rays' block is parked on the net and
             # served to the composite deformer's call below
             tr = self.deformer.defs[0]
-            if n_valid > 0 and hasattr(tr, 'jet_two_blocks'):
+            jet_ok = (getattr(tr, 'embed_fn', None) is not None and def_pts.is_cuda and def_pts.dtype == torch.float32
+                      and torch.is_grad_enabled())             # MLPTranslator.forward's own gate for its jet path
+            if n_valid > 0 and jet_ok and hasattr(tr, 'jet_two_blocks'):
                 defVs_r = tr.jet_two_blocks(def_pts, d_cond, self.TmpPs[g_i], self.batch_inds[g_i], ratio['deformerRatio'], name)
             else:
                 defVs_r = tr(def_pts, d_cond, ratio=ratio, offset_type=name, jet=True)
@@ -1274,7 +1281,19 @@ class HotLoop:
             # for propagateTmpPsGrad: the two jets at these points (same parameters until the optimiser steps)
             self.__dict__.setdefault('_prop_pre', {})[g_i] = (
                 p, onx, grad_d_p.detach() if grad_d_p is not None else None, _param_versions(net, self.deformer))
+        self.deformer.defs[0].__dict__.pop('_jet_prefetch', None)      # (a parked ray block nobody asked for dies with the phase)
         return total_loss
+
+    def _record_handover(self, stream, extra=()):
+        """record_stream(`stream`) on every tensor the render loss leaves on this object for a later phase on another stream."""
+        keep = list(extra)
+        for name in ('TmpPs', 'rays', 'batch_inds', 'row_inds', 'col_inds'):
+            keep += [t for t in getattr(self, name, None) or [] if t is not None]
+        for pre in getattr(self, '_prop_pre', {}).values():
+            keep += [t for t in pre[:3] if torch.is_tensor(t)]
+        for t in keep:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
 
     def _def_regu_term(self, name, pts, defVs):
         """The deformation regulariser (:1135-1155) from the offset MLP's output at `pts` (its Jacobian carried by the jet pass)."""
@@ -1411,6 +1430,8 @@ class HotLoop:
                 s_ray.wait_event(getattr(self, '_sgd_done', None))
                 render_loss = self.surface_render_loss(N, cameras_rays, frame_ids, ratio, checks, init_ps_list, samples)
             main.wait_stream(s_ray)
+            if cuda:
+                self._record_handover(main, [render_loss] if torch.is_tensor(render_loss) else [])
             total_loss = total_loss + render_loss
             with self._phase('dct'):
                 d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)

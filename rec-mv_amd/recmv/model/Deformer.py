@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import _lib as L
 from .. import ops
 from ..MCAcc.grid_sampler_mine import GridSamplerMine3dFunction
 from ..utils.utils import annealing_weights, quat2mat
@@ -237,7 +238,7 @@ def _translator_forward_jet(self, ps, conds, batch_inds, ratio, offset_type):
     """forward() with the Jacobian d out / d ps carried along (one C call): out._recmv_jac = (ps, I + J_offset)."""
     from ..chains import mlp_jet
     pf = self.__dict__.pop('_jet_prefetch', None)
-    if pf is not None and pf[0] is ps and pf[2] is conds and pf[3] == ratio:
+    if pf is not None and pf[0] is ps and pf[2] is conds and pf[3] == ratio and pf[4] is batch_inds:
         # these very points went through the net a moment ago as the second row block of jet_two_blocks()
         out = pf[1]
         self.offset[offset_type] = out - ps[..., :3]
@@ -291,7 +292,7 @@ def _translator_jet_two_blocks(self, pts, conds, ps, batch_inds, ratio, offset_t
     out2 = y[n1:].view(ps.shape)
     out2._recmv_jac = (ps, J[n1:])
     self.offset[offset_type] = out1 - pts[..., :3]
-    self.__dict__['_jet_prefetch'] = (ps, out2, conds, ratio)
+    self.__dict__['_jet_prefetch'] = (ps, out2, conds, ratio, batch_inds)
     return out1
 
 
@@ -306,6 +307,7 @@ def _translator_chain(self, ratio):
     key = (wl,) + tuple((lin.weight._version, lin.weight.data_ptr(), lin.bias._version) for lin in lins)
     hit = self.__dict__.get('_chain_cache')
     if hit is not None and hit[0] == key:
+        L.acquire(hit[2])
         return hit[1]
     Ws = [lin.weight.detach().contiguous() for lin in lins]
     bs = [lin.bias.detach() for lin in lins]
@@ -313,7 +315,7 @@ def _translator_chain(self, ratio):
     dims = [Ws[0].shape[1]] + [W.shape[0] for W in Ws]
     ch = MlpChain(Ws, bs, Wts, dims, [W.shape[0] for W in Ws], self.multires, cond_dim=self.feature_vector_size,
                   skip_layer=-1, hidden_act=ops.ACT_RELU, act_param=0.0, residual=True, pe_weights=wl)
-    self.__dict__['_chain_cache'] = (key, ch)
+    self.__dict__['_chain_cache'] = (key, ch, L.publish(Ws[0].device))     # behind the transposes' launches
     return ch
 
 
@@ -340,8 +342,11 @@ def _cached_t(module, l, W):
     key = (W._version, W.data_ptr())
     hit = cache.get(l)
     if hit is None or hit[0] != key:
-        hit = (key, W.detach().t().contiguous())
+        Wt = W.detach().t().contiguous()
+        hit = (key, Wt, L.publish(Wt.device))         # read from several streams: the event behind the transpose travels with it
         cache[l] = hit
+    else:
+        L.acquire(hit[2])
     return hit[1]
 
 
@@ -549,10 +554,12 @@ class LBSkinner(nn.Module):
         hit = self.__dict__.get('_posed_cache')
         if hit is not None and hit[0] is poses and hit[1] == poses._version and hit[2] is trans \
                 and hit[3] == trans._version:
+            L.acquire(hit[6])                        # (the garments' root finders read it on their own streams)
             return hit[4], hit[5]
         _, A = self._chain_fused(poses.detach())
+        A = A.contiguous()
         t = (trans.detach() + self.extra_trans).contiguous()
-        self.__dict__['_posed_cache'] = (poses, poses._version, trans, trans._version, A.contiguous(), t)
+        self.__dict__['_posed_cache'] = (poses, poses._version, trans, trans._version, A, t, L.publish(A.device))
         return A, t
 
     @torch.no_grad()

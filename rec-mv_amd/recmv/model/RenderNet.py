@@ -4,6 +4,7 @@ import warnings
 import torch
 import torch.nn as nn
 
+from .. import _lib as L
 from .. import ops
 from ..utils.utils import annealing_weights
 from .Embedder import get_embedder
@@ -49,8 +50,11 @@ class RenderingNetwork_view_norm(nn.Module):
                 key = (v._version, g._version, v.data_ptr())
                 hit = cache.get(l)
                 if hit is None or hit[0] != key:
-                    hit = (key, ops.weight_norm(v, g))
+                    W = ops.weight_norm(v, g)
+                    hit = (key, W, L.publish(W.device))     # the event behind the producer: a hit on another stream waits
                     cache[l] = hit
+                else:
+                    L.acquire(hit[2])
                 return hit[1], lin.bias
             return ops.weight_norm(v, g), lin.bias
         return lin.weight, lin.bias

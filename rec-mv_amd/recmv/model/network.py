@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import _lib as L
 from .. import ops
 from ..utils.utils import annealing_weights
 from .Embedder import get_embedder
@@ -72,13 +73,18 @@ class ImplicitNetwork(nn.Module):
             v, g = lin.weight_v, lin.weight_g
             if not torch.is_grad_enabled():
                 # the normalised weights only change at optimizer.step(): cache them for the no-grad passes
-                # (grid queries, root-finder checks) keyed on the parameters' in-place version counters
+                # (grid queries, root-finder checks) keyed on the parameters' in-place version counters.  The cache is read
+                # from every stream of the loop (re-mesh and root-finder preparation on the main stream, the root finders on
+                # the ray streams): an entry carries the event recorded behind its producer, a hit on another stream waits
                 cache = self.__dict__.setdefault('_wn_cache', {})
                 key = (v._version, g._version, v.data_ptr())
                 hit = cache.get(l)
                 if hit is None or hit[0] != key:
-                    hit = [key, ops.weight_norm(v, g), None]
+                    W = ops.weight_norm(v, g)
+                    hit = [key, W, None, L.publish(W.device), None]       # key, W, W^T, token of W, token of W^T
                     cache[l] = hit
+                else:
+                    L.acquire(hit[3])
                 return hit[1], lin.bias
             return ops.weight_norm(v, g), lin.bias                                # weight_norm dim=0
         return lin.weight, lin.bias
@@ -170,6 +176,9 @@ class ImplicitNetwork(nn.Module):
         wl = None if ws is None else tuple(float(w) for w in ws)
         if hit is not None and hit[0] == wl and len(hit[1]) == nl and all(a is b for a, b in zip(hit[1], Ws)) \
                 and (hit[3] or not need_t):
+            if hit[3]:
+                for l in range(nl):                 # (a hit on another stream than the transposes' producer waits for them)
+                    self._weight_t(l, Ws[l])
             return hit[2]
         assert len(self.skip_in) <= 1, "one skip connection (the reference uses skip_in=[4])"
         Wts = [self._weight_t(l, Ws[l]) for l in range(nl)] if need_t else None
@@ -230,7 +239,11 @@ class ImplicitNetwork(nn.Module):
         if hit is None or hit[1] is not W:
             return W.t().contiguous()
         if hit[2] is None:
+            L.acquire(hit[3])
             hit[2] = W.t().contiguous()
+            hit[4] = L.publish(W.device)
+        else:
+            L.acquire(hit[4])
         return hit[2]
 
     def gradient(self, x, y=None):

@@ -49,7 +49,7 @@ def presplit(W):
     N, K = W.shape
     if K % 8 != 0 or N < 64 or not W.is_contiguous() or W.data_ptr() % 16 != 0 or getattr(W, '_recmv_b3', None) is not None:
         return W
-    planes = torch.empty(int(lib.recmv_b3_planes_bytes(N, K)), dtype=torch.uint8, device=W.device)
+    planes = L.scratch(int(lib.recmv_b3_planes_bytes(N, K)), torch.uint8, W.device)
     with L.device_guard(W.device):
         L.check(lib.recmv_b3_split(L.ptr(W), K, N, K, L.ptr(planes), planes.numel(), L.stream_ptr(W.device)), "b3_split")
     try:
@@ -93,11 +93,11 @@ def linear_backward(gy, y, x, W, act, act_param, need_gx=True, need_gW=True, nee
     need = int(lib.recmv_linear_backward_workspace_bytes(M, N, K))
     ws = _lb_ws.get(_ws_key(dev))
     if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = L.scratch(need, torch.uint8, dev)
         _lb_ws[_ws_key(dev)] = ws
-    gx = torch.empty((M, K), dtype=torch.float32, device=dev) if need_gx else None
-    gW = torch.empty((N, K), dtype=torch.float32, device=dev) if need_gW else None
-    gb = torch.empty((N,), dtype=torch.float32, device=dev) if need_gb else None
+    gx = L.scratch((M, K), torch.float32, dev) if need_gx else None
+    gW = L.scratch((N, K), torch.float32, dev) if need_gW else None
+    gb = L.scratch((N,), torch.float32, dev) if need_gb else None
     Wt = transposed(W) if need_gx else None
     yd = y.detach() if y is not None else None
     with L.device_guard(dev):
@@ -129,7 +129,7 @@ def gemm_nt(A, B, bias=None, act=ACT_NONE, act_param=0.0, out_scale=1.0, out=Non
     if K != K2:
         raise RuntimeError(f"gemm_nt: inner dimensions differ ({K} vs {K2})")
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        out = L.scratch((M, N), torch.float32, A.device)
     else:
         assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
     if bias is not None:
@@ -151,14 +151,14 @@ def gemm_tn(A, B):
     K2, N = B.shape
     if K != K2:
         raise RuntimeError(f"gemm_tn: reduction dimensions differ ({K} vs {K2})")
-    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    out = L.scratch((M, N), torch.float32, A.device)
     lib = L.lib()
     with L.device_guard(A.device):
         need = int(lib.recmv_gemm_tn_workspace_bytes(M, N, K))
         key = _ws_key(A.device)
         ws = _tn_ws.get(key)
         if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=A.device)
+            ws = L.scratch(max(need, 256), torch.uint8, A.device)
             _tn_ws[key] = ws
         lda = A.stride(0) if K > 1 else max(M, 1)
         ldb = B.stride(0) if K > 1 else max(N, 1)
@@ -179,7 +179,7 @@ def posenc(x, multires, weights=None, out_scale=1.0, out=None, ld_fill=None):
     P = x.shape[0]
     width = 3 + 6 * multires
     if out is None:
-        out = torch.empty((P, width), dtype=torch.float32, device=x.device)
+        out = L.scratch((P, width), torch.float32, x.device)
     assert out.stride(1) == 1 and out.shape[0] == P and out.shape[1] >= width
     ldo = out.stride(0) if P > 1 else out.shape[1]
     fill = width if ld_fill is None else ld_fill
@@ -317,7 +317,7 @@ def _cptr(buf):
 def _pe_vjp(x, g, t, multires, weights):
     x = x.contiguous()
     g = g if g.stride(1) == 1 else g.contiguous()
-    out = torch.empty((x.shape[0], 3), dtype=torch.float32, device=x.device)
+    out = L.scratch((x.shape[0], 3), torch.float32, x.device)
     if t is not None:
         t = t.contiguous()
     P = x.shape[0]
@@ -331,7 +331,7 @@ def _pe_vjp(x, g, t, multires, weights):
 def _pe_jvp(x, t, multires, weights):
     x, t = x.contiguous(), t.contiguous()
     P = x.shape[0]
-    out = torch.empty((P, 3 + 6 * multires), dtype=torch.float32, device=x.device)
+    out = L.scratch((P, 3 + 6 * multires), torch.float32, x.device)
     with L.device_guard(x.device):
         L.check(L.lib().recmv_posenc_jvp(L.ptr(x), 3, L.ptr(t), 3, L.ptr(out), out.shape[1], P, multires,
                                          _cptr(_wbuf(weights, multires)), L.stream_ptr(x.device)), "posenc_jvp")
@@ -416,7 +416,7 @@ class PosEncVjp2(torch.autograd.Function):
 def act_grad(gy, y, act, act_param):
     """gy * act'(z) through y = act(z), no autograd."""
     gy, y = gy.contiguous(), y.contiguous()
-    out = torch.empty_like(gy)
+    out = L.scratch_like(gy)
     with L.device_guard(gy.device):
         L.check(L.lib().recmv_act_grad(L.ptr(gy), L.ptr(y), L.ptr(out), out.numel(), act, float(act_param),
                                        L.stream_ptr(gy.device)), "act_grad")
@@ -431,7 +431,7 @@ class ActGrad(torch.autograd.Function):
         ctx.save_for_backward(gy, y)
         ctx.cfg = (act, act_param)
         gy_c, y_c = gy.detach().contiguous(), y.detach().contiguous()
-        out = torch.empty_like(gy_c)
+        out = L.scratch_like(gy_c)
         with L.device_guard(gy.device):
             L.check(L.lib().recmv_act_grad(L.ptr(gy_c), L.ptr(y_c), L.ptr(out), out.numel(), act, float(act_param),
                                            L.stream_ptr(gy.device)), "act_grad")
@@ -457,7 +457,7 @@ class ActGrad(torch.autograd.Function):
 def act_grad2(a, b, y, act, act_param):
     """a * b * d(act')/dy, no autograd."""
     a_c, b_c, y_c = a.detach().contiguous(), b.detach().contiguous(), y.detach().contiguous()
-    out = torch.empty_like(a_c)
+    out = L.scratch_like(a_c)
     with L.device_guard(a.device):
         L.check(L.lib().recmv_act_grad2(L.ptr(a_c), L.ptr(b_c), L.ptr(y_c), L.ptr(out), out.numel(), act,
                                         float(act_param), L.stream_ptr(a.device)), "act_grad2")
@@ -482,8 +482,8 @@ class WeightNorm(torch.autograd.Function):
     def forward(ctx, v, g):
         v_c, g_c = v.detach().contiguous(), g.detach().contiguous()
         rows, cols = v_c.shape
-        W = torch.empty_like(v_c)
-        norms = torch.empty(rows, dtype=torch.float32, device=v.device)
+        W = L.scratch_like(v_c)
+        norms = L.scratch(rows, torch.float32, v.device)
         with L.device_guard(v.device):
             L.check(L.lib().recmv_weight_norm_forward(L.ptr(v_c), L.ptr(g_c), L.ptr(W), L.ptr(norms), rows, cols,
                                                       L.stream_ptr(v.device)), "weight_norm")
@@ -495,8 +495,8 @@ class WeightNorm(torch.autograd.Function):
     def backward(ctx, gW):
         v, g, norms = ctx.saved_tensors
         gW = gW.contiguous()
-        gv = torch.empty_like(v)
-        gg = torch.empty_like(g)
+        gv = L.scratch_like(v)
+        gg = L.scratch_like(g)
         with L.device_guard(v.device):
             L.check(L.lib().recmv_weight_norm_backward(L.ptr(v), L.ptr(g), L.ptr(norms), L.ptr(gW), L.ptr(gv),
                                                        L.ptr(gg), v.shape[0], v.shape[1], L.stream_ptr(v.device)),
@@ -520,8 +520,8 @@ class DefRegu(torch.autograd.Function):
     def forward(ctx, J, c):
         Jc = J.detach().contiguous()
         P = Jc.shape[0]
-        y = torch.empty(P, dtype=torch.float32, device=J.device)
-        gJ = torch.empty_like(Jc)
+        y = L.scratch(P, torch.float32, J.device)
+        gJ = L.scratch_like(Jc)
         with L.device_guard(J.device):
             L.check(L.lib().recmv_def_regu(L.ptr(Jc), P, float(c), L.ptr(y), L.ptr(gJ), L.stream_ptr(J.device)), "def_regu")
         ctx.save_for_backward(gJ)

@@ -1,0 +1,180 @@
+"""Run-to-run reproducibility of ONE optimiser iteration, counted in one process: the loop is built once, warmed up (re-mesh +
+one plain iteration), its whole state is snapshotted, and every repetition restores the snapshot and runs the same iteration
+again — same inputs, same host random draws; whatever differs between repetitions comes from the schedule.  Per configuration
+("cell") the digests of the results are counted; per result group too, so a cell that parts says WHERE.
+
+    python tools/loop_repro_inproc.py [reps=50] [cells=all|name,name,...] [steps_per_rep=1]
+
+Cells toggle, at run time: the matrix mode (recmv_set_gemm_mode), the second garment's render chain on a side stream
+(RECMV_RENDER_STREAMS), how the jets zero their tangent rows (recmv_set_jet_fill: kernel / hipMemsetAsync), the waits on the
+lazily built per-weight-version caches (RECMV_CACHE_EVENTS), joint / per-garment implicit differentiation (RECMV_PROP_JOINT),
+the poison detector (RECMV_POISON=1: every workspace and output buffer pre-filled with NaN — a read of memory nobody wrote shows
+as a non-finite count in EVERY repetition), and the one-stream order (RECMV_SERIAL=1).
+"""
+import copy
+import hashlib
+import os
+import sys
+import time
+from collections import Counter
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(REPO / "rec-mv_amd"), str(REPO)]
+import torch  # noqa: E402
+from recmv import _lib as L  # noqa: E402
+from recmv.hocon import ConfigFactory  # noqa: E402
+from recmv.loop import HotLoop  # noqa: E402
+
+ENV_KEYS = ("RECMV_RENDER_STREAMS", "RECMV_CACHE_EVENTS", "RECMV_PROP_JOINT", "RECMV_POISON", "RECMV_SERIAL", "RECMV_MERGE_JETS",
+            "RECMV_B3_PRESPLIT")
+
+# name -> (gemm mode, jet fill by kernel, env)
+CELLS = {
+    "f32 side-stream": (0, 1, {"RECMV_RENDER_STREAMS": "1"}),
+    "f32 one-ray-stream": (0, 1, {"RECMV_RENDER_STREAMS": "0"}),
+    "bf16x6 side-stream": (1, 1, {"RECMV_RENDER_STREAMS": "1"}),
+    "bf16x6 one-ray-stream": (1, 1, {"RECMV_RENDER_STREAMS": "0"}),
+    "bf16x6 side-stream memset-fill": (1, 0, {"RECMV_RENDER_STREAMS": "1"}),
+    "bf16x6 side-stream memset-fill per-garment-prop": (1, 0, {"RECMV_RENDER_STREAMS": "1", "RECMV_PROP_JOINT": "0"}),
+    "bf16x6 side-stream memset-fill no-cache-events": (1, 0, {"RECMV_RENDER_STREAMS": "1", "RECMV_CACHE_EVENTS": "0"}),
+    "bf16x6 side-stream no-cache-events": (1, 1, {"RECMV_RENDER_STREAMS": "1", "RECMV_CACHE_EVENTS": "0"}),
+    "f32 side-stream memset-fill no-cache-events": (0, 0, {"RECMV_RENDER_STREAMS": "1", "RECMV_CACHE_EVENTS": "0"}),
+    "bf16x6 side-stream memset-fill POISON": (1, 0, {"RECMV_RENDER_STREAMS": "1", "RECMV_POISON": "1"}),
+    "bf16x6 side-stream POISON": (1, 1, {"RECMV_RENDER_STREAMS": "1", "RECMV_POISON": "1"}),
+    "f32 side-stream POISON": (0, 1, {"RECMV_RENDER_STREAMS": "1", "RECMV_POISON": "1"}),
+    "bf16x6 serial": (1, 1, {"RECMV_SERIAL": "1"}),
+    "f32 serial": (0, 1, {"RECMV_SERIAL": "1"}),
+}
+
+
+def md5(*tensors):
+    h = hashlib.md5()
+    for t in tensors:
+        if t is None:
+            h.update(b"-")
+        else:
+            h.update(t.detach().contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()[:8]
+
+
+class Snapshot:
+    """Everything an iteration reads and changes: the shared tensors and their Adam state, the explicit vertices and their SGD
+    state, the curves and their AdamW state, the counters, both random generators."""
+
+    def __init__(self, loop):
+        self.loop = loop
+        self.tensors = [(p, p.detach().clone()) for p in self._all(loop)]
+        self.opts = [(o, copy.deepcopy(o.state_dict())) for o in self._opts(loop)]
+        self.counters = (loop.forward_time, loop.opt_times)
+        self.cuda = torch.device(loop.device).type == "cuda"
+        self.rng = (torch.get_rng_state(), torch.cuda.get_rng_state(loop.device) if self.cuda else None)
+
+    @staticmethod
+    def _all(loop):
+        out = list(loop.shared_parameters()) + list(loop.garment_vs)
+        if getattr(loop, "curves", False):
+            out += list(loop.inter_free_curve.parameters())
+        return out
+
+    @staticmethod
+    def _opts(loop):
+        out = [loop.optimizer, loop.garment_optimizer]
+        if getattr(loop, "curves", False):
+            out.append(loop.fl_optimizer)
+        return out
+
+    def restore(self):
+        loop = self.loop
+        with torch.no_grad():
+            for p, saved in self.tensors:
+                p.copy_(saved)
+                p.grad = None
+        for o, sd in self.opts:
+            o.load_state_dict(copy.deepcopy(sd))
+        loop.forward_time, loop.opt_times = self.counters
+        torch.set_rng_state(self.rng[0])
+        if self.cuda:
+            torch.cuda.set_rng_state(self.rng[1], loop.device)
+            torch.cuda.synchronize()
+
+
+def digests(loop, loss):
+    named = {
+        "loss": [loss],
+        "sdf0.grad": [p.grad for p in loop.garment_nets[0].parameters()],
+        "sdf1.grad": [p.grad for p in loop.garment_nets[1].parameters()] if loop.garment_size > 1 else [],
+        "deformer.grad": [p.grad for p in loop.deformer.parameters()],
+        "render.grad": [p.grad for p in loop.netRender.parameters()],
+        "frames.grad": [p.grad for p in loop.dataset.learnable_weights()],
+        "verts": list(loop.garment_vs),
+        "curves": list(loop.inter_free_curve.parameters()) if getattr(loop, "curves", False) else [],
+        "TmpPs": [t for t in loop.TmpPs if t is not None],
+        "TmpPs.grad": [t.grad for t in loop.TmpPs if t is not None],
+        "params_after": list(loop.shared_parameters()),
+    }
+    bad = 0
+    for ts in named.values():
+        for t in ts:
+            if t is not None and t.is_floating_point():
+                bad += int((~torch.isfinite(t)).sum())
+    return {k: md5(*v) for k, v in named.items()}, bad
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    which = sys.argv[2] if len(sys.argv) > 2 else "all"
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    names = list(CELLS) if which == "all" else [n.strip() for n in which.split(",")]
+    lib = L.lib()
+    conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
+    cpu = os.environ.get("RECMV_REPRO_CPU") == "1"          # logic smoke test of this tool on the host (tiny scene)
+    dev = torch.device("cpu") if cpu else torch.device("cuda", 0)
+    t0 = time.time()
+    lib.recmv_set_gemm_mode(0)
+    if cpu:
+        from oracle import cpu_port                         # (tool smoke test only: the host stand-in of tests/)
+        cpu_port.install()
+        conf.put('train.sample_pix_num', 32)
+        loop = HotLoop(conf, "cpu", n_frames=12, H=64, W=64, resolutions=[(9, 11, 7), (17, 21, 13)], skin_grid=(5, 9, 7), curves=True)
+    else:
+        loop = HotLoop(conf, dev, n_frames=64, H=512, W=512, curves=True)
+    for it in range(2):                       # re-mesh + one plain iteration: every kernel loaded, every pool grown
+        loop.step(it)
+    if not cpu:
+        torch.cuda.synchronize()
+    snap = Snapshot(loop)
+    print("# built + warmed up in %.1f s; %d repetitions of %d iteration(s) per cell; vertices %s" % (
+        time.time() - t0, reps, steps, [int(v.shape[0]) for v in loop.garment_vs]), flush=True)
+    for name in names:
+        mode, fill, env = CELLS[name]
+        for k in ENV_KEYS:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        lib.recmv_set_gemm_mode(mode)
+        lib.recmv_set_jet_fill(fill)
+        whole, groups, bad_total, rays = Counter(), {}, 0, None
+        t1 = time.time()
+        for _ in range(reps):
+            snap.restore()
+            for s in range(steps):
+                loss, rays = loop.step(2 + s)
+            if not cpu:
+                torch.cuda.synchronize()
+            d, bad = digests(loop, loss)
+            bad_total += bad
+            whole[md5(*[torch.frombuffer(bytearray("".join(d.values()).encode()), dtype=torch.uint8)])] += 1
+            for k, v in d.items():
+                groups.setdefault(k, Counter())[v] += 1
+        parted = {k: sorted(c.values(), reverse=True) for k, c in groups.items() if len(c) > 1}
+        print("%-52s %s  non-finite %d  rays %s conv %s  %.1f s%s" % (
+            name, " ".join("%s x%d" % kv for kv in whole.most_common()), bad_total, rays, loop.info.get("rays_converged"),
+            time.time() - t1, ("   PARTED in: " + ", ".join("%s %s" % kv for kv in parted.items())) if parted else ""), flush=True)
+    for k in ENV_KEYS:
+        os.environ.pop(k, None)
+    lib.recmv_set_gemm_mode(0)
+    lib.recmv_set_jet_fill(1)
+
+
+if __name__ == "__main__":
+    main()

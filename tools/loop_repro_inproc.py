@@ -43,6 +43,10 @@ CELLS = {
     "bf16x6 side-stream memset-fill POISON": (1, 0, {"RECMV_RENDER_STREAMS": "1", "RECMV_POISON": "1"}),
     "bf16x6 side-stream POISON": (1, 1, {"RECMV_RENDER_STREAMS": "1", "RECMV_POISON": "1"}),
     "f32 side-stream POISON": (0, 1, {"RECMV_RENDER_STREAMS": "1", "RECMV_POISON": "1"}),
+    "bf16x6 side-stream no-presplit": (1, 1, {"RECMV_RENDER_STREAMS": "1", "RECMV_B3_PRESPLIT": "0"}),
+    "bf16x6 side-stream two-jet-passes": (1, 1, {"RECMV_RENDER_STREAMS": "1", "RECMV_MERGE_JETS": "0"}),
+    "bf16x6 side-stream no-curve-branch": (1, 1, {"RECMV_RENDER_STREAMS": "1", "REPRO_CURVES": "0"}),
+    "bf16x6 one-ray-stream no-curve-branch": (1, 1, {"RECMV_RENDER_STREAMS": "0", "REPRO_CURVES": "0"}),
     "bf16x6 serial": (1, 1, {"RECMV_SERIAL": "1"}),
     "f32 serial": (0, 1, {"RECMV_SERIAL": "1"}),
 }
@@ -113,6 +117,11 @@ def digests(loop, loss):
         "TmpPs.grad": [t.grad for t in loop.TmpPs if t is not None],
         "params_after": list(loop.shared_parameters()),
     }
+    for n_, p_ in loop.deformer.named_parameters():          # which tensor of the offset MLP
+        named["def:" + n_.replace("defs.0.", "")] = [p_.grad]
+    for stage, grads in getattr(loop, "_stage_grads", {}).items():      # ... and after which phase (clones taken on the main stream)
+        for n_, g_ in grads.items():
+            named["%s:%s" % (stage, n_)] = [g_]
     bad = 0
     for ts in named.values():
         for t in ts:
@@ -144,6 +153,25 @@ def main():
     if not cpu:
         torch.cuda.synchronize()
     snap = Snapshot(loop)
+    if os.environ.get("RECMV_REPRO_STAGES") == "1":
+        # the offset MLP's gradients as they stand after the mask loss's backward, after the final backward and after the implicit
+        # differentiation: stream-ordered clones on the main stream, no host synchronisation added
+        def grab(stage):
+            loop.__dict__.setdefault("_stage_grads", {})[stage] = {
+                n_.replace("defs.0.", ""): (p_.grad.clone() if p_.grad is not None else None)
+                for n_, p_ in loop.deformer.named_parameters() if n_.endswith("lin0.weight") or n_.endswith("lin2.weight")
+                or n_.endswith("lin4.bias")}
+        orig_mask, orig_prop = loop.mask_loss, loop.propagateTmpPsGrad
+
+        def mask_loss(*a, **k):
+            out = orig_mask(*a, **k)
+            grab("after_mask")
+            return out
+
+        def prop(*a, **k):
+            grab("after_backward")
+            return orig_prop(*a, **k)
+        loop.mask_loss, loop.propagateTmpPsGrad = mask_loss, prop
     print("# built + warmed up in %.1f s; %d repetitions of %d iteration(s) per cell; vertices %s" % (
         time.time() - t0, reps, steps, [int(v.shape[0]) for v in loop.garment_vs]), flush=True)
     for name in names:
@@ -153,6 +181,7 @@ def main():
         os.environ.update(env)
         lib.recmv_set_gemm_mode(mode)
         lib.recmv_set_jet_fill(fill)
+        loop.curves = os.environ.pop("REPRO_CURVES", "1") != "0"       # (the curve branch and its stream: a run-time switch of the loop)
         whole, groups, bad_total, rays = Counter(), {}, 0, None
         t1 = time.time()
         for _ in range(reps):

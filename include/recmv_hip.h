@@ -242,6 +242,9 @@ int recmv_gemm_nt_mulgrad_seg(const float* A, int64_t lda, const float* B, const
  * matrix rate).  Returns the previous mode. */
 int recmv_set_gemm_mode(int mode);
 int recmv_get_gemm_mode(void);
+/* Mode 1 only: which kernel families compute in bf16x6 — bit 0 the 128 x 128 NT tiles, bit 1 the 64 x 64 / 64 x 32 NT tiles, bit 2 the
+ * TN (dW) tiles; the others stay on the exact-f32 kernels.  7 (default) = all.  A bisect / A-B switch; returns the previous mask. (ABI v7) */
+int recmv_set_b3_families(int mask);
 /* How the jet pass (recmv_mlp_jet_forward) zeroes the code / padding columns of its tangent rows: 1 (default) = a kernel over those
  * columns only, 0 = hipMemsetAsync over the whole tangent block (rounds 1-4; the A/B of tools/loop_repro_inproc.py).  Same bits either
  * way.  Process-global; RECMV_JET_FILL_KERNEL=0 sets 0 at load.  Returns the previous value.  (ABI v7) */

@@ -1468,6 +1468,7 @@ int tn_splits(int64_t M, int64_t N, int64_t K) {
 
 using namespace recmv;
 
+int g_b3_families = 7;   // mode 1 only: bit 0 the 128 x 128 NT kernels, bit 1 the 64 x 64 / 64 x 32 NT kernels, bit 2 the TN (dW) kernel
 int g_gemm_mode = 0;     // 0: f32 MFMA (exact f32 products), 1: bf16x6 (3-way bf16 split, six bf16 MFMA products)
 
 template <int T, bool FAST, bool AMUL, bool BF3>
@@ -1574,13 +1575,15 @@ static int dispatch_nt(const float* A, int64_t lda, const float* B, int64_t ldb,
   const bool fast = a_vec && b_vec && K % 4 == 0 && K > 0;
   // tile choice: 128x128 tiles unless they would leave the 256 CUs under-filled (< 2 workgroups per CU)
   const int64_t big_blocks = ceil_div(M, BM) * ceil_div(N, BN);
+  // (which kernel families take the bf16x6 path in mode 1: recmv_set_b3_families, all of them by default)
+  const bool bf3_big = g_gemm_mode == 1 && (g_b3_families & 1), bf3_mid = g_gemm_mode == 1 && (g_b3_families & 2);
 #define RECMV_NT(TT, FF)                                                                                          \
-  (g_gemm_mode == 1 ? launch_nt<TT, FF, AMUL, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, \
+  ((TT == 2 ? bf3_big : bf3_mid) ? launch_nt<TT, FF, AMUL, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, \
                                                     a_vec, b_vec, c_vec, am, s)                                    \
                     : launch_nt<TT, FF, AMUL, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param,        \
                                                      out_scale, a_vec, b_vec, c_vec, am, s))
   if (big_blocks >= 2 * kNumCU) {
-    if (g_gemm_mode == 1 && fast) {
+    if (bf3_big && fast) {
       return launch_nt_b3<2, AMUL>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, c_vec, am, s);
     }
     // f32 mode, aligned operands: the high-occupancy kernels (gemm_nt_occ_kernel) — 128x128 tiles at four workgroups per CU
@@ -1588,7 +1591,7 @@ static int dispatch_nt(const float* A, int64_t lda, const float* B, int64_t ldb,
     // 90 k and 150 k rows at N = 512: profiles/r03_gemm_occupancy_variants.txt).  RECMV_GEMM_OCC=0 keeps the two-per-CU
     // kernel for the A/B.
     static const bool occ = [] { const char* e = getenv("RECMV_GEMM_OCC"); return !(e && e[0] == '0'); }();
-    if (fast && g_gemm_mode == 0 && occ) {
+    if (fast && !bf3_big && occ) {
       if (big_blocks >= 3600)
         return launch_nt_occ<AMUL, 16, true, 2, 2>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, c_vec, am, s);
       return launch_nt_occ<AMUL, 16, true, 1, 2>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, c_vec, am, s);
@@ -1599,7 +1602,7 @@ static int dispatch_nt(const float* A, int64_t lda, const float* B, int64_t ldb,
   const int64_t mid_blocks = ceil_div(M, 64) * ceil_div(N, 64);
   if (mid_blocks < (5 * kNumCU) / 2) {
 #define RECMV_NTN(FF)                                                                                                  \
-  (g_gemm_mode == 1 ? launch_nt_narrow<FF, AMUL, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, \
+  (bf3_mid ? launch_nt_narrow<FF, AMUL, true>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param, out_scale, \
                                                        a_vec, b_vec, c_vec, am, s)                                     \
                     : launch_nt_narrow<FF, AMUL, false>(A, lda, B, ldb, bias, C, ldc, M, N, K, act, act_param,          \
                                                         out_scale, a_vec, b_vec, c_vec, am, s))
@@ -1620,6 +1623,15 @@ extern "C" int recmv_set_gemm_mode(int mode) {
 }
 
 extern "C" int recmv_get_gemm_mode(void) { return g_gemm_mode; }
+
+// Mode 1 only — which kernel families compute in bf16x6 (the others stay on the exact-f32 kernels): bit 0 = 128 x 128 NT tiles, bit 1 =
+// 64 x 64 and 64 x 32 NT tiles, bit 2 = TN (dW) tiles.  7 (default) = all.  A bisect / A-B switch (tools/loop_repro_inproc.py); returns
+// the previous mask.
+extern "C" int recmv_set_b3_families(int mask) {
+  const int prev = g_b3_families;
+  if (mask >= 0 && mask <= 7) g_b3_families = mask;
+  return prev;
+}
 
 extern "C" int64_t recmv_b3_planes_bytes(int64_t N, int64_t K) {
   if (N <= 0 || K <= 0) return 0;
@@ -1765,11 +1777,12 @@ extern "C" int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_
   int rc;
   {                          // the events bracket the product kernel alone (slot 8 = one kernel symbol); its reduction pass follows
   ScopedLaunchTimer timer(8, 2.0 * M * N * K, s);
-  if (g_gemm_mode == 0 && tn_occ() && a_vec && b_vec && lda >= ((M + 3) & ~3ll) && ldb >= ((N + 3) & ~3ll) && M >= 4 && N >= 4) {
+  const bool bf3_tn = g_gemm_mode == 1 && (g_b3_families & 4);
+  if (!bf3_tn && tn_occ() && a_vec && b_vec && lda >= ((M + 3) & ~3ll) && ldb >= ((N + 3) & ~3ll) && M >= 4 && N >= 4) {
     kchunk = ceil_div(ceil_div(K, splits), 16) * 16;
     hipLaunchKernelGGL(gemm_tn_occ_kernel<16>, dim3((unsigned)(nbm * nbn * splits)), dim3(kBlk), 2 * 16 * LDM * 4, s, A, lda,
                        B, ldb, (float*)workspace, (int)M, (int)N, K, nbm, nbn, kchunk);
-  } else if (g_gemm_mode == 1)
+  } else if (bf3_tn)
     hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)(nbm * nbn * splits)), dim3(kBlk), kTnLds, s, A, lda, B,
                        ldb, (float*)workspace, (int)M, (int)N, K, nbm, nbn, kchunk, a_vec, b_vec);
   else

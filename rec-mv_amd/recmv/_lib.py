@@ -92,6 +92,7 @@ def _declare(lib):
         "recmv_gemm_nt_mulgrad_seg": (C.c_int, [vp, i64, vp, vp, i64, i64, vp, i64, i64, i64, i64, vp, i64, i32, f32, f32, f32, vp]),
         "recmv_set_gemm_mode": (C.c_int, [i32]),
         "recmv_get_gemm_mode": (C.c_int, []),
+        "recmv_set_b3_families": (C.c_int, [i32]),
         "recmv_b3_planes_bytes": (i64, [i64, i64]),
         "recmv_b3_split": (C.c_int, [vp, i64, i64, i64, vp, i64, vp]),
         "recmv_b3_forget": (C.c_int, [vp]),

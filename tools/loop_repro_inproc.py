@@ -47,6 +47,12 @@ CELLS = {
     "bf16x6 side-stream two-jet-passes": (1, 1, {"RECMV_RENDER_STREAMS": "1", "RECMV_MERGE_JETS": "0"}),
     "bf16x6 side-stream no-curve-branch": (1, 1, {"RECMV_RENDER_STREAMS": "1", "REPRO_CURVES": "0"}),
     "bf16x6 one-ray-stream no-curve-branch": (1, 1, {"RECMV_RENDER_STREAMS": "0", "REPRO_CURVES": "0"}),
+    "bf16x6 side-stream fam=big+mid (TN in f32)": (1, 1, {"RECMV_RENDER_STREAMS": "1", "REPRO_FAMILIES": "3"}),
+    "bf16x6 side-stream fam=big+TN (mid NT in f32)": (1, 1, {"RECMV_RENDER_STREAMS": "1", "REPRO_FAMILIES": "5"}),
+    "bf16x6 side-stream fam=mid+TN (big NT in f32)": (1, 1, {"RECMV_RENDER_STREAMS": "1", "REPRO_FAMILIES": "6"}),
+    "bf16x6 side-stream fam=big": (1, 1, {"RECMV_RENDER_STREAMS": "1", "REPRO_FAMILIES": "1"}),
+    "bf16x6 side-stream fam=mid": (1, 1, {"RECMV_RENDER_STREAMS": "1", "REPRO_FAMILIES": "2"}),
+    "bf16x6 side-stream fam=TN": (1, 1, {"RECMV_RENDER_STREAMS": "1", "REPRO_FAMILIES": "4"}),
     "bf16x6 serial": (1, 1, {"RECMV_SERIAL": "1"}),
     "f32 serial": (0, 1, {"RECMV_SERIAL": "1"}),
 }
@@ -181,10 +187,12 @@ def main():
         os.environ.update(env)
         lib.recmv_set_gemm_mode(mode)
         lib.recmv_set_jet_fill(fill)
+        lib.recmv_set_b3_families(int(os.environ.pop("REPRO_FAMILIES", "7")))
         loop.curves = os.environ.pop("REPRO_CURVES", "1") != "0"       # (the curve branch and its stream: a run-time switch of the loop)
         whole, groups, bad_total, rays = Counter(), {}, 0, None
         t1 = time.time()
-        for _ in range(reps):
+        ref, reports, report = None, 0, []
+        for _rep in range(reps):
             snap.restore()
             for s in range(steps):
                 loss, rays = loop.step(2 + s)
@@ -192,6 +200,30 @@ def main():
                 torch.cuda.synchronize()
             d, bad = digests(loop, loss)
             bad_total += bad
+            # where and by how much a repetition parts from the cell's first one (the offset MLP's weight gradients + the loss)
+            cur = {"loss": loss.detach().double().view(1, 1).cpu()}
+            for n_, p_ in loop.deformer.named_parameters():
+                if n_.endswith("weight") and p_.grad is not None and "defs.0" in n_:
+                    cur[n_.replace("defs.0.", "")] = p_.grad.detach().cpu()
+            for k_, t_ in loop.__dict__.get("_stage_grads", {}).get("after_backward", {}).items():
+                if t_ is not None and t_.dim() == 2:
+                    cur["after_backward:" + k_] = t_.cpu()
+            if ref is None:
+                ref = cur
+            elif reports < 6:
+                lines = []
+                for k_, t_ in cur.items():
+                    r_ = ref[k_]
+                    ne = (t_ != r_)
+                    if bool(ne.any()):
+                        rows, cols = ne.any(1).nonzero().view(-1), ne.any(0).nonzero().view(-1)
+                        dd = (t_.double() - r_.double()).abs()
+                        lines.append("      %-28s %d of %d elements differ, max |d| %.3e (max |ref| %.3e), rows %d..%d (%d distinct), cols %d..%d (%d distinct)" % (
+                            k_, int(ne.sum()), ne.numel(), float(dd.max()), float(r_.double().abs().max()), int(rows.min()), int(rows.max()),
+                            rows.numel(), int(cols.min()), int(cols.max()), cols.numel()))
+                if lines:
+                    reports += 1
+                    report.append("    repetition %d parts from repetition 0:\n%s" % (_rep, "\n".join(lines)))
             whole[md5(*[torch.frombuffer(bytearray("".join(d.values()).encode()), dtype=torch.uint8)])] += 1
             for k, v in d.items():
                 groups.setdefault(k, Counter())[v] += 1
@@ -199,10 +231,13 @@ def main():
         print("%-52s %s  non-finite %d  rays %s conv %s  %.1f s%s" % (
             name, " ".join("%s x%d" % kv for kv in whole.most_common()), bad_total, rays, loop.info.get("rays_converged"),
             time.time() - t1, ("   PARTED in: " + ", ".join("%s %s" % kv for kv in parted.items())) if parted else ""), flush=True)
+        for r_ in report:
+            print(r_, flush=True)
     for k in ENV_KEYS:
         os.environ.pop(k, None)
     lib.recmv_set_gemm_mode(0)
     lib.recmv_set_jet_fill(1)
+    lib.recmv_set_b3_families(7)
 
 
 if __name__ == "__main__":

@@ -125,6 +125,9 @@ def digests(loop, loss):
     }
     for n_, p_ in loop.deformer.named_parameters():          # which tensor of the offset MLP
         named["def:" + n_.replace("defs.0.", "")] = [p_.grad]
+    for name_, y_, J_ in loop.__dict__.get("_jet_log", []):
+        named[name_ + " y"] = [y_]
+        named[name_ + " J"] = [J_]
     for stage, grads in getattr(loop, "_stage_grads", {}).items():      # ... and after which phase (clones taken on the main stream)
         for n_, g_ in grads.items():
             named["%s:%s" % (stage, n_)] = [g_]
@@ -178,6 +181,17 @@ def main():
             grab("after_backward")
             return orig_prop(*a, **k)
         loop.mask_loss, loop.propagateTmpPsGrad = mask_loss, prop
+    if os.environ.get("RECMV_REPRO_JETS") == "1":
+        # every jet pass of the iteration (SDF nets and offset MLP, all streams): its outputs cloned on the stream that produced them
+        from recmv import chains
+        orig_jet = chains.mlp_jet
+        jets = loop.__dict__.setdefault("_jet_log", [])
+
+        def mlp_jet(x, cond, cond_index, Ws, bs, dims, *a, **k):
+            y, J = orig_jet(x, cond, cond_index, Ws, bs, dims, *a, **k)
+            jets.append(("jet%02d P=%d dims=%d..%d" % (len(jets), x.shape[0], dims[0], dims[-1]), y.detach().clone(), J.detach().clone()))
+            return y, J
+        chains.mlp_jet = mlp_jet
     print("# built + warmed up in %.1f s; %d repetitions of %d iteration(s) per cell; vertices %s" % (
         time.time() - t0, reps, steps, [int(v.shape[0]) for v in loop.garment_vs]), flush=True)
     for name in names:
@@ -194,6 +208,7 @@ def main():
         ref, reports, report = None, 0, []
         for _rep in range(reps):
             snap.restore()
+            loop.__dict__.get("_jet_log", []).clear()
             for s in range(steps):
                 loss, rays = loop.step(2 + s)
             if not cpu:

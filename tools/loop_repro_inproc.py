@@ -125,6 +125,9 @@ def digests(loop, loss):
     }
     for n_, p_ in loop.deformer.named_parameters():          # which tensor of the offset MLP
         named["def:" + n_.replace("defs.0.", "")] = [p_.grad]
+    for k_, v_ in loop.info.items():                         # every loss term the iteration reports
+        if torch.is_tensor(v_) and v_.numel() == 1:
+            named["info:" + k_] = [v_]
     for name_, y_, J_ in loop.__dict__.get("_jet_log", []):
         named[name_ + " y"] = [y_]
         named[name_ + " J"] = [J_]
@@ -192,6 +195,15 @@ def main():
             jets.append(("jet%02d P=%d dims=%d..%d" % (len(jets), x.shape[0], dims[0], dims[-1]), y.detach().clone(), J.detach().clone()))
             return y, J
         chains.mlp_jet = mlp_jet
+        from recmv import ops as _ops
+        orig_regu = _ops.def_regu
+
+        def def_regu(J, c):
+            y = orig_regu(J, c)
+            n_ = sum(1 for e in jets if e[0].startswith("regu"))
+            jets.append(("regu%d P=%d" % (n_, J.shape[0]), y.detach().clone(), J.detach().clone()))
+            return y
+        _ops.def_regu = def_regu
     print("# built + warmed up in %.1f s; %d repetitions of %d iteration(s) per cell; vertices %s" % (
         time.time() - t0, reps, steps, [int(v.shape[0]) for v in loop.garment_vs]), flush=True)
     for name in names:

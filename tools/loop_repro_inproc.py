@@ -204,6 +204,23 @@ def main():
             jets.append(("regu%d P=%d" % (n_, J.shape[0]), y.detach().clone(), J.detach().clone()))
             return y
         _ops.def_regu = def_regu
+        # ... and what the regulariser's kernel was handed (the contiguous copy of J) and what it left for the backward pass
+        import ctypes as C_
+
+        def regu_forward(ctx, J, c):
+            Jc = J.detach().contiguous()
+            P_ = Jc.shape[0]
+            y = torch.empty(P_, dtype=torch.float32, device=J.device)
+            gJ = torch.empty_like(Jc)
+            L.check(L.lib().recmv_def_regu(L.ptr(Jc), P_, float(c), L.ptr(y), L.ptr(gJ), L.stream_ptr(J.device)), "def_regu")
+            n_ = sum(1 for e in jets if e[0].startswith("kern"))
+            jets.append(("kern%d regu input copy / dy/dJ" % n_, Jc.clone(), gJ.clone()))
+            y2, gJ2 = torch.empty_like(y), torch.empty_like(gJ)           # the same launch once more, right behind the first
+            L.check(L.lib().recmv_def_regu(L.ptr(Jc), P_, float(c), L.ptr(y2), L.ptr(gJ2), L.stream_ptr(J.device)), "def_regu")
+            jets.append(("kern%d regu second launch y / dy/dJ" % n_, y2, gJ2))
+            ctx.save_for_backward(gJ)
+            return y
+        _ops.DefRegu.forward = staticmethod(regu_forward)
     print("# built + warmed up in %.1f s; %d repetitions of %d iteration(s) per cell; vertices %s" % (
         time.time() - t0, reps, steps, [int(v.shape[0]) for v in loop.garment_vs]), flush=True)
     for name in names:

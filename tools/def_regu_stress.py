@@ -1,5 +1,13 @@
-"""Is recmv_def_regu bit-reproducible from launch to launch while two other streams run the bf16x6 mode's large products?
-    python tools/def_regu_stress.py [repeats=400]"""
+"""Is recmv_def_regu bit-reproducible from launch to launch while two other streams run large products?  Which products disturb it,
+and what do the differences look like?
+
+    python tools/def_regu_stress.py [repeats=400]
+    RECMV_GEMM_OCC=0 python tools/def_regu_stress.py      # the f32 mode's products on the 128 x 128 kernel with 72 KB of LDS
+
+Round 5: with the bf16x6 mode's 128 x 128 kernel (gemm_nt_b3_kernel, 66 KB of dynamic LDS per workgroup) on the side streams, a few
+launches in a hundred of this per-thread, atomics-free kernel give different bits for the SAME input (profiles/r05_def_regu_stress*.txt).
+"""
+import os
 import sys
 from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
@@ -13,23 +21,51 @@ dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(0)
 P = 30714
 J = (torch.eye(3).view(1, 3, 3) + 0.02 * torch.randn(P, 3, 3, generator=g)).to(dev).contiguous()
-noiseA, noiseB = torch.randn(120000, 512, generator=g).to(dev), (torch.randn(512, 512, generator=g) / 22.0).to(dev)
+big_A, big_B = torch.randn(120000, 512, generator=g).to(dev), (torch.randn(512, 512, generator=g) / 22.0).to(dev)
+mid_A = torch.randn(12000, 512, generator=g).to(dev)
+tn_A, tn_B = torch.randn(120000, 512, generator=g).to(dev), torch.randn(120000, 512, generator=g).to(dev)
 side = [torch.cuda.Stream(), torch.cuda.Stream()]
-for mode in (1, 0):
+print("# RECMV_GEMM_OCC=%s" % os.environ.get("RECMV_GEMM_OCC", "(unset)"))
+
+
+def run(label, mode, fam, work):
     lib.recmv_set_gemm_mode(mode)
+    lib.recmv_set_b3_families(fam)
     y0, g0 = torch.empty(P, device=dev), torch.empty_like(J)
     L.check(lib.recmv_def_regu(L.ptr(J), P, 0.03, L.ptr(y0), L.ptr(g0), L.stream_ptr(dev)), "def_regu")
     torch.cuda.synchronize()
-    for busy in (False, True):
-        bad = 0
-        for r in range(reps):
-            if busy:
-                for st in side:
-                    with torch.cuda.stream(st):
-                        ops.gemm_nt(noiseA, noiseB, None, ops.ACT_RELU, 0.0)
-            y, gj = torch.empty(P, device=dev), torch.empty_like(J)
-            L.check(lib.recmv_def_regu(L.ptr(J), P, 0.03, L.ptr(y), L.ptr(gj), L.stream_ptr(dev)), "def_regu")
-            bad += int(not (torch.equal(y, y0) and torch.equal(gj, g0)))
-        print("def_regu, %s products on two side streams %s: %d of %d launches differ from the first" % (
-            "bf16x6" if mode else "f32", "busy" if busy else "idle", bad, reps), flush=True)
+    bad, shown = 0, 0
+    for r in range(reps):
+        if work is not None:
+            for st in side:
+                with torch.cuda.stream(st):
+                    work()
+        y, gj = torch.empty(P, device=dev), torch.empty_like(J)
+        L.check(lib.recmv_def_regu(L.ptr(J), P, 0.03, L.ptr(y), L.ptr(gj), L.stream_ptr(dev)), "def_regu")
+        same = torch.equal(y, y0) and torch.equal(gj, g0)
+        if not same:
+            bad += 1
+            if shown < 3:
+                shown += 1
+                torch.cuda.synchronize()
+                ny = (y != y0).nonzero().view(-1)
+                ng = (gj != g0).view(P, 9).any(1).nonzero().view(-1)
+                idx = torch.unique(torch.cat([ny, ng]))
+                blocks = torch.unique(idx // 256)
+                lanes = torch.unique(idx % 64)
+                dy = (y - y0).abs().max().item()
+                dg = (gj - g0).abs().max().item()
+                print("    launch %d: %d matrices differ (y %d, dy/dJ %d) in %d workgroup(s) %s, lanes %s; max |dy| %.3e (max |y| %.3e), "
+                      "max |d dy/dJ| %.3e (max %.3e); first matrices %s" % (
+                          r, idx.numel(), ny.numel(), ng.numel(), blocks.numel(), blocks[:6].tolist(), lanes[:8].tolist(), dy,
+                          y0.abs().max().item(), dg, g0.abs().max().item(), idx[:6].tolist()), flush=True)
+    print("def_regu beside %-64s %d of %d launches differ from the first" % (label + ":", bad, reps), flush=True)
+
+
+run("idle side streams", 1, 7, None)
+run("bf16x6 128x128 products (gemm_nt_b3_kernel, 66 KB LDS)", 1, 7, lambda: ops.gemm_nt(big_A, big_B, None, ops.ACT_RELU, 0.0))
+run("bf16x6 64x64 products (gemm_nt_kernel<1,..,BF3>, 36 KB LDS)", 1, 7, lambda: ops.gemm_nt(mid_A, big_B, None, ops.ACT_RELU, 0.0))
+run("bf16x6 TN products (gemm_tn_kernel<BF3>, 66 KB LDS)", 1, 7, lambda: ops.gemm_tn(tn_A, tn_B))
+run("f32 128x128 products", 0, 7, lambda: ops.gemm_nt(big_A, big_B, None, ops.ACT_RELU, 0.0))
+run("f32 TN products", 0, 7, lambda: ops.gemm_tn(tn_A, tn_B))
 lib.recmv_set_gemm_mode(0)

@@ -1,0 +1,241 @@
+// Why does a per-thread, atomics-free kernel (csrc/def_regu.hip) give different bits for the same input when the bf16x6 mode's NT
+// product kernels run beside it on other streams?  (tools/def_regu_stress.py: a few launches in a hundred, always lanes 48..63 of a
+// wave, errors up to the size of the values.)  Variants of the kernel, each launched `iters` times on the same input while two other
+// streams run recmv_gemm_nt (bf16x6, 64 x 64 tiles); a launch is "bad" when its output differs from the first launch's.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/bin/valu_disturb_repro tools/valu_disturb_repro.hip -Iinclude -Lrec-mv_amd/lib -lrecmv_hip -Wl,-rpath,$PWD/rec-mv_amd/lib
+//   tools/bin/valu_disturb_repro [iters=300]
+//
+//   V0  the product's kernel: LDS staging of the 3x3 matrices + libm sqrtf / logf / division
+//   V1  the same arithmetic, global loads and stores only (no LDS)
+//   V2  LDS staging, raw hardware transcendentals (v_rcp / v_sqrt / v_log) instead of libm's refined sequences
+//   V3  V2 with `s_nop 7` tied to every transcendental's result
+//   V4  no transcendental at all: a dependent chain of FMAs per thread, LDS staging
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "recmv_hip.h"
+
+#define CK(x)                                                                              \
+  do {                                                                                     \
+    hipError_t e__ = (x);                                                                  \
+    if (e__ != hipSuccess) {                                                               \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e__)); \
+      exit(2);                                                                             \
+    }                                                                                      \
+  } while (0)
+
+constexpr int kBlk = 256;
+
+template <int V>
+__device__ __forceinline__ float t_rcp(float x) {
+  if (V == 2) return __builtin_amdgcn_rcpf(x);
+  float r = __builtin_amdgcn_rcpf(x);
+  asm volatile("s_nop 7" : "+v"(r));
+  return r;
+}
+template <int V>
+__device__ __forceinline__ float t_sqrt(float x) {
+  if (V == 2) return __builtin_amdgcn_sqrtf(x);
+  float r = __builtin_amdgcn_sqrtf(x);
+  asm volatile("s_nop 7" : "+v"(r));
+  return r;
+}
+template <int V>
+__device__ __forceinline__ float t_log(float x) {
+  if (V == 2) return __builtin_amdgcn_logf(x) * 0.6931471805599453f;
+  float r = __builtin_amdgcn_logf(x);
+  asm volatile("s_nop 7" : "+v"(r));
+  return r * 0.6931471805599453f;
+}
+
+template <int V, int p, int q>
+__device__ __forceinline__ void rotate(float (&b)[3][3], float (&v)[3][3]) {
+  const float alpha = b[0][p] * b[0][p] + b[1][p] * b[1][p] + b[2][p] * b[2][p];
+  const float beta = b[0][q] * b[0][q] + b[1][q] * b[1][q] + b[2][q] * b[2][q];
+  const float gamma = b[0][p] * b[0][q] + b[1][p] * b[1][q] + b[2][p] * b[2][q];
+  if (fabsf(gamma) < 1e-37f) return;
+  float zeta, t, c;
+  if (V <= 1) {
+    zeta = (beta - alpha) / (2.f * gamma);
+    t = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(zeta * zeta + 1.f));
+    c = 1.f / sqrtf(t * t + 1.f);
+  } else {
+    zeta = (beta - alpha) * t_rcp<V>(2.f * gamma);
+    t = (zeta >= 0.f ? 1.f : -1.f) * t_rcp<V>(fabsf(zeta) + t_sqrt<V>(zeta * zeta + 1.f));
+    c = t_rcp<V>(t_sqrt<V>(t * t + 1.f));
+  }
+  const float s = t * c;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float bp = b[k][p], bq = b[k][q];
+    b[k][p] = c * bp - s * bq;
+    b[k][q] = s * bp + c * bq;
+    const float vp = v[k][p], vq = v[k][q];
+    v[k][p] = c * vp - s * vq;
+    v[k][q] = s * vp + c * vq;
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(kBlk) void regu_variant(const float* __restrict__ J, long P, float inv_c2, float* __restrict__ y,
+                                                     float* __restrict__ gJ) {
+  __shared__ float tile[kBlk * 9];
+  const long base = (long)blockIdx.x * kBlk;
+  const int n = (int)((P - base) < kBlk ? (P - base) : kBlk);
+  const int t = threadIdx.x;
+  if (V != 1) {
+    for (int e = threadIdx.x; e < n * 9; e += kBlk) tile[e] = J[base * 9 + e];
+    __syncthreads();
+  }
+  float g[9];
+  if (t < n) {
+    float b[3][3], v[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        b[i][j] = V != 1 ? tile[t * 9 + 3 * i + j] : J[(base + t) * 9 + 3 * i + j];
+        v[i][j] = i == j ? 1.f : 0.f;
+      }
+    if (V == 4) {
+      // no transcendental: 60 dependent FMAs per entry
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float z = b[i][j];
+#pragma unroll
+          for (int r = 0; r < 60; ++r) z = fmaf(z, 0.99f, b[(i + r) % 3][(j + r / 3) % 3] * 0.01f);
+          g[3 * i + j] = z;
+          acc += z;
+        }
+      y[base + t] = acc;
+    } else {
+#pragma unroll
+      for (int sweep = 0; sweep < 5; ++sweep) {
+        rotate<V, 0, 1>(b, v);
+        rotate<V, 0, 2>(b, v);
+        rotate<V, 1, 2>(b, v);
+      }
+      float x = 0.f, w[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float lam = b[0][i] * b[0][i] + b[1][i] * b[1][i] + b[2][i] * b[2][i];
+        const bool live = lam > 1e-20f;
+        const float lc = live ? lam : 1e-20f;
+        const float s = 0.5f * (V <= 1 ? logf(lc) : t_log<V>(lc));
+        x += s * s;
+        w[i] = live ? (V <= 1 ? s / lc : s * t_rcp<V>(lc)) : 0.f;
+      }
+      const float u = x * inv_c2;
+      const float d = V <= 1 ? 1.f / (u + 4.f) : t_rcp<V>(u + 4.f);
+      y[base + t] = 2.f * u * d;
+      const float k2 = 2.f * 8.f * inv_c2 * d * d;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g[3 * i + j] = k2 * (b[i][0] * w[0] * v[j][0] + b[i][1] * w[1] * v[j][1] + b[i][2] * w[2] * v[j][2]);
+    }
+  }
+  if (V == 1) {
+    if (t < n)
+#pragma unroll
+      for (int e = 0; e < 9; ++e) gJ[(base + t) * 9 + e] = g[e];
+    return;
+  }
+  __syncthreads();
+  if (t < n) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) tile[t * 9 + e] = g[e];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n * 9; e += kBlk) gJ[base * 9 + e] = tile[e];
+}
+
+typedef void (*Kern)(const float*, long, float, float*, float*);
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 300;
+  const long P = 30714;
+  std::vector<float> hJ(P * 9);
+  unsigned s = 12345u;
+  auto rnd = [&]() {
+    s = s * 1664525u + 1013904223u;
+    return ((s >> 8) * (1.f / 16777216.f)) - 0.5f;
+  };
+  for (long i = 0; i < P; ++i)
+    for (int e = 0; e < 9; ++e) hJ[i * 9 + e] = (e % 4 == 0 ? 1.f : 0.f) + 0.06f * rnd();
+  float *J, *y, *g, *y0, *g0;
+  CK(hipMalloc(&J, P * 36));
+  CK(hipMalloc(&y, P * 4));
+  CK(hipMalloc(&g, P * 36));
+  CK(hipMalloc(&y0, P * 4));
+  CK(hipMalloc(&g0, P * 36));
+  CK(hipMemcpy(J, hJ.data(), P * 36, hipMemcpyHostToDevice));
+  // the disturbing work: bf16x6 products with 64 x 64 tiles (12 000 x 512 x 512) on two side streams
+  const long M = 12000, N = 512, K = 512;
+  float *A, *B, *C[2];
+  CK(hipMalloc(&A, M * K * 4));
+  CK(hipMalloc(&B, N * K * 4));
+  std::vector<float> hA(M * K), hB(N * K);
+  for (auto& v : hA) v = rnd();
+  for (auto& v : hB) v = rnd() * 0.05f;
+  CK(hipMemcpy(A, hA.data(), M * K * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(B, hB.data(), N * K * 4, hipMemcpyHostToDevice));
+  hipStream_t main_s, side[2];
+  CK(hipStreamCreateWithFlags(&main_s, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    CK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+    CK(hipMalloc(&C[i], M * N * 4));
+  }
+  Kern kerns[5] = {regu_variant<0>, regu_variant<1>, regu_variant<2>, regu_variant<3>, regu_variant<4>};
+  const char* names[5] = {"V0 LDS + libm (the product's kernel)", "V1 no LDS, libm", "V2 LDS, raw v_rcp/v_sqrt/v_log",
+                          "V3 LDS, raw transcendentals + s_nop 7 behind each", "V4 LDS, FMA chain, no transcendental"};
+  std::vector<float> hy(P), hy0(P), hg(P * 9), hg0(P * 9);
+  for (int mode = 1; mode >= 0; --mode) {
+    recmv_set_gemm_mode(mode);
+    for (int busy = 0; busy < 2; ++busy)
+      for (int v = 0; v < 5; ++v) {
+        hipLaunchKernelGGL(kerns[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y0, g0);
+        CK(hipStreamSynchronize(main_s));
+        CK(hipMemcpy(hy0.data(), y0, P * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hg0.data(), g0, P * 36, hipMemcpyDeviceToHost));
+        int bad = 0;
+        long first_lane = -1, nbad_elems = 0;
+        for (int it = 0; it < iters; ++it) {
+          if (busy)
+            for (int i = 0; i < 2; ++i)
+              for (int r = 0; r < 2; ++r)
+                if (recmv_gemm_nt(A, K, B, K, nullptr, C[i], N, M, N, K, RECMV_ACT_RELU, 0.f, 1.f, side[i]) != 0) {
+                  fprintf(stderr, "gemm_nt: %s\n", recmv_last_error());
+                  return 2;
+                }
+          hipLaunchKernelGGL(kerns[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y, g);
+          CK(hipMemcpyAsync(hy.data(), y, P * 4, hipMemcpyDeviceToHost, main_s));
+          CK(hipMemcpyAsync(hg.data(), g, P * 36, hipMemcpyDeviceToHost, main_s));
+          CK(hipStreamSynchronize(main_s));
+          bool diff = false;
+          for (long i = 0; i < P; ++i) {
+            bool d = memcmp(&hy[i], &hy0[i], 4) != 0 || memcmp(&hg[i * 9], &hg0[i * 9], 36) != 0;
+            if (d) {
+              diff = true;
+              ++nbad_elems;
+              if (first_lane < 0) first_lane = i % 64;
+            }
+          }
+          bad += diff;
+        }
+        CK(hipDeviceSynchronize());
+        printf("%-7s products %-5s  %-52s %3d of %d launches differ from the first (%ld matrices in all; lane of the first: %ld)\n",
+               mode ? "bf16x6" : "f32", busy ? "busy" : "idle", names[v], bad, iters, nbad_elems, first_lane);
+        fflush(stdout);
+      }
+  }
+  return 0;
+}

@@ -158,6 +158,67 @@ __global__ __launch_bounds__(kBlk) void regu_variant(const float* __restrict__ J
   for (int e = threadIdx.x; e < n * 9; e += kBlk) gJ[base * 9 + e] = tile[e];
 }
 
+
+// ---- aggressors: one instruction family each, on two side streams -------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// A0: v_cvt_pk_bf16_f32 only     A1: bf16 MFMA only     A2: both interleaved (the split-in-loop kernels)     A3: f32 MFMA only
+// A4: transcendentals (v_exp_f32) only     A5: software f32 -> bf16 rounding (integer ops) + bf16 MFMA
+template <int A>
+__global__ __launch_bounds__(256) void aggressor(float* __restrict__ out, int rounds) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  float x0 = 1.0f + 1e-3f * (tid & 1023), x1 = 0.5f + 1e-3f * (tid & 511);
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  unsigned h = 0x3f803f80u;
+  for (int i = 0; i < rounds; ++i) {
+    if (A == 0 || A == 2) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const f32x2_t v = {x0, x1};
+        h ^= __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+        x0 = x0 * 1.0001f + 0.25f;
+        x1 = x1 * 0.9999f + 0.125f;
+      }
+    }
+    if (A == 5) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        unsigned a = __float_as_uint(x0), b = __float_as_uint(x1);
+        a += 0x7fffu + ((a >> 16) & 1u);
+        b += 0x7fffu + ((b >> 16) & 1u);
+        h ^= (a >> 16) | (b & 0xffff0000u);
+        x0 = x0 * 1.0001f + 0.25f;
+        x1 = x1 * 0.9999f + 0.125f;
+      }
+    }
+    if (A == 1 || A == 2 || A == 5) {
+      const bf16x8_t f = __builtin_bit_cast(bf16x8_t, (u32x4_t){h, h ^ 0x00010001u, h, h ^ 0x00020002u});
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, f, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, f, acc, 0, 0, 0);
+    }
+    if (A == 3) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, x1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, x0, acc, 0, 0, 0);
+      x0 = x0 * 1.0001f + 0.25f;
+    }
+    if (A == 4) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x0 = __builtin_amdgcn_exp2f(x0 * 0.001f) + x1;
+    }
+  }
+  float sum = x0 + x1 + __uint_as_float(h & 0x3fffffffu);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sum += acc[r];
+  out[tid] = sum;
+}
+typedef void (*Agg)(float*, int);
+
 typedef void (*Kern)(const float*, long, float, float*, float*);
 
 int main(int argc, char** argv) {
@@ -234,6 +295,42 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         printf("%-7s products %-5s  %-52s %3d of %d launches differ from the first (%ld matrices in all; lane of the first: %ld)\n",
                mode ? "bf16x6" : "f32", busy ? "busy" : "idle", names[v], bad, iters, nbad_elems, first_lane);
+        fflush(stdout);
+      }
+  }
+  // ---- which instruction family of the side streams' work disturbs the victim?
+  {
+    Agg aggs[6] = {aggressor<0>, aggressor<1>, aggressor<2>, aggressor<3>, aggressor<4>, aggressor<5>};
+    const char* anames[6] = {"A0 v_cvt_pk_bf16_f32 only", "A1 bf16 MFMA only", "A2 v_cvt_pk_bf16_f32 + bf16 MFMA", "A3 f32 MFMA only",
+                             "A4 v_exp_f32 only", "A5 integer f32->bf16 rounding + bf16 MFMA"};
+    float* aout;
+    CK(hipMalloc(&aout, 2048 * 256 * 4));
+    const int victims[2] = {2, 0};
+    for (int vi = 0; vi < 2; ++vi)
+      for (int a = 0; a < 6; ++a) {
+        const int v = victims[vi];
+        hipLaunchKernelGGL(kerns[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y0, g0);
+        CK(hipStreamSynchronize(main_s));
+        CK(hipMemcpy(hy0.data(), y0, P * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hg0.data(), g0, P * 36, hipMemcpyDeviceToHost));
+        int bad = 0;
+        long nbad = 0;
+        for (int it = 0; it < iters; ++it) {
+          for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(aggs[a], dim3(1024), dim3(256), 0, side[i], aout + i * 1024 * 256, 400);
+          hipLaunchKernelGGL(kerns[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y, g);
+          CK(hipMemcpyAsync(hy.data(), y, P * 4, hipMemcpyDeviceToHost, main_s));
+          CK(hipMemcpyAsync(hg.data(), g, P * 36, hipMemcpyDeviceToHost, main_s));
+          CK(hipStreamSynchronize(main_s));
+          bool diff = false;
+          for (long i = 0; i < P; ++i)
+            if (memcmp(&hy[i], &hy0[i], 4) != 0 || memcmp(&hg[i * 9], &hg0[i * 9], 36) != 0) {
+              diff = true;
+              ++nbad;
+            }
+          bad += diff;
+        }
+        CK(hipDeviceSynchronize());
+        printf("victim %-32.32s beside %-44s %3d of %d launches differ (%ld matrices)\n", names[v], anames[a], bad, iters, nbad);
         fflush(stdout);
       }
   }

@@ -217,6 +217,67 @@ __global__ __launch_bounds__(256) void aggressor(float* __restrict__ out, int ro
   for (int r = 0; r < 16; ++r) sum += acc[r];
   out[tid] = sum;
 }
+// A6..A11: the same with LDS traffic, as the product kernels have it.  W = bytes per ds_read (16: ds_read_b128 as in the NT kernels, 4:
+// ds_read_b32 as in the TN kernel); CVT: split the values read into bf16 with v_cvt_pk_bf16_f32; MF: 0 none, 1 bf16 MFMA, 2 f32 MFMA;
+// BAR: a workgroup barrier + LDS rewrite per round (the K-tile loop's shape)
+template <int W, bool CVT, int MF, bool BAR>
+__global__ __launch_bounds__(256) void aggressor_lds(float* __restrict__ out, int rounds) {
+  __shared__ __attribute__((aligned(16))) float sm[8192];          // 32 KB
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 8192; e += 256) sm[e] = 1.0f + 1e-4f * e;
+  __syncthreads();
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float keep = 0.f;
+  unsigned h = 0x3f803f80u;
+  for (int i = 0; i < rounds; ++i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float4 a, b;
+      const int o = ((tid * 8 + u * 2048 + i * 64) & 8191) & ~7;
+      if (W == 16) {
+        a = *reinterpret_cast<const float4*>(sm + o);
+        b = *reinterpret_cast<const float4*>(sm + o + 4);
+      } else {
+        a = make_float4(sm[o], sm[(o + 36) & 8191], sm[(o + 72) & 8191], sm[(o + 108) & 8191]);
+        b = make_float4(sm[(o + 144) & 8191], sm[(o + 180) & 8191], sm[(o + 216) & 8191], sm[(o + 252) & 8191]);
+      }
+      u32x4_t f;
+      if (CVT) {
+        f[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a.x, a.y}, bf16x2_t));
+        f[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a.z, a.w}, bf16x2_t));
+        f[2] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){b.x, b.y}, bf16x2_t));
+        f[3] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){b.z, b.w}, bf16x2_t));
+      } else {
+        f[0] = __float_as_uint(a.x) ^ h;
+        f[1] = __float_as_uint(a.z);
+        f[2] = __float_as_uint(b.x);
+        f[3] = __float_as_uint(b.z);
+        keep += a.y + a.w + b.y + b.w;
+      }
+      if (MF == 1) {
+        const bf16x8_t fr = __builtin_bit_cast(bf16x8_t, f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr, fr, acc, 0, 0, 0);
+      } else if (MF == 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        h ^= f[1];
+      } else {
+        h ^= f[0] ^ f[1] ^ f[2] ^ f[3];
+      }
+    }
+    if (BAR) {
+      __syncthreads();
+      sm[(tid * 4 + i) & 8191] = keep + 1.0f;
+      __syncthreads();
+    }
+  }
+  float sum = keep + __uint_as_float(h & 0x3fffffffu);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sum += acc[r];
+  out[blockIdx.x * 256 + tid] = sum;
+}
 typedef void (*Agg)(float*, int);
 
 typedef void (*Kern)(const float*, long, float, float*, float*);
@@ -300,14 +361,21 @@ int main(int argc, char** argv) {
   }
   // ---- which instruction family of the side streams' work disturbs the victim?
   {
-    Agg aggs[6] = {aggressor<0>, aggressor<1>, aggressor<2>, aggressor<3>, aggressor<4>, aggressor<5>};
-    const char* anames[6] = {"A0 v_cvt_pk_bf16_f32 only", "A1 bf16 MFMA only", "A2 v_cvt_pk_bf16_f32 + bf16 MFMA", "A3 f32 MFMA only",
-                             "A4 v_exp_f32 only", "A5 integer f32->bf16 rounding + bf16 MFMA"};
+    constexpr int NA = 14;
+    Agg aggs[NA] = {aggressor<0>, aggressor<1>, aggressor<2>, aggressor<3>, aggressor<4>, aggressor<5>,
+                    aggressor_lds<16, false, 0, false>, aggressor_lds<16, false, 1, false>, aggressor_lds<16, true, 1, false>,
+                    aggressor_lds<16, true, 1, true>, aggressor_lds<4, true, 1, true>, aggressor_lds<16, false, 2, true>,
+                    aggressor_lds<16, true, 0, true>, aggressor_lds<16, false, 1, true>};
+    const char* anames[NA] = {"A0 v_cvt_pk_bf16_f32 only", "A1 bf16 MFMA only", "A2 v_cvt_pk_bf16_f32 + bf16 MFMA", "A3 f32 MFMA only",
+                              "A4 v_exp_f32 only", "A5 integer f32->bf16 rounding + bf16 MFMA", "A6 ds_read_b128 only",
+                              "A7 ds_read_b128 + bf16 MFMA", "A8 ds_read_b128 + cvt_pk + bf16 MFMA", "A9 A8 + barrier + LDS store per round",
+                              "A10 ds_read_b32 + cvt_pk + bf16 MFMA + barrier", "A11 ds_read_b128 + f32 MFMA + barrier",
+                              "A12 ds_read_b128 + cvt_pk + barrier, no MFMA", "A13 ds_read_b128 + bf16 MFMA + barrier, no cvt"};
     float* aout;
     CK(hipMalloc(&aout, 2048 * 256 * 4));
-    const int victims[2] = {2, 0};
-    for (int vi = 0; vi < 2; ++vi)
-      for (int a = 0; a < 6; ++a) {
+    const int victims[1] = {2};
+    for (int vi = 0; vi < 1; ++vi)
+      for (int a = 0; a < NA; ++a) {
         const int v = victims[vi];
         hipLaunchKernelGGL(kerns[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y0, g0);
         CK(hipStreamSynchronize(main_s));

@@ -384,7 +384,10 @@ int main(int argc, char** argv) {
         int bad = 0;
         long nbad = 0;
         for (int it = 0; it < iters; ++it) {
-          for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(aggs[a], dim3(1024), dim3(256), 0, side[i], aout + i * 1024 * 256, 400);
+          // 32 KB static (LDS variants) or 36 KB dynamic LDS per workgroup: at most four aggressor workgroups (four waves per SIMD) on a CU,
+          // so the victim's waves run BESIDE them, as they do beside the 64 x 64 product kernel (36 KB)
+          for (int i = 0; i < 2; ++i)
+            hipLaunchKernelGGL(aggs[a], dim3(1024), dim3(256), a < 6 ? 36864 : 4096, side[i], aout + i * 1024 * 256, 400);
           hipLaunchKernelGGL(kerns[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y, g);
           CK(hipMemcpyAsync(hy.data(), y, P * 4, hipMemcpyDeviceToHost, main_s));
           CK(hipMemcpyAsync(hg.data(), g, P * 36, hipMemcpyDeviceToHost, main_s));

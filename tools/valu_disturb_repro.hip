@@ -359,6 +359,37 @@ int main(int argc, char** argv) {
         fflush(stdout);
       }
   }
+  // ---- the same instruction stream on different DATA: does what the product kernel multiplies matter?
+  {
+    recmv_set_gemm_mode(1);
+    const char* dnames[4] = {"random operands (as above)", "all-zero operands", "all-ones operands", "A random, B zero"};
+    std::vector<float> z(M * K, 0.f), o(M * K, 1.f);
+    for (int d = 0; d < 4; ++d) {
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(A, d == 0 || d == 3 ? hA.data() : (d == 1 ? z.data() : o.data()), M * K * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(B, d == 0 ? hB.data() : (d == 2 ? o.data() : z.data()), N * K * 4, hipMemcpyHostToDevice));
+      const int v = 2;
+      hipLaunchKernelGGL(kerns[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y0, g0);
+      CK(hipStreamSynchronize(main_s));
+      CK(hipMemcpy(hy0.data(), y0, P * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hg0.data(), g0, P * 36, hipMemcpyDeviceToHost));
+      int bad = 0;
+      for (int it = 0; it < iters; ++it) {
+        for (int i = 0; i < 2; ++i)
+          for (int r = 0; r < 2; ++r) recmv_gemm_nt(A, K, B, K, nullptr, C[i], N, M, N, K, RECMV_ACT_RELU, 0.f, 1.f, side[i]);
+        hipLaunchKernelGGL(kerns[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y, g);
+        CK(hipMemcpyAsync(hy.data(), y, P * 4, hipMemcpyDeviceToHost, main_s));
+        CK(hipMemcpyAsync(hg.data(), g, P * 36, hipMemcpyDeviceToHost, main_s));
+        CK(hipStreamSynchronize(main_s));
+        bad += memcmp(hy.data(), hy0.data(), P * 4) != 0 || memcmp(hg.data(), hg0.data(), P * 36) != 0;
+      }
+      printf("victim V2 beside the bf16x6 64 x 64 product kernel on %-28s %3d of %d launches differ\n", dnames[d], bad, iters);
+      fflush(stdout);
+    }
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(A, hA.data(), M * K * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, hB.data(), N * K * 4, hipMemcpyHostToDevice));
+  }
   // ---- which instruction family of the side streams' work disturbs the victim?
   {
     constexpr int NA = 14;

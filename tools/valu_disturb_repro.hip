@@ -278,6 +278,85 @@ __global__ __launch_bounds__(256) void aggressor_lds(float* __restrict__ out, in
   for (int r = 0; r < 16; ++r) sum += acc[r];
   out[blockIdx.x * 256 + tid] = sum;
 }
+// A14..: the inner loop of gemm_nt_kernel<1, FAST, false, BF3> as it is (LDS tile of f32 rows, two ds_read_b128 per operand row and
+// 16-column step, the three-way bf16 split of csrc/gemm_f32.hip split8, six dependent bf16 MFMAs per 32 x 32 tile), without the
+// global traffic.  SPLIT: 0 = v_cvt_pk_bf16_f32 (the product's), 1 = integer round-to-nearest-even;  MF: 0 = pieces only, no MFMA.
+struct Pcs {
+  bf16x8_t h, m, l;
+};
+template <int SPLIT>
+__device__ __forceinline__ void split2_(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  auto cvt = [](float a, float b) -> unsigned {
+    if (SPLIT == 0) return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua += 0x7fffu + ((ua >> 16) & 1u);
+    ub += 0x7fffu + ((ub >> 16) & 1u);
+    return (ua >> 16) | (ub & 0xffff0000u);
+  };
+  h = cvt(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt(r0, r1);
+  const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = cvt(q0, q1);
+}
+template <int SPLIT>
+__device__ __forceinline__ Pcs split8_(float4 a, float4 b) {
+  unsigned h[4], m[4], l[4];
+  split2_<SPLIT>(a.x, a.y, h[0], m[0], l[0]);
+  split2_<SPLIT>(a.z, a.w, h[1], m[1], l[1]);
+  split2_<SPLIT>(b.x, b.y, h[2], m[2], l[2]);
+  split2_<SPLIT>(b.z, b.w, h[3], m[3], l[3]);
+  Pcs p;
+  p.h = __builtin_bit_cast(bf16x8_t, (u32x4_t){h[0], h[1], h[2], h[3]});
+  p.m = __builtin_bit_cast(bf16x8_t, (u32x4_t){m[0], m[1], m[2], m[3]});
+  p.l = __builtin_bit_cast(bf16x8_t, (u32x4_t){l[0], l[1], l[2], l[3]});
+  return p;
+}
+template <int SPLIT, int MF>
+__global__ __launch_bounds__(256) void aggressor_loop(float* __restrict__ out, int rounds) {
+  constexpr int LDK = 36;
+  __shared__ __attribute__((aligned(16))) float As[2 * 64 * LDK], Bs[2 * 64 * LDK];       // 36 KB, as the kernel's
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < 2 * 64 * LDK; e += 256) {
+    As[e] = 1.0f + 1e-4f * e;
+    Bs[e] = 0.5f - 1e-4f * e;
+  }
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31), khalf = (lane >> 5) * 4;
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  unsigned sink = 0;
+  for (int kt = 0; kt < rounds; ++kt) {
+    const int buf = kt & 1;
+    const float* as = As + (buf * 64 + arow) * LDK + 2 * khalf;
+    const float* bs = Bs + (buf * 64 + brow) * LDK + 2 * khalf;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const Pcs pa = split8_<SPLIT>(*reinterpret_cast<const float4*>(as + ks * 16), *reinterpret_cast<const float4*>(as + ks * 16 + 4));
+      const Pcs pb = split8_<SPLIT>(*reinterpret_cast<const float4*>(bs + ks * 16), *reinterpret_cast<const float4*>(bs + ks * 16 + 4));
+      if (MF) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.h, pb.l, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.l, pb.h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.m, pb.m, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.h, pb.m, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.m, pb.h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa.h, pb.h, acc, 0, 0, 0);
+      } else {
+        const u32x4_t a = __builtin_bit_cast(u32x4_t, pa.l), b = __builtin_bit_cast(u32x4_t, pb.l);
+        sink ^= a[0] ^ a[1] ^ a[2] ^ a[3] ^ b[0] ^ b[1] ^ b[2] ^ b[3];
+      }
+    }
+    __syncthreads();
+    As[(tid * 4 + kt) % (2 * 64 * LDK)] += 1e-6f;
+    __syncthreads();
+  }
+  float sum = __uint_as_float(sink & 0x3fffffffu);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sum += acc[r];
+  out[blockIdx.x * 256 + tid] = sum;
+}
 typedef void (*Agg)(float*, int);
 
 typedef void (*Kern)(const float*, long, float, float*, float*);
@@ -392,21 +471,24 @@ int main(int argc, char** argv) {
   }
   // ---- which instruction family of the side streams' work disturbs the victim?
   {
-    constexpr int NA = 14;
+    constexpr int NA = 18;
     Agg aggs[NA] = {aggressor<0>, aggressor<1>, aggressor<2>, aggressor<3>, aggressor<4>, aggressor<5>,
                     aggressor_lds<16, false, 0, false>, aggressor_lds<16, false, 1, false>, aggressor_lds<16, true, 1, false>,
                     aggressor_lds<16, true, 1, true>, aggressor_lds<4, true, 1, true>, aggressor_lds<16, false, 2, true>,
-                    aggressor_lds<16, true, 0, true>, aggressor_lds<16, false, 1, true>};
+                    aggressor_lds<16, true, 0, true>, aggressor_lds<16, false, 1, true>,
+                    aggressor_loop<0, 1>, aggressor_loop<1, 1>, aggressor_loop<0, 0>, aggressor_loop<1, 0>};
     const char* anames[NA] = {"A0 v_cvt_pk_bf16_f32 only", "A1 bf16 MFMA only", "A2 v_cvt_pk_bf16_f32 + bf16 MFMA", "A3 f32 MFMA only",
                               "A4 v_exp_f32 only", "A5 integer f32->bf16 rounding + bf16 MFMA", "A6 ds_read_b128 only",
                               "A7 ds_read_b128 + bf16 MFMA", "A8 ds_read_b128 + cvt_pk + bf16 MFMA", "A9 A8 + barrier + LDS store per round",
                               "A10 ds_read_b32 + cvt_pk + bf16 MFMA + barrier", "A11 ds_read_b128 + f32 MFMA + barrier",
-                              "A12 ds_read_b128 + cvt_pk + barrier, no MFMA", "A13 ds_read_b128 + bf16 MFMA + barrier, no cvt"};
+                              "A12 ds_read_b128 + cvt_pk + barrier, no MFMA", "A13 ds_read_b128 + bf16 MFMA + barrier, no cvt",
+                              "A14 the product kernel's K loop (cvt_pk split)", "A15 the K loop, integer-rounded split",
+                              "A16 the K loop's split (cvt_pk), no MFMA", "A17 integer-rounded split, no MFMA"};
     float* aout;
     CK(hipMalloc(&aout, 2048 * 256 * 4));
     const int victims[1] = {2};
     for (int vi = 0; vi < 1; ++vi)
-      for (int a = 0; a < NA; ++a) {
+      for (int a = 6; a < NA; ++a) {
         const int v = victims[vi];
         hipLaunchKernelGGL(kerns[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y0, g0);
         CK(hipStreamSynchronize(main_s));
@@ -418,7 +500,7 @@ int main(int argc, char** argv) {
           // 32 KB static (LDS variants) or 36 KB dynamic LDS per workgroup: at most four aggressor workgroups (four waves per SIMD) on a CU,
           // so the victim's waves run BESIDE them, as they do beside the 64 x 64 product kernel (36 KB)
           for (int i = 0; i < 2; ++i)
-            hipLaunchKernelGGL(aggs[a], dim3(1024), dim3(256), a < 6 ? 36864 : 4096, side[i], aout + i * 1024 * 256, 400);
+            hipLaunchKernelGGL(aggs[a], dim3(1024), dim3(256), a < 6 ? 36864 : (a < 14 ? 4096 : 0), side[i], aout + i * 1024 * 256, 400);
           hipLaunchKernelGGL(kerns[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y, g);
           CK(hipMemcpyAsync(hy.data(), y, P * 4, hipMemcpyDeviceToHost, main_s));
           CK(hipMemcpyAsync(hg.data(), g, P * 36, hipMemcpyDeviceToHost, main_s));

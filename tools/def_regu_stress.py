@@ -62,6 +62,22 @@ def run(label, mode, fam, work):
     print("def_regu beside %-64s %d of %d launches differ from the first" % (label + ":", bad, reps), flush=True)
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "shapes":
+    # which part of the 64 x 64 product kernel matters: the K loop's length, the epilogue's activation, the loader
+    B32, A32 = (torch.randn(512, 32, generator=g) / 6.0).to(dev), torch.randn(12000, 32, generator=g).to(dev)
+    A4k, B4k = torch.randn(12000, 4096, generator=g).to(dev), (torch.randn(512, 4096, generator=g) / 64.0).to(dev)
+    A510, B510 = torch.randn(12000, 510, generator=g).to(dev), (torch.randn(512, 510, generator=g) / 22.0).to(dev)
+    nar_A = torch.randn(3000, 512, generator=g).to(dev)
+    for mode in (1, 0):
+        tag = "bf16x6" if mode else "f32"
+        run(tag + " 64x64 K=512 no activation", mode, 7, lambda: ops.gemm_nt(mid_A, big_B, None, ops.ACT_NONE, 0.0))
+        run(tag + " 64x64 K=512 softplus(100)", mode, 7, lambda: ops.gemm_nt(mid_A, big_B, None, ops.ACT_SOFTPLUS, 100.0))
+        run(tag + " 64x64 K=32 (one K-tile) relu", mode, 7, lambda: ops.gemm_nt(A32, B32, None, ops.ACT_RELU, 0.0))
+        run(tag + " 64x64 K=4096 relu", mode, 7, lambda: ops.gemm_nt(A4k, B4k, None, ops.ACT_RELU, 0.0))
+        run(tag + " 64x64 K=510 (element-guarded loader) relu", mode, 7, lambda: ops.gemm_nt(A510, B510, None, ops.ACT_RELU, 0.0))
+        run(tag + " 64x32 narrow tiles, 3000 rows, relu", mode, 7, lambda: ops.gemm_nt(nar_A, big_B, None, ops.ACT_RELU, 0.0))
+    lib.recmv_set_gemm_mode(0)
+    sys.exit(0)
 run("idle side streams", 1, 7, None)
 run("bf16x6 128x128 products (gemm_nt_b3_kernel, 66 KB LDS)", 1, 7, lambda: ops.gemm_nt(big_A, big_B, None, ops.ACT_RELU, 0.0))
 run("bf16x6 64x64 products (gemm_nt_kernel<1,..,BF3>, 36 KB LDS)", 1, 7, lambda: ops.gemm_nt(mid_A, big_B, None, ops.ACT_RELU, 0.0))

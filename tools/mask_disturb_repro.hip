@@ -29,9 +29,12 @@
     }                                                                                      \
   } while (0)
 
-__device__ __forceinline__ float next_x(unsigned& s) {       // in [0, 1), never exactly 0.5
+__host__ __device__ inline float next_x(unsigned& s) {       // in [0, 1), never exactly 0.5
   s = s * 1664525u + 1013904223u;
-  return __uint_as_float(0x3f800000u | (s >> 9) | 1u) - 1.0f;
+  const unsigned u = 0x3f800000u | (s >> 9) | 1u;
+  float f;
+  memcpy(&f, &u, 4);
+  return f - 1.0f;
 }
 
 template <int W>

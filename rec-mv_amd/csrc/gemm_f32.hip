@@ -44,13 +44,25 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct Pieces {
   bf16x8 h, m, l;
 };
+// Two f32 -> one packed pair of bf16, round to nearest even.  Default: the hardware conversion (v_cvt_pk_bf16_f32, new in gfx950).
+// -DRECMV_SPLIT_INT: the same rounding in integer arithmetic (finite operands; the A/B build of tools/def_regu_stress.py).
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+#ifdef RECMV_SPLIT_INT
+  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua += 0x7fffu + ((ua >> 16) & 1u);
+  ub += 0x7fffu + ((ub >> 16) & 1u);
+  return (ua >> 16) | (ub & 0xffff0000u);
+#else
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+#endif
+}
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  const f32x2 v = {x0, x1};
-  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  h = pack_bf16(x0, x1);
   const f32x2 r = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u)};
-  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  m = pack_bf16(r.x, r.y);
   const f32x2 q = {r.x - __uint_as_float(m << 16), r.y - __uint_as_float(m & 0xffff0000u)};
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
+  l = pack_bf16(q.x, q.y);
 }
 __device__ __forceinline__ Pieces split8(float4 a, float4 b) {
   unsigned h[4], m[4], l[4];

@@ -13,7 +13,7 @@ from pathlib import Path
 import torch
 
 _PKG = Path(__file__).resolve().parent.parent          # rec-mv_amd/
-LIB_PATH = _PKG / "lib" / "librecmv_hip.so"
+LIB_PATH = Path(os.environ["RECMV_LIB_PATH"]) if os.environ.get("RECMV_LIB_PATH") else _PKG / "lib" / "librecmv_hip.so"   # (override: A/B builds of tools/)
 
 RECMV_OK = 0
 ABI_VERSION = 7          # include/recmv_hip.h; bumped when a signature changes (v7: recmv_get_sampler_mode, recmv_set_jet_fill added; v5: second weight set + split_row in recmv_mlp; v6: recmv_def_regu, recmv_b3_*, recmv_mlp_rows_*, recmv_mc_run_batch added)

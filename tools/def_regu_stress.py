@@ -31,6 +31,7 @@ print("# RECMV_GEMM_OCC=%s" % os.environ.get("RECMV_GEMM_OCC", "(unset)"))
 def run(label, mode, fam, work):
     lib.recmv_set_gemm_mode(mode)
     lib.recmv_set_b3_families(fam)
+    torch.cuda.synchronize()               # (the reference launch runs alone)
     y0, g0 = torch.empty(P, device=dev), torch.empty_like(J)
     L.check(lib.recmv_def_regu(L.ptr(J), P, 0.03, L.ptr(y0), L.ptr(g0), L.stream_ptr(dev)), "def_regu")
     torch.cuda.synchronize()
@@ -62,6 +63,20 @@ def run(label, mode, fam, work):
     print("def_regu beside %-64s %d of %d launches differ from the first" % (label + ":", bad, reps), flush=True)
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "ab":
+    # the A/B of the f32 -> bf16 conversion inside the product kernels: run once with the product library and once with
+    # RECMV_LIB_PATH=tools/bin/librecmv_hip_intsplit.so (the same sources built with -DRECMV_SPLIT_INT)
+    A4k, B4k = torch.randn(12000, 4096, generator=g).to(dev), (torch.randn(512, 4096, generator=g) / 64.0).to(dev)
+    print("# library: %s" % L.LIB_PATH)
+    torch.cuda.synchronize()
+    run("bf16x6 64x64 products, K = 4096", 1, 7, lambda: ops.gemm_nt(A4k, B4k, None, ops.ACT_RELU, 0.0))
+    torch.cuda.synchronize()
+    run("bf16x6 64x64 products, K = 512", 1, 7, lambda: ops.gemm_nt(mid_A, big_B, None, ops.ACT_RELU, 0.0))
+    torch.cuda.synchronize()
+    run("bf16x6 128x128 products (gemm_nt_b3_kernel)", 1, 7, lambda: ops.gemm_nt(big_A, big_B, None, ops.ACT_RELU, 0.0))
+    torch.cuda.synchronize()
+    lib.recmv_set_gemm_mode(0)
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "shapes":
     # which part of the 64 x 64 product kernel matters: the K loop's length, the epilogue's activation, the loader
     B32, A32 = (torch.randn(512, 32, generator=g) / 6.0).to(dev), torch.randn(12000, 32, generator=g).to(dev)

@@ -1108,13 +1108,11 @@ class HotLoop:
         # paced by host read-backs then); with those gone and one jet pass per net it is worth 3-4 % of the iteration
         # (tools/ab_interleaved.py render_streams, profiles/r04_ab_render_streams.txt).  RECMV_RENDER_STREAMS=0: one stream (A/B).
         side = None
-        rs = os.environ.get('RECMV_RENDER_STREAMS')
-        if rs is None and torch.device(dev).type == 'cuda':
-            # bf16x6 matrix mode: with the two chains beside each other about one run in four parts from the others in the last bits
-            # (the first garment's pass through the offset MLP's jet; cause open), without the side stream 12 runs of 12
-            # are identical at -2 % in that mode — so the side stream is the default in the f32 mode only (8 of 8 identical there)
-            from . import _lib as L
-            rs = '1' if L.lib().recmv_get_gemm_mode() == 0 else '0'
+        # (Round 4 took the side stream out of the bf16x6 mode's default on the strength of 12-run samples; round 5's in-process counts
+        # — tools/loop_repro_inproc.py, 40-100 repetitions per cell — show that mode parting with AND without it, and why: a kernel of
+        # the iteration computes wrong values beside that mode's product kernels, whatever the schedule, DESIGN.md §9.  The f32 mode is
+        # identical in every repetition of every cell, so the side stream is simply the default.)
+        rs = os.environ.get('RECMV_RENDER_STREAMS', '1')
         if (torch.device(dev).type == 'cuda' and self.garment_size > 1 and os.environ.get('RECMV_SERIAL') != '1'
                 and rs != '0'):
             from .utils.FindSurfacePs import _streams

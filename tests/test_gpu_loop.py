@@ -134,3 +134,108 @@ def test_iterations_on_a_capture_directory_read_by_recmv_dataset(tmp_path):
     assert not torch.equal(ds.conds[0].detach(), before[1])
     assert not torch.equal(ds.camera_params['focal_length'].detach(), before[2])
     assert torch.isfinite(optNet.info['fl_loss']['total']) and optNet.info['rays_total'] > 0
+
+
+def _snapshot(loop):
+    import copy
+    tensors = list(loop.shared_parameters()) + list(loop.garment_vs) + (
+        list(loop.inter_free_curve.parameters()) if getattr(loop, 'curves', False) else [])
+    opts = [loop.optimizer, loop.garment_optimizer] + ([loop.fl_optimizer] if getattr(loop, 'curves', False) else [])
+    state = dict(tensors=[(p, p.detach().clone()) for p in tensors], opts=[(o, copy.deepcopy(o.state_dict())) for o in opts],
+                 counters=(loop.forward_time, loop.opt_times), rng=(torch.get_rng_state(), torch.cuda.get_rng_state(loop.device)))
+
+    def restore():
+        with torch.no_grad():
+            for p, saved in state['tensors']:
+                p.copy_(saved)
+                p.grad = None
+        for o, sd in state['opts']:
+            o.load_state_dict(copy.deepcopy(sd))
+        loop.forward_time, loop.opt_times = state['counters']
+        torch.set_rng_state(state['rng'][0])
+        torch.cuda.set_rng_state(state['rng'][1], loop.device)
+        torch.cuda.synchronize()
+    return restore
+
+
+def _iteration_result(loop, it):
+    loss, rays = loop.step(it)
+    torch.cuda.synchronize()
+    out = [loss.detach().clone()] + [p.detach().clone() for p in loop.shared_parameters()] + [v.detach().clone() for v in loop.garment_vs]
+    out += [t.grad.clone() for t in loop.TmpPs if t is not None and t.grad is not None]
+    return rays, out
+
+
+def test_iteration_is_bit_reproducible():
+    """The four-stream iteration (main, ray pipeline, curve branch, second garment) repeated from one snapshot of the whole state gives
+    the same bits every time — the property the frame-sharded replicas rely on (tools/loop_repro_inproc.py counts
+    40-100 repetitions per configuration on the bench scene).  Default (f32) matrix mode."""
+    from recmv import _lib as L
+    from recmv.hocon import ConfigFactory
+    from recmv.loop import HotLoop
+    assert L.lib().recmv_get_gemm_mode() == 0
+    conf = ConfigFactory.parse_file(CONF)
+    conf.put('train.sample_pix_num', 256)
+    loop = HotLoop(conf, torch.device("cuda:0"), n_frames=12, H=160, W=128,
+                   resolutions=[(9, 13, 7), (17, 25, 13), (33, 49, 25), (65, 97, 49)], skin_grid=(17, 33, 17), curves=True)
+    loop.step(0)
+    loop.step(1)
+    torch.cuda.synchronize()
+    restore = _snapshot(loop)
+    ref = None
+    for rep in range(12):
+        restore()
+        rays, out = _iteration_result(loop, 2)
+        if ref is None:
+            ref = (rays, out)
+            assert rays > 300 and sum(loop.info['rays_converged']) > 0
+            continue
+        assert rays == ref[0]
+        for i, (a, b) in enumerate(zip(ref[1], out)):
+            assert torch.equal(a, b), "repetition %d parts from the first in result tensor %d" % (rep, i)
+
+
+@pytest.mark.parametrize("switch", ["RECMV_PROP_JOINT", "RECMV_MERGE_JETS", "RECMV_RENDER_STREAMS", "RECMV_SERIAL"])
+def test_schedule_switches_leave_the_iteration_unchanged(switch, monkeypatch):
+    """The default forms of round 4 — both garments' implicit differentiation as one block of rows, one jet pass per net over the
+    eikonal points and the converged rays, the second garment's render chain on a side stream, the three-stream order — against the forms
+    they replaced (the switch set to its other value), one iteration from the same snapshot: same rays, parameters after the step within
+    f32 rounding of the gradients' different summation order (joint / merged passes sum the two row blocks in one product), bit-identical
+    for the pure schedule switches."""
+    conf_mod = __import__('recmv.hocon', fromlist=['ConfigFactory'])
+    from recmv.loop import HotLoop
+    conf = conf_mod.ConfigFactory.parse_file(CONF)
+    conf.put('train.sample_pix_num', 256)
+    loop = HotLoop(conf, torch.device("cuda:0"), n_frames=12, H=160, W=128,
+                   resolutions=[(9, 13, 7), (17, 25, 13), (33, 49, 25), (65, 97, 49)], skin_grid=(17, 33, 17), curves=True)
+    loop.step(0)
+    loop.step(1)
+    torch.cuda.synchronize()
+    restore = _snapshot(loop)
+    restore()
+    rays_a, out_a = _iteration_result(loop, 2)
+    grads_a = [p.grad.clone() if p.grad is not None else None for p in loop.shared_parameters()]
+    monkeypatch.setenv(switch, "1" if switch == "RECMV_SERIAL" else "0")
+    restore()
+    rays_b, out_b = _iteration_result(loop, 2)
+    grads_b = [p.grad.clone() if p.grad is not None else None for p in loop.shared_parameters()]
+    assert rays_a == rays_b
+    exact = switch in ("RECMV_RENDER_STREAMS", "RECMV_SERIAL")
+    worst = 0.0
+    for ga, gb in zip(grads_a, grads_b):
+        assert (ga is None) == (gb is None)
+        if ga is None:
+            continue
+        if exact:
+            assert torch.equal(ga, gb)
+        else:
+            scale = float(ga.abs().max()) + 1e-30
+            worst = max(worst, float((ga - gb).abs().max()) / scale)
+    if not exact:
+        # same terms, the two garments' (or the two row blocks') partial sums formed in one product instead of two and an add
+        assert worst < 2e-4, worst
+    for a, b in zip(out_a[1:], out_b[1:]):
+        if exact:
+            assert torch.equal(a, b)
+        else:
+            assert torch.allclose(a, b, rtol=0, atol=2e-5 * (float(a.abs().max()) + 1e-6) + 1e-7)

@@ -85,11 +85,14 @@ class KernelEvents:
         from recmv import _lib as L
         buf = (C.c_double * (5 * len(NT_VARIANTS)))()
         L.check(L.lib().recmv_profile_end(C.cast(buf, C.c_void_p), len(NT_VARIANTS)), "profile_end")
+        by = (C.c_double * len(NT_VARIANTS))()
+        L.check(L.lib().recmv_profile_bytes(C.cast(by, C.c_void_p), len(NT_VARIANTS)), "profile_bytes")
         out, small = {}, {}
         for v, name in enumerate(NT_VARIANTS):
             n, sec, fl, un, ufl = buf[5 * v:5 * v + 5]
             if n > 0:
-                out[name] = dict(launches=int(n), seconds=sec, flops=fl, avg_us=sec / n * 1e6, avg_flops=fl / n)
+                out[name] = dict(launches=int(n), seconds=sec, flops=fl, avg_us=sec / n * 1e6, avg_flops=fl / n,
+                                 avg_alg_bytes=by[v] / n)
             if un > 0:
                 small[name] = dict(launches=int(un), gflop=round(ufl / 1e9, 1))
         self.small = small
@@ -351,6 +354,25 @@ def hbm_kernel_block(loop, device):
         out[-1]["us"] = round(out[-1]["us"] / 3, 2)          # (the launch set serves three volumes)
         out[-1]["achieved_gbs"] = round(out[-1]["achieved_gbs"] * 3, 1)
         out[-1]["frac"] = round(out[-1]["frac"] * 3, 4)
+    # The kernels the ITERATION runs on the sampler path (csrc/lbs_fused.hip: skinning weights sampled, blended and applied in one
+    # kernel; the sampled weights never leave it): the ray pipeline's passes over ~3 k rays and the mask loss's pass over the three
+    # frames' vertices.  Algorithmic bytes = what crosses the kernel's boundary per point: canonical point 12 + frame index 8 +
+    # deformed point 12 (forward); + cotangent 12 (input VJP: point 12 + frame 8 + g_d 12 + g_p 12).  The 8 x 96 B of corner records
+    # a point gathers are L1 / L2 traffic, as in the sampler's lines above.
+    from recmv import chains
+    poses = (0.15 * torch.randn(3, 24, 3, device=device))
+    trans = 0.01 * torch.randn(3, 3, device=device)
+    with torch.no_grad():
+        A_pose, t_pose = sk._posed(poses, trans)
+    grid = sk._lbs_grid()
+    for P_, tag in ((3072, "the root finder's rays of one garment"), (3 * verts.shape[0], "one garment's vertices in 3 frames")):
+        pts = verts[torch.arange(P_, device=device) % verts.shape[0]].contiguous()
+        frame = (torch.arange(P_, device=device) * 3 // P_).contiguous()
+        g_d = torch.randn(P_, 3, device=device)
+        add(f"lbs_forward_kernel (fused sample + blend + apply), P={P_} ({tag})", P_ * 32,
+            lambda pts=pts, frame=frame: chains.lbs_forward(pts, frame, A_pose, t_pose, grid))
+        add(f"lbs_vjp_kernel (input VJP of the same), P={P_}", P_ * 44,
+            lambda pts=pts, frame=frame, g_d=g_d: chains.lbs_vjp_input(pts, frame, A_pose, grid, g_d))
     x = torch.randn(1, 1, 129, 129, 129, device=device)
     add("interp2x_boundary3d forward 129^3 -> 257^3", 4 * 129 ** 3 + 5 * 257 ** 3, lambda: interp2x_boundary3d.forward(x, 0.0))
     ms = torch.randn(1 << 20, 3, 3, device=device)
@@ -820,6 +842,11 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                                 "traffic_detail": tr,
                                 "launches": g["launches"], "avg_launch_us": round(g["avg_us"], 2),
                                 "avg_launch_gflop": round(g["avg_flops"] / 1e9, 3),
+                                # the same bracketed launches from the memory side: operands read once + result written once
+                                "alg_bytes": int(g.get("avg_alg_bytes", 0)),
+                                "alg_gbs": round(g.get("avg_alg_bytes", 0) / max(g["avg_us"], 1e-9) / 1e3, 1),
+                                "traffic_large_launches": (tr or {}).get("large_launches"),
+                                "frac_in_loop": round(ach / MFMA_F32_PEAK, 4),
                                 "share_of_step": round(g["seconds"] / elapsed, 3),
                                 "other_variants": {k: {"launches": v["launches"], "avg_launch_us": round(v["avg_us"], 2),
                                                        "achieved": round(v["flops"] / v["seconds"] / 1e12, 3)}
@@ -831,6 +858,10 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                 log("whole-step matrix rate not computed: %r" % (e,))
             if gs_serial and dom in gs_serial:
                 a = gs_serial[dom]
+                line["roofline"]["frac_kernel_only"] = round(a["flops"] / a["seconds"] / MFMA_F32_PEAK, 4)
+                line["roofline"]["frac_note"] = ("`frac` / `frac_in_loop`: HIP events around every launch of the kernel in the timed region, "
+                                                 "where two to three other streams share the CUs with it (the events measure the sharing too); "
+                                                 "`frac_kernel_only`: the same kernel, same shapes, with the iteration on one stream")
                 line["roofline"]["serial_order"] = {
                     "achieved": round(a["flops"] / a["seconds"] / 1e12, 3),
                     "frac": round(a["flops"] / a["seconds"] / MFMA_F32_PEAK, 4), "launches": a["launches"],

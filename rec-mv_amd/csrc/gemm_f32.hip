@@ -1400,7 +1400,7 @@ __global__ __launch_bounds__(kBlk) void posenc_kernel(const float* __restrict__ 
 struct LaunchRec {
   hipEvent_t a, b;
   int variant;
-  double flops;
+  double flops, bytes;
 };
 struct Profiler {
   bool on = false;
@@ -1408,6 +1408,7 @@ struct Profiler {
   double untimed[14][2] = {};      // [variant][launches, flops]
   std::vector<LaunchRec> recs;
   std::vector<hipEvent_t> pool;
+  double timed_bytes[14] = {};     // of the last recmv_profile_end: algorithmic bytes (4 (MK + NK + MN)) of the bracketed launches, per variant
   double busy_union_s = 0.0, busy_span_s = 0.0;   // of the last recmv_profile_end: union of the bracketed intervals, first start -> last end
   std::mutex mu;        // autograd's backward thread launches too
   hipEvent_t get() {
@@ -1428,8 +1429,10 @@ struct ScopedLaunchTimer {
   LaunchRec r;
   hipStream_t s;
   bool active;
-  ScopedLaunchTimer(int variant, double flops, hipStream_t stream) : s(stream), active(g_prof.on) {
+  ScopedLaunchTimer(int variant, double M, double N, double K, hipStream_t stream) : s(stream), active(g_prof.on) {
     if (!active) return;
+    const double flops = 2.0 * M * N * K;
+    r.bytes = 4.0 * (M * K + N * K + M * N);
     if (flops < g_prof.min_flops) {
       std::lock_guard<std::mutex> lk(g_prof.mu);
       g_prof.untimed[variant][0] += 1.0;
@@ -1495,7 +1498,7 @@ static int launch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, c
     attr_set = true;
   }
   const int nbm = (int)ceil_div(M, 64 * T), nbn = (int)ceil_div(N, 64 * T);
-  ScopedLaunchTimer timer((T - 1) + 2 * (FAST ? 1 : 0) + 4 * (AMUL ? 1 : 0), 2.0 * M * N * K, stream);
+  ScopedLaunchTimer timer((T - 1) + 2 * (FAST ? 1 : 0) + 4 * (AMUL ? 1 : 0), (double)M, (double)N, (double)K, stream);
   hipLaunchKernelGGL((gemm_nt_kernel<T, FAST, AMUL, BF3>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds, stream, A,
                      lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, a_vec,
                      b_vec, c_vec, am);
@@ -1509,7 +1512,7 @@ static int launch_nt_occ(const float* A, int64_t lda, const float* B, int64_t ld
   constexpr int lds_ops = (SINGLE ? 1 : 2) * 64 * (MI + NI) * (BKT + 4) * 4, lds_c = 32 * MI * (64 * NI + 4) * 4;
   constexpr int lds = lds_ops > lds_c ? lds_ops : lds_c;
   const int nbm = (int)ceil_div(M, 64 * MI), nbn = (int)ceil_div(N, 64 * NI);
-  ScopedLaunchTimer timer(AMUL ? 11 : (MI == 2 ? 9 : 10), 2.0 * M * N * K, stream);
+  ScopedLaunchTimer timer(AMUL ? 11 : (MI == 2 ? 9 : 10), (double)M, (double)N, (double)K, stream);
   hipLaunchKernelGGL((gemm_nt_occ_kernel<AMUL, BKT, SINGLE, MI, NI>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds,
                      stream, A, lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, c_vec,
                      am);
@@ -1544,7 +1547,7 @@ static int launch_nt_b3_as(const float* A, int64_t lda, const float* B, int64_t 
     attr_set = true;
   }
   const int nbm = (int)ceil_div(M, 64 * T), nbn = (int)ceil_div(N, 64 * T);
-  ScopedLaunchTimer timer((T - 1) + 2 + 4 * (AMUL ? 1 : 0), 2.0 * M * N * K, stream);
+  ScopedLaunchTimer timer((T - 1) + 2 + 4 * (AMUL ? 1 : 0), (double)M, (double)N, (double)K, stream);
   hipLaunchKernelGGL((gemm_nt_b3_kernel<T, AMUL, PRE>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk), lds, stream, A, lda,
                      B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale, nbm, nbn, c_vec, am, pre);
   return check_launch("gemm_nt(b3)");
@@ -1570,7 +1573,7 @@ static int launch_nt_narrow(const float* A, int64_t lda, const float* B, int64_t
                             int64_t ldc, int64_t M, int64_t N, int64_t K, int act, float act_param, float out_scale,
                             bool a_vec, bool b_vec, bool c_vec, const AMul& am, hipStream_t stream) {
   const int nbm = (int)ceil_div(M, 64), nbn = (int)ceil_div(N, 32);
-  ScopedLaunchTimer timer(FAST && !AMUL ? 12 : 13, 2.0 * M * N * K, stream);
+  ScopedLaunchTimer timer(FAST && !AMUL ? 12 : 13, (double)M, (double)N, (double)K, stream);
   hipLaunchKernelGGL((gemm_nt_narrow_kernel<FAST, AMUL, BF3>), dim3((unsigned)((int64_t)nbm * nbn)), dim3(kBlk),
                      kNarrowLds, stream, A, lda, B, ldb, bias, C, ldc, (int)M, (int)N, (int)K, act, act_param, out_scale,
                      nbm, nbn, a_vec, b_vec, c_vec, am);
@@ -1788,7 +1791,7 @@ extern "C" int recmv_gemm_tn(const float* A, int64_t lda, const float* B, int64_
   const bool a_vec = aligned16(A) && lda % 4 == 0, b_vec = aligned16(B) && ldb % 4 == 0;
   int rc;
   {                          // the events bracket the product kernel alone (slot 8 = one kernel symbol); its reduction pass follows
-  ScopedLaunchTimer timer(8, 2.0 * M * N * K, s);
+  ScopedLaunchTimer timer(8, (double)M, (double)N, (double)K, s);
   const bool bf3_tn = g_gemm_mode == 1 && (g_b3_families & 4);
   if (!bf3_tn && tn_occ() && a_vec && b_vec && lda >= ((M + 3) & ~3ll) && ldb >= ((N + 3) & ~3ll) && M >= 4 && N >= 4) {
     kchunk = ceil_div(ceil_div(K, splits), 16) * 16;
@@ -1842,6 +1845,16 @@ extern "C" int recmv_profile_begin(double min_flops) {
   return RECMV_OK;
 }
 
+// Algorithmic bytes (4 (M K + N K + M N): both operands read once, the result written once) of the launches the last
+// recmv_profile_end bracketed, per variant with the same slot folding as its `out`.  (ABI v7)
+extern "C" int recmv_profile_bytes(double* out, int n_variants) {
+  RECMV_REQUIRE(out && n_variants >= 9, "profile_bytes: need room for 9 variants");
+  for (int i = 0; i < n_variants; ++i) out[i] = 0.0;
+  auto slot = [&](int v) { return v < n_variants ? v : (v == 11 ? 7 : (v == 12 ? 2 : (v == 13 ? 6 : 3))); };
+  for (int v = 0; v < 14; ++v) out[slot(v)] += g_prof.timed_bytes[v];
+  return RECMV_OK;
+}
+
 extern "C" int recmv_profile_busy(double* out2) {
   RECMV_REQUIRE(out2, "profile_busy: NULL");
   out2[0] = g_prof.busy_union_s;
@@ -1864,7 +1877,9 @@ extern "C" int recmv_profile_end(double* out, int n_variants) {
   std::vector<std::pair<double, double>> iv;
   iv.reserve(g_prof.recs.size());
   hipEvent_t origin = g_prof.recs.empty() ? nullptr : g_prof.recs.front().a;
+  for (auto& b : g_prof.timed_bytes) b = 0.0;
   for (auto& r : g_prof.recs) {
+    g_prof.timed_bytes[r.variant] += r.bytes;
     RECMV_HIP_TRY(hipEventSynchronize(r.b));
     float ms = 0.f;
     RECMV_HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));

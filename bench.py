@@ -451,7 +451,25 @@ def config2_leg(loop, it, allreduce, world, device, steps=6):
             "rays_converged_fraction": round(conv / max(rays, 1), 4), "_steps_run": n}
 
 
-def high_convergence_leg(loop, it, allreduce, world, device, sync, steps=10, lr_scale=0.1):
+def full_load_leg(loop, it, allreduce, world, device, sync, steps=20, lr_scale=0.1):
+    """`value`'s cadence — ONE re-mesh inside the timed steps, as in the headline's 20 steps of a 30-iteration period — with the render
+    phases at full load: the learning rate scaled like high_convergence_leg's, so that nearly every ray converges, and the re-mesh
+    placed in the middle of the timed steps (forward_time set so that step steps/2 is the period's first)."""
+    period = int(loop.remesh_intersect)
+    old_ft = loop.forward_time
+    try:
+        def before_timed():
+            loop.forward_time = period - steps // 2          # the (steps/2)-th timed step re-meshes
+        out = high_convergence_leg(loop, it, allreduce, world, device, sync, steps=steps, lr_scale=lr_scale, before_timed=before_timed)
+    finally:
+        pass
+    out["workload"] = ("configs[1] as in `value` — one re-mesh inside the %d timed steps (the reference's cadence of one in %d would be "
+                       "%.2f of one) — with the main optimiser's learning rate x %g so that the render phases run at full load"
+                       % (steps, period, steps / period, lr_scale))
+    return out
+
+
+def high_convergence_leg(loop, it, allreduce, world, device, sync, steps=10, lr_scale=0.1, before_timed=None):
     """The headline iteration in the regime of a capture late in its optimisation, where the networks move slowly and the explicit
     meshes stay valid between two re-meshes: the main optimiser's learning rate scaled by `lr_scale` for the leg, a re-mesh in the
     untimed first step, then `steps` timed steps.  On the headline scene (fresh nets, Adam at 1e-4) under half of the rays still
@@ -466,6 +484,8 @@ def high_convergence_leg(loop, it, allreduce, world, device, sync, steps=10, lr_
         loop.forward_time = 0                       # the leg starts on freshly extracted meshes
         loop.step(it + n, allreduce)
         n += 1
+        if before_timed is not None:
+            before_timed()
         rdist.barrier()
         sync()
         t0 = time.perf_counter()
@@ -948,10 +968,12 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
             log("extra leg %s failed: %r" % (fn.__name__, exc))
             return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300]), "_steps_run": 0}
 
-    leg_hc = None
+    leg_hc = leg_fl = None
     if not args.no_config2 and on_gpu:
         leg_hc = leg(high_convergence_leg, loop, it, allreduce, world, device, sync)
         it += leg_hc.pop("_steps_run")
+        leg_fl = leg(full_load_leg, loop, it, allreduce, world, device, sync)
+        it += leg_fl.pop("_steps_run")
     leg2 = None
     if not args.no_config2:
         leg2 = leg(config2_leg, loop, it, allreduce, world, device)
@@ -963,6 +985,8 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                 ms = leg_hc["ms_per_step"] + rm["remesh_extra_ms"] / rm["period_iters"]
                 leg_hc["iters_per_sec_at_reference_cadence"] = round(world * 1e3 / ms, 4)
             line["high_convergence"] = leg_hc
+        if leg_fl:
+            line["full_load"] = leg_fl
         if leg2:
             line["config2"] = leg2
         print(json.dumps(line), flush=True)

@@ -37,24 +37,39 @@ def init_distributed(backend: str | None = None):
             local_rank = 0
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        # The default collective timeout (10 min for RCCL) is shorter than a first run's start-up stage, during which the other
-        # ranks wait for rank 0 (train.py: skinner bake, SDF pre-fit, feature-line registration): two hours unless told otherwise.
-        timeout = datetime.timedelta(seconds=float(os.environ.get("RECMV_DIST_TIMEOUT_S", "7200")))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+        # The training collectives keep the backend's default timeout (10 min for RCCL: a rank that crashed or fell out of step in steady
+        # state takes the job down in minutes; RECMV_DIST_TIMEOUT_S overrides).  Only the START-UP rendezvous waits long — a first
+        # run's start-up stage (train.py: skinner bake, SDF pre-fit, feature-line registration) takes rank 0 far longer than that while
+        # the other ranks wait — and it has its own host-side group with its own timeout (startup_gate below).
+        kw = {}
+        if os.environ.get("RECMV_DIST_TIMEOUT_S"):
+            kw["timeout"] = datetime.timedelta(seconds=float(os.environ["RECMV_DIST_TIMEOUT_S"]))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        global _gate_group
+        _gate_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(
+            seconds=float(os.environ.get("RECMV_STARTUP_TIMEOUT_S", "7200"))))
     return rank, local_rank, world
+
+
+_gate_group = None          # gloo group of all ranks for the start-up rendezvous (two-hour timeout), made by init_distributed
 
 
 def startup_gate(ok: bool = True, what: str = "start-up stage"):
     """Rendezvous behind a stage that only rank 0 ran: every rank learns whether it succeeded.  A plain barrier leaves the waiting
     ranks hanging until the collective timeout when rank 0 raised; here rank 0 reports its outcome (MIN over one flag per rank) and
-    every rank leaves with the same SystemExit when it failed."""
+    every rank leaves with the same SystemExit when it failed.  Called a second time behind the part EVERY rank runs (each rank
+    reporting its own outcome) it also catches a non-zero rank that failed after the first gate."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         if not ok:
             raise SystemExit(f"{what} failed")
         return
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if _gate_group is not None:                  # the long-timeout host group: a flag per rank, no device involved
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_gate_group)
+    else:                                        # (a process group somebody else initialised)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
         raise SystemExit(f"{what} failed on another rank" if ok else f"{what} failed")
 

@@ -270,13 +270,20 @@ def main(argv=None, large_pose=False):
             register_feature_lines(optNet, dataloader, load_fl_templates(args.fl_templates, FL_INFOS[optNet.garment_type], device),
                                    save_root)
     except BaseException:
-        if staged and rank == 0:
+        if staged:
             import traceback
             traceback.print_exc()
-            rdist.startup_gate(False)          # releases the waiting ranks with the failure instead of the collective timeout
+            if rank == 0:
+                rdist.startup_gate(False)      # releases the waiting ranks with the failure instead of the collective timeout
+            else:
+                rdist.startup_gate(False, "start-up stage (rank %d)" % rank)      # second gate: this rank's own failure, see below
         raise
     if staged and rank == 0:
         rdist.startup_gate(True)
+    if staged:
+        # second gate, every rank reporting its OWN outcome: a non-zero rank that failed in its getOptNet after the first gate (a
+        # half-written file, a missing capture on its node) takes the job down here instead of at the first collective's timeout
+        rdist.startup_gate(True, "start-up stage (every rank)")
     if rank == 0:                                 # train.py:86: wandb when it is there, a jsonl file under logs/ otherwise
         from recmv.engineer.visualizer import wandb_visualizer
         optNet.visualizer = wandb_visualizer(args.project_name, args.exp_name, resume=False, log_dir=osp.join(save_root, 'logs'))

@@ -2,6 +2,7 @@
 backward + propagateTmpPsGrad) and the tests (recmv's HotLoop): the state of tests/project2d_case.py (two explicit garment
 meshes, body, six curves, camera, 2-D feature lines) on a 40-frame sequence, plus images, normal maps, garment masks and
 per-frame colour codes."""
+import numpy as np
 import torch
 
 import project2d_case as pc
@@ -26,6 +27,11 @@ TRAJ_LR = 2e-5            # a fifth of the reference's train.learning_rate: on t
 # canonical surfaces by 0.1 in 35 steps and two runs of the REFERENCE ITSELF (4 vs 1 sgemm threads) end 2.4e-4 apart in Chamfer;
 # at 2e-5 the reference's own envelope is a few 1e-5 — below the north_star's 1e-4 — while the surfaces still move by ~100x that
 TRAJ_CANONICAL_RES = [(9, 11, 7), (17, 21, 13), (33, 41, 25), (65, 81, 49)]
+# trajectory_c2: the same 14 iterations with the re-mesh on BASELINE configs[1]'s own coarse pyramid (train.py:42-47) — ~1e5 vertices
+# per garment instead of ~1e2 — every TRAJ_C2_REMESH iterations (forward_time starts at 1: iterations 4 and 9), canonical extraction
+# on the same pyramid
+TRAJ_C2_RES = [(15, 21, 9), (29, 41, 17), (57, 81, 33), (113, 161, 65), (225, 321, 129)]
+TRAJ_C2_ITERS, TRAJ_C2_REMESH = 14, 5
 
 
 def trajectory_frames(it):
@@ -126,7 +132,8 @@ def build(g, device, large_pose=False, inputs=None, remesh=False, single=False, 
     dev = torch.device(device)
     st = {k[3:]: v.to(dev) for k, v in (inputs if inputs is not None else g).items() if k.startswith('in_')}
     ds = CaseDataset(st, dev, single=single)
-    optNet, _ = getOptNet(ds, None, N, (-0.8, -1.1, -0.6), (0.8, 1.1, 0.6), [(9, 11, 7), (17, 21, 13)], device, conf, curves=False,
+    res = [tuple(int(v) for v in r) for r in g['resolutions'].tolist()] if 'resolutions' in g else RESOLUTIONS      # (trajectory_c2)
+    optNet, _ = getOptNet(ds, None, N, (-0.8, -1.1, -0.6), (0.8, 1.1, 0.6), res, device, conf, curves=False,
                           skin_grid=(5, 9, 7), opt_large=large_pose)
     assert optNet.large_pose == large_pose
     leaf = lambda t: t.detach().clone().requires_grad_(True)
@@ -144,7 +151,7 @@ def build(g, device, large_pose=False, inputs=None, remesh=False, single=False, 
         torch.manual_seed(520)
         optNet.sdf = cs.perturb(getTmpSdf("cpu", 6, bias=BODY_BIAS), 502, 0.003).to(dev)
         optNet.body_vs = optNet.body_fs = None
-        assert [tuple(r) for r in optNet.engine.resolutions.tolist()] == RESOLUTIONS
+        assert [tuple(r) for r in optNet.engine.resolutions.tolist()] == res
     if not remesh:
         verts = [leaf(st['verts_u']), leaf(st['verts_b'])][:len(sdfs)]
         optNet.garment_vs, optNet.garment_fs = verts, [st['faces_u'].long(), st['faces_b'].long()][:len(sdfs)]
@@ -273,12 +280,18 @@ def run(g, device, rtol=1e-3, rtol_grad=1e-2, large_pose=False, inputs=None, rem
     return worst
 
 
-def chamfer_vertices(a, b):
+def chamfer_vertices(a, b, chunk=2048):
     """Symmetric Chamfer distance between two vertex sets in pytorch3d's convention (mean over points of the SQUARED distance to
-    the nearest neighbour, both directions summed) and the mean UNsquared nearest-neighbour distance, in float64."""
+    the nearest neighbour, both directions summed) and the mean UNsquared nearest-neighbour distance, in float64 (rows of the
+    distance matrix in chunks: the C2-sized meshes have ~1e5 vertices)."""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    d2 = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
-    ab, ba = d2.min(1).values, d2.min(0).values
+
+    def nearest(p, q):
+        out = []
+        for i in range(0, p.shape[0], chunk):
+            out.append(((p[i:i + chunk, None, :] - q[None, :, :]) ** 2).sum(-1).min(1).values)
+        return torch.cat(out) if out else p.new_zeros(0)
+    ab, ba = nearest(a, b), nearest(b, a)
     return float(ab.mean() + ba.mean()), float(0.5 * (ab.sqrt().mean() + ba.sqrt().mean()))
 
 
@@ -318,7 +331,8 @@ def run_trajectory(g, inputs, device, iters=None):
     ref_rays = g['rays']                                         # per garment (entering, converged)
     out['rays_ref'] = [(int(r[0] + r[2]), int(r[1]), int(r[3])) for r in ref_rays[:T]]
     if T == int(g['losses'].shape[0]):
-        fine = Seg3dLossless(query_func=None, b_min=list(BOX[0]), b_max=list(BOX[1]), resolutions=TRAJ_CANONICAL_RES,
+        canon_res = ([tuple(int(v) for v in r) for r in g['canonical_res'].tolist()] if 'canonical_res' in g else TRAJ_CANONICAL_RES)
+        fine = Seg3dLossless(query_func=None, b_min=list(BOX[0]), b_max=list(BOX[1]), resolutions=canon_res,
                              align_corners=False, balance_value=0.0, use_cuda_impl=dev.type == 'cuda', faster=False).to(dev)
         vs, fs = optNet.discretizeSDF(pc.RATIO, fine, 0.)
         for tag, v, f in zip(('body', 'u', 'b'), vs, fs):
@@ -401,6 +415,16 @@ def check_trajectory(out, g, other_arithmetic=False):
     return report
 
 
+def reference_envelope():
+    """tests/golden/trajectory_envelope.npz (make_golden_envelope.py): all pairwise canonical-mesh Chamfer distances between six runs
+    of the reference's own 35-iteration loop that differ only in the number of sgemm threads."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trajectory_envelope.npz")
+    if not os.path.isfile(path):
+        return None
+    return dict(np.load(path))
+
+
 def _check_trajectory_device(out, g):
     """The same run on the DEVICE, whose matrix products (f32 MFMA fma chains) round differently from the torch-CPU sgemm the
     reference and the CPU port share: the first iteration differs by 1e-6 on the loss instead of 1e-8, and the map amplifies a
@@ -428,15 +452,38 @@ def _check_trajectory_device(out, g):
     if n < total:
         return report
     short = total <= TRAJ_SHORT_ITERS
+    env = reference_envelope() if not short else None
     for tag in ('body', 'u', 'b'):
         c = out['canon_' + tag]
         ref_self = float(g['self_canon_chamfer_' + tag][0])
-        bound = 1e-4 if short else (1e-4 if tag == 'body' else min(1e-3, 0.2 * c['moved_sq']))
+        # 14 iterations: the north_star's 1e-4.  35 iterations: the spread the REFERENCE'S OWN loop shows when only the summation order
+        # of its matrix products changes — the largest of the 15 pairwise distances between six runs (1, 2, 3, 4, 6, 8 sgemm
+        # threads; tests/golden/make_golden_envelope.py -> trajectory_envelope.npz: upper garment 5.9e-6 .. 6.5e-5, bottom 9.7e-6 ..
+        # 5.2e-4, body 0).  The device is inside it for the bottom garment and the body; for the UPPER garment it ends at 2-3e-4,
+        # about four times the reference's largest pair: a different arithmetic (MFMA fma chains, hardware exp / log / sin) starts
+        # 1e-6 away on the loss where a reordered sgemm starts 1e-8 away, and the map multiplies a difference by ~2.5 per iteration —
+        # that garment is held to the old bound (a fifth of the distance its surface moved, at most 1e-3) and reported as OUTSIDE the
+        # envelope (`inside_reference_envelope`): the 35-iteration horizon is not claimed.
+        inside = None
+        if short:
+            bound = 1e-4
+        elif env is not None and tag != 'u':
+            bound = max(float(env['canon_chamfer_' + tag].max()), 1e-12) if tag != 'body' else 1e-4
+            inside = True
+        else:
+            bound = 1e-4 if tag == 'body' else min(1e-3, 0.2 * c['moved_sq'])
+        if env is not None:
+            inside = bool(c['chamfer_sq'] <= max(float(env['canon_chamfer_' + tag].max()), 1e-12))
         assert c['chamfer_sq'] <= bound, ("canonical-mesh Chamfer", tag, c, bound)
-        if short and tag != 'body':
+        if short and tag != 'body' and 'resolutions' not in g:
             assert c['moved_sq'] > 2.5 * 1e-4, ("fixture: the surfaces move by more than the tolerance", tag, c)
         report['canon_' + tag] = dict(chamfer_sq=c['chamfer_sq'], bound=bound, mean_dist=c['mean_dist'], moved_sq=c['moved_sq'],
                                       reference_vs_itself=ref_self, verts=c['verts'], faces_equal=c['faces_equal'])
+        if env is not None:
+            d = env['canon_chamfer_' + tag]
+            iu = d[np.triu_indices(d.shape[0], 1)]
+            report['canon_' + tag].update(reference_envelope_min_median_max=[float(iu.min()), float(np.median(iu)), float(iu.max())],
+                                          inside_reference_envelope=inside)
     report['remesh_faces_equal'] = out['remesh_faces_equal']
     report['explicit'] = {t: out['explicit_' + t] for t in ('u', 'b')}
     return report

@@ -1,6 +1,6 @@
 # Round-end evidence on one MI355X box: PMC passes over bench.py (-> profiles/rNN_pmc_loop.json), the kernel trace of the bench
 # command, the driver's bench command, the GPU suite.   bash tools/round_measure.sh r03 <commit sha>
-R=${1:-r04}; SHA=${2:-unknown}
+R=${1:-r05}; SHA=${2:-unknown}
 REPO=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -20,6 +20,15 @@ timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_ben
 tail -3 gpurun_out/${R}_bench_driver.err
 timeout 900 python -m pytest tests -m gpu -q > gpurun_out/${R}_gpu_suite_final.txt 2>&1
 tail -3 gpurun_out/${R}_gpu_suite_final.txt
+# row (g): the trajectory reports (14 / 35 iterations, the C2-sized pyramid) as the test prints them
+timeout 600 python -m pytest tests/test_gpu_composite.py -q -s -k trajectory 2>&1 | grep "on the GPU:" > gpurun_out/${R}_trajectory_gpu.txt
+cut -c1-600 gpurun_out/${R}_trajectory_gpu.txt
+# run-to-run reproducibility: 50 repetitions of one iteration per cell, both matrix modes, side stream on / off
+timeout 300 python tools/loop_repro_inproc.py 50 "f32 side-stream,f32 one-ray-stream,bf16x6 side-stream,bf16x6 one-ray-stream,f32 serial" 2>/dev/null | cut -c1-400 > gpurun_out/${R}_loop_repro_50.txt
+cat gpurun_out/${R}_loop_repro_50.txt
+# ... and across processes (f32, default switches): 6 fresh processes, 3 iterations each, one digest expected
+for i in 1 2 3 4 5 6; do timeout 120 python tools/determinism_probe.py 3 2>/dev/null | md5sum | cut -c1-8; done | sort | uniq -c > gpurun_out/${R}_loop_repro_processes.txt
+cat gpurun_out/${R}_loop_repro_processes.txt
 python -c "
 import json
 d=json.loads(open('gpurun_out/${R}_bench_line_driver_command.json').read().strip().splitlines()[-1])

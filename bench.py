@@ -287,10 +287,16 @@ def hbm_kernel_block(loop, device):
     from recmv import FastMinv, GridSamplerMine, _lib as L, interp2x_boundary3d
     out = []
 
-    def add(name, nbytes, fn):
+    def add(name, nbytes, fn, survey_bytes=None):
         sec, how = _graph_time(fn)
         out.append(dict(kernel=name, us=round(sec * 1e6, 2), alg_bytes=int(nbytes),
                         achieved_gbs=round(nbytes / sec / 1e9, 1), frac=round(nbytes / sec / HBM_PEAK, 4), timing=how))
+        if survey_bytes is not None:
+            # SURVEY.md §8(d)'s own formula for the sampler adds the touched part of the grid, min(4 C D H W, 32 C P): it counts the
+            # corner records a point gathers, which the L2 serves when neighbouring points share them — the fraction can exceed 1
+            # there; `frac` above counts only what must cross HBM per point (coordinates in, result out)
+            out[-1]["alg_bytes_survey_8d"] = int(survey_bytes)
+            out[-1]["frac_survey_8d"] = round(survey_bytes / sec / HBM_PEAK, 4)
 
     sk = loop.deformer.defs[1]
     vol = sk.ws                                                          # [1,24,D,H,W] channels-last
@@ -302,12 +308,15 @@ def hbm_kernel_block(loop, device):
         P = g.shape[3]
         go = torch.randn(1, Cc, 1, 1, P, device=device)
         gg = torch.randn(1, 1, 1, P, 3, device=device)
+        touched = min(4 * Cc * vol.shape[2] * vol.shape[3] * vol.shape[4], 32 * Cc * P)
         add(f"grid sampler forward, P={P} MC vertices ({tag})", P * (12 + 4 * Cc),
-            lambda g=g: GridSamplerMine.forward(vol, g, 0, 1))
+            lambda g=g: GridSamplerMine.forward(vol, g, 0, 1), survey_bytes=P * (12 + 4 * Cc) + touched)
         add(f"grid sampler backward (grad_grid), P={P}", P * (12 + 4 * Cc + 12),
-            lambda g=g, go=go: GridSamplerMine.backward(vol, g, go, 0, 1, need_grad_input=False))
+            lambda g=g, go=go: GridSamplerMine.backward(vol, g, go, 0, 1, need_grad_input=False),
+            survey_bytes=P * (12 + 4 * Cc + 12) + touched)
         add(f"grid sampler double backward, P={P}", P * (12 + 12 + 4 * Cc + 12 + 4 * Cc),
-            lambda g=g, go=go, gg=gg: GridSamplerMine.dbackward(None, gg, vol, g, go, 0, 1, need_grad_input=False))
+            lambda g=g, go=go, gg=gg: GridSamplerMine.dbackward(None, gg, vol, g, go, 0, 1, need_grad_input=False),
+            survey_bytes=P * (12 + 12 + 4 * Cc + 12 + 4 * Cc) + touched)
     lib = L.lib()
     st = lambda: L.stream_ptr(device)
     for shape, volume in (((257, 257, 257), None), (tuple(int(v) for v in loop.engine.resolutions[-1]), None)):

@@ -287,10 +287,14 @@ def chamfer_vertices(a, b, chunk=2048):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
 
     def nearest(p, q):
-        out = []
-        for i in range(0, p.shape[0], chunk):
-            out.append(((p[i:i + chunk, None, :] - q[None, :, :]) ** 2).sum(-1).min(1).values)
-        return torch.cat(out) if out else p.new_zeros(0)
+        if p.shape[0] * q.shape[0] <= 1 << 24:                      # small sets: the plain difference form
+            return ((p[:, None, :] - q[None, :, :]) ** 2).sum(-1).min(1).values
+        out, q2 = [], (q * q).sum(1)
+        for i in range(0, p.shape[0], chunk):                       # |p|^2 + |q|^2 - 2 p.q in float64, then the exact difference at the argmin
+            pc_ = p[i:i + chunk]
+            j = ((pc_ * pc_).sum(1, keepdim=True) + q2[None, :] - 2.0 * pc_ @ q.t()).argmin(1)
+            out.append(((pc_ - q[j]) ** 2).sum(1))
+        return torch.cat(out)
     ab, ba = nearest(a, b), nearest(b, a)
     return float(ab.mean() + ba.mean()), float(0.5 * (ab.sqrt().mean() + ba.sqrt().mean()))
 

@@ -477,7 +477,7 @@ def _check_trajectory_device(out, g):
         else:
             bound = 1e-4 if tag == 'body' else min(1e-3, 0.2 * c['moved_sq'])
         if env is not None:
-            inside = bool(c['chamfer_sq'] <= max(float(env['canon_chamfer_' + tag].max()), 1e-12))
+            inside = bool(c['chamfer_sq'] <= max(float(env['canon_chamfer_' + tag].max()), 1e-10))      # (1e-10: vertices 1e-5 apart — f32 evaluation of the untrained body net)
         assert c['chamfer_sq'] <= bound, ("canonical-mesh Chamfer", tag, c, bound)
         if short and tag != 'body' and 'resolutions' not in g:
             assert c['moved_sq'] > 2.5 * 1e-4, ("fixture: the surfaces move by more than the tolerance", tag, c)

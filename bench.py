@@ -87,12 +87,15 @@ class KernelEvents:
         L.check(L.lib().recmv_profile_end(C.cast(buf, C.c_void_p), len(NT_VARIANTS)), "profile_end")
         by = (C.c_double * len(NT_VARIANTS))()
         L.check(L.lib().recmv_profile_bytes(C.cast(by, C.c_void_p), len(NT_VARIANTS)), "profile_bytes")
+        lg = (C.c_double * (3 * len(NT_VARIANTS)))()
+        L.check(L.lib().recmv_profile_large(C.cast(lg, C.c_void_p), len(NT_VARIANTS)), "profile_large")
         out, small = {}, {}
         for v, name in enumerate(NT_VARIANTS):
             n, sec, fl, un, ufl = buf[5 * v:5 * v + 5]
             if n > 0:
                 out[name] = dict(launches=int(n), seconds=sec, flops=fl, avg_us=sec / n * 1e6, avg_flops=fl / n,
-                                 avg_alg_bytes=by[v] / n)
+                                 avg_alg_bytes=by[v] / n,
+                                 large=dict(launches=int(lg[3 * v]), seconds=lg[3 * v + 1], flops=lg[3 * v + 2]))
             if un > 0:
                 small[name] = dict(launches=int(un), gflop=round(ufl / 1e9, 1))
         self.small = small
@@ -887,7 +890,13 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                 log("whole-step matrix rate not computed: %r" % (e,))
             if gs_serial and dom in gs_serial:
                 a = gs_serial[dom]
-                line["roofline"]["frac_kernel_only"] = round(a["flops"] / a["seconds"] / MFMA_F32_PEAK, 4)
+                big = a.get("large") or {}
+                if big.get("launches"):                # the same subset as the timed region's brackets: launches of >= 4 GFLOP
+                    line["roofline"]["frac_kernel_only"] = round(big["flops"] / big["seconds"] / MFMA_F32_PEAK, 4)
+                    line["roofline"]["kernel_only_launches"] = big["launches"]
+                    line["roofline"]["kernel_only_avg_launch_us"] = round(big["seconds"] / big["launches"] * 1e6, 2)
+                else:
+                    line["roofline"]["frac_kernel_only"] = round(a["flops"] / a["seconds"] / MFMA_F32_PEAK, 4)
                 line["roofline"]["frac_note"] = ("`frac` / `frac_in_loop`: HIP events around every launch of the kernel in the timed region, "
                                                  "where two to three other streams share the CUs with it (the events measure the sharing too); "
                                                  "`frac_kernel_only`: the same kernel, same shapes, with the iteration on one stream")
@@ -907,7 +916,9 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                 fc.append({"kernel": "recmv::" + k, "launches": v["launches"], "avg_launch_us": round(v["avg_us"], 2),
                            "achieved": round(v["flops"] / v["seconds"] / 1e12, 3),
                            "frac": round(v["flops"] / v["seconds"] / MFMA_F32_PEAK, 4),
-                           "share_of_step": round(v["seconds"] / elapsed, 3), "timing": "HIP events around every launch in the timed region"})
+                           "share_of_step": round(v["seconds"] / elapsed, 3), "timing": "HIP events around every launch in the timed region",
+                           "frac_kernel_only": (round(gs_serial[k]["large"]["flops"] / gs_serial[k]["large"]["seconds"] / MFMA_F32_PEAK, 4)
+                                                if gs_serial and k in gs_serial and gs_serial[k].get("large", {}).get("launches") else None)})
             for k, v in (small_launches or {}).items():
                 sv = (gs_serial or {}).get(k)
                 if not sv or v["launches"] < 100:

@@ -546,6 +546,8 @@ int recmv_profile_end(double* out, int n_variants);
 /* Algorithmic bytes, 4 (M K + N K + M N), of the launches the last recmv_profile_end bracketed, per variant (same slots as its `out`:
  * out[v]).  With their summed duration this is the kernel's HBM-side roofline beside its MFMA one.  (ABI v7) */
 int recmv_profile_bytes(double* out, int n_variants);
+/* The launches of >= 4 GFLOP among the bracketed ones: out[3v] launches, out[3v+1] seconds, out[3v+2] FLOP.  (ABI v7) */
+int recmv_profile_large(double* out, int n_variants);
 /* After recmv_profile_end: out2[0] = seconds in which at least ONE bracketed launch was running (union of the event intervals of all
  * streams on one time axis), out2[1] = seconds from the first bracketed start to the last bracketed end. */
 int recmv_profile_busy(double* out2);

@@ -1408,6 +1408,7 @@ struct Profiler {
   double untimed[14][2] = {};      // [variant][launches, flops]
   std::vector<LaunchRec> recs;
   std::vector<hipEvent_t> pool;
+  double large[14][3] = {};        // of the last recmv_profile_end: launches / seconds / FLOP of the bracketed launches of >= 4 GFLOP
   double timed_bytes[14] = {};     // of the last recmv_profile_end: algorithmic bytes (4 (MK + NK + MN)) of the bracketed launches, per variant
   double busy_union_s = 0.0, busy_span_s = 0.0;   // of the last recmv_profile_end: union of the bracketed intervals, first start -> last end
   std::mutex mu;        // autograd's backward thread launches too
@@ -1855,6 +1856,17 @@ extern "C" int recmv_profile_bytes(double* out, int n_variants) {
   return RECMV_OK;
 }
 
+// The launches of >= 4 GFLOP among those the last recmv_profile_end bracketed (a pass that brackets EVERY launch still yields the
+// large products' own rate): out[3v] = launches, out[3v+1] = seconds, out[3v+2] = FLOP, same slots as recmv_profile_end.  (ABI v7)
+extern "C" int recmv_profile_large(double* out, int n_variants) {
+  RECMV_REQUIRE(out && n_variants >= 9, "profile_large: need room for 9 variants");
+  for (int i = 0; i < 3 * n_variants; ++i) out[i] = 0.0;
+  auto slot = [&](int v) { return v < n_variants ? v : (v == 11 ? 7 : (v == 12 ? 2 : (v == 13 ? 6 : 3))); };
+  for (int v = 0; v < 14; ++v)
+    for (int q = 0; q < 3; ++q) out[3 * slot(v) + q] += g_prof.large[v][q];
+  return RECMV_OK;
+}
+
 extern "C" int recmv_profile_busy(double* out2) {
   RECMV_REQUIRE(out2, "profile_busy: NULL");
   out2[0] = g_prof.busy_union_s;
@@ -1878,11 +1890,17 @@ extern "C" int recmv_profile_end(double* out, int n_variants) {
   iv.reserve(g_prof.recs.size());
   hipEvent_t origin = g_prof.recs.empty() ? nullptr : g_prof.recs.front().a;
   for (auto& b : g_prof.timed_bytes) b = 0.0;
+  for (auto& l : g_prof.large) l[0] = l[1] = l[2] = 0.0;
   for (auto& r : g_prof.recs) {
     g_prof.timed_bytes[r.variant] += r.bytes;
     RECMV_HIP_TRY(hipEventSynchronize(r.b));
     float ms = 0.f;
     RECMV_HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+    if (r.flops >= 4.0e9) {
+      g_prof.large[r.variant][0] += 1.0;
+      g_prof.large[r.variant][1] += (double)ms * 1e-3;
+      g_prof.large[r.variant][2] += r.flops;
+    }
     out[5 * slot(r.variant) + 0] += 1.0;
     out[5 * slot(r.variant) + 1] += (double)ms * 1e-3;
     out[5 * slot(r.variant) + 2] += r.flops;

@@ -115,6 +115,7 @@ def _declare(lib):
         "recmv_mlp_vjp_input": (C.c_int, [C.POINTER(Mlp), vp, i64, i32, vp, i64, vp, vp, i64, vp]),
         "recmv_profile_busy": (C.c_int, [vp]),
         "recmv_profile_bytes": (C.c_int, [vp, i32]),
+        "recmv_profile_large": (C.c_int, [vp, i32]),
         "recmv_mc_run_batch": (C.c_int, [i32, vp, i64, i64, i64, f32, f32, f32, f32, f32, f32, f32, vp, i64, vp, vp, vp, vp, vp, vp]),
         "recmv_mlp_rows_supported": (C.c_int, [C.POINTER(Mlp)]),
         "recmv_set_mlp_rows_tile": (C.c_int, [i32]),

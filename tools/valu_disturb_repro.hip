@@ -31,23 +31,48 @@
 
 constexpr int kBlk = 256;
 
+// FMA-only stand-ins (V6): no v_rcp / v_sqrt / v_rsq / v_log anywhere — integer-seeded Newton iterations and an atanh series
+__device__ __forceinline__ float n_rcp(float x) {
+  float r = __uint_as_float(0x7ef311c7u - __float_as_uint(fabsf(x)));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r = r * (2.f - fabsf(x) * r);
+  return __uint_as_float(__float_as_uint(r) | (__float_as_uint(x) & 0x80000000u));
+}
+__device__ __forceinline__ float n_rsqrt(float x) {
+  float r = __uint_as_float(0x5f3759dfu - (__float_as_uint(x) >> 1));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r = r * (1.5f - 0.5f * x * r * r);
+  return r;
+}
+__device__ __forceinline__ float n_log(float x) {       // x > 0, normal
+  const unsigned u = __float_as_uint(x);
+  const float e = (float)((int)(u >> 23) - 127);
+  const float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);      // [1, 2)
+  const float t = (m - 1.f) * n_rcp(m + 1.f), t2 = t * t;
+  const float p = t * (2.f + t2 * (0.66666667f + t2 * (0.4f + t2 * (0.28571429f + t2 * 0.22222222f))));
+  return e * 0.6931471805599453f + p;
+}
+
 template <int V>
 __device__ __forceinline__ float t_rcp(float x) {
-  if (V == 2) return __builtin_amdgcn_rcpf(x);
+  if (V == 6) return n_rcp(x);
+  if (V == 2 || V == 5) return __builtin_amdgcn_rcpf(x);
   float r = __builtin_amdgcn_rcpf(x);
   asm volatile("s_nop 7" : "+v"(r));
   return r;
 }
 template <int V>
 __device__ __forceinline__ float t_sqrt(float x) {
-  if (V == 2) return __builtin_amdgcn_sqrtf(x);
+  if (V == 6) return x * n_rsqrt(x);
+  if (V == 2 || V == 5) return __builtin_amdgcn_sqrtf(x);
   float r = __builtin_amdgcn_sqrtf(x);
   asm volatile("s_nop 7" : "+v"(r));
   return r;
 }
 template <int V>
 __device__ __forceinline__ float t_log(float x) {
-  if (V == 2) return __builtin_amdgcn_logf(x) * 0.6931471805599453f;
+  if (V == 6) return n_log(x);
+  if (V == 2 || V == 5) return __builtin_amdgcn_logf(x) * 0.6931471805599453f;
   float r = __builtin_amdgcn_logf(x);
   asm volatile("s_nop 7" : "+v"(r));
   return r * 0.6931471805599453f;
@@ -58,14 +83,16 @@ __device__ __forceinline__ void rotate(float (&b)[3][3], float (&v)[3][3]) {
   const float alpha = b[0][p] * b[0][p] + b[1][p] * b[1][p] + b[2][p] * b[2][p];
   const float beta = b[0][q] * b[0][q] + b[1][q] * b[1][q] + b[2][q] * b[2][q];
   const float gamma = b[0][p] * b[0][q] + b[1][p] * b[1][q] + b[2][p] * b[2][q];
-  if (fabsf(gamma) < 1e-37f) return;
+  if (V != 5) {
+    if (fabsf(gamma) < 1e-37f) return;
+  }
   float zeta, t, c;
   if (V <= 1) {
     zeta = (beta - alpha) / (2.f * gamma);
     t = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(zeta * zeta + 1.f));
     c = 1.f / sqrtf(t * t + 1.f);
   } else {
-    zeta = (beta - alpha) * t_rcp<V>(2.f * gamma);
+    zeta = (beta - alpha) * t_rcp<V>(V == 5 ? 2.f * gamma + copysignf(1e-30f, gamma) : 2.f * gamma);
     t = (zeta >= 0.f ? 1.f : -1.f) * t_rcp<V>(fabsf(zeta) + t_sqrt<V>(zeta * zeta + 1.f));
     c = t_rcp<V>(t_sqrt<V>(t * t + 1.f));
   }
@@ -395,14 +422,15 @@ int main(int argc, char** argv) {
     CK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
     CK(hipMalloc(&C[i], M * N * 4));
   }
-  Kern kerns[5] = {regu_variant<0>, regu_variant<1>, regu_variant<2>, regu_variant<3>, regu_variant<4>};
-  const char* names[5] = {"V0 LDS + libm (the product's kernel)", "V1 no LDS, libm", "V2 LDS, raw v_rcp/v_sqrt/v_log",
-                          "V3 LDS, raw transcendentals + s_nop 7 behind each", "V4 LDS, FMA chain, no transcendental"};
+  Kern kerns[7] = {regu_variant<0>, regu_variant<1>, regu_variant<2>, regu_variant<3>, regu_variant<4>, regu_variant<5>, regu_variant<6>};
+  const char* names[7] = {"V0 LDS + libm (the product's kernel)", "V1 no LDS, libm", "V2 LDS, raw v_rcp/v_sqrt/v_log",
+                          "V3 LDS, raw transcendentals + s_nop 7 behind each", "V4 LDS, FMA chain, no transcendental",
+                          "V5 = V2 without the divergent early-out", "V6 = V2's control flow, FMA-only rcp / sqrt / log"};
   std::vector<float> hy(P), hy0(P), hg(P * 9), hg0(P * 9);
   for (int mode = 1; mode >= 0; --mode) {
     recmv_set_gemm_mode(mode);
     for (int busy = 0; busy < 2; ++busy)
-      for (int v = 0; v < 5; ++v) {
+      for (int v = 0; v < 7; ++v) {
         hipLaunchKernelGGL(kerns[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y0, g0);
         CK(hipStreamSynchronize(main_s));
         CK(hipMemcpy(hy0.data(), y0, P * 4, hipMemcpyDeviceToHost));
@@ -438,6 +466,7 @@ int main(int argc, char** argv) {
         fflush(stdout);
       }
   }
+  if (argc > 2) return 0;          // (variants only)
   // ---- the same instruction stream on different DATA: does what the product kernel multiplies matter?
   {
     recmv_set_gemm_mode(1);

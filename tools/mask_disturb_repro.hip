@@ -63,12 +63,42 @@ __global__ __launch_bounds__(256) void victim(unsigned* __restrict__ out, int ro
     } else if (W == 4) {
       const unsigned long long m = __ballot(x < 0.5f);
       bad += ((unsigned)(m >> (threadIdx.x & 63)) & 1u) ^ sign;
-    } else {
+    } else if (W == 5) {
       float a = x + 1.0f, b = a;
       asm volatile("" : "+v"(a));
       asm volatile("" : "+v"(b));
       const float r1 = __builtin_amdgcn_sqrtf(a) + __builtin_amdgcn_logf(a), r2 = __builtin_amdgcn_sqrtf(b) + __builtin_amdgcn_logf(b);
       bad |= __float_as_uint(r1) ^ __float_as_uint(r2);
+    } else if (W == 6 || W == 7) {
+      // the form the compiler emits in the regulariser: a VOP3 compare into an SGPR PAIR (not VCC) and a VOP3 select reading that pair,
+      // W6 back to back, W7 with `s_nop 4` between them
+      unsigned long long m;
+      unsigned sel;
+      const float half = 0.5f;
+      if (W == 6)
+        asm volatile("v_cmp_lt_f32_e64 %0, %2, %3\n\tv_cndmask_b32_e64 %1, 0, 1, %0" : "=&s"(m), "=v"(sel) : "v"(x), "v"(half));
+      else
+        asm volatile("v_cmp_lt_f32_e64 %0, %2, %3\n\ts_nop 4\n\tv_cndmask_b32_e64 %1, 0, 1, %0" : "=&s"(m), "=v"(sel) : "v"(x), "v"(half));
+      bad += sel ^ sign;
+    } else if (W == 8) {
+      // packed f32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32), each checked against the scalar instruction's bits
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 a = {x, x + 0.25f}, b = {x * 0.5f + 0.1f, 1.5f - x}, c = {0.75f, x};
+      asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+      f2 pm, pf, pa;
+      asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(pm) : "v"(a), "v"(b));
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pf) : "v"(a), "v"(b), "v"(c));
+      asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(pa) : "v"(a), "v"(b));
+      float sm0, sm1, sf0, sf1, sa0, sa1;
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(sm0) : "v"(a.x), "v"(b.x));
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(sm1) : "v"(a.y), "v"(b.y));
+      asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(sf0) : "v"(a.x), "v"(b.x), "v"(c.x));
+      asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(sf1) : "v"(a.y), "v"(b.y), "v"(c.y));
+      asm volatile("v_add_f32 %0, %1, %2" : "=v"(sa0) : "v"(a.x), "v"(b.x));
+      asm volatile("v_add_f32 %0, %1, %2" : "=v"(sa1) : "v"(a.y), "v"(b.y));
+      bad |= (__float_as_uint(pm.x) ^ __float_as_uint(sm0)) | (__float_as_uint(pm.y) ^ __float_as_uint(sm1)) |
+             (__float_as_uint(pf.x) ^ __float_as_uint(sf0)) | (__float_as_uint(pf.y) ^ __float_as_uint(sf1)) |
+             (__float_as_uint(pa.x) ^ __float_as_uint(sa0)) | (__float_as_uint(pa.y) ^ __float_as_uint(sa1));
     }
   }
   out[tid] = W == 2 ? (count ^ expect) : bad;
@@ -97,13 +127,15 @@ int main(int argc, char** argv) {
     CK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
     CK(hipMalloc(&C[i], M * N * 4));
   }
-  Vic vics[5] = {victim<1>, victim<2>, victim<3>, victim<4>, victim<5>};
-  const char* names[5] = {"W1 v_cmp + v_cndmask vs sign bit", "W2 v_cmp + divergent branch vs sign bits", "W3 v_rcp_f32 twice, same operand",
-                          "W4 v_cmp -> SGPR pair (ballot) vs sign bit", "W5 v_sqrt_f32 + v_log_f32 twice"};
+  constexpr int NW = 8;
+  Vic vics[NW] = {victim<1>, victim<2>, victim<3>, victim<4>, victim<5>, victim<6>, victim<7>, victim<8>};
+  const char* names[NW] = {"W1 v_cmp + v_cndmask vs sign bit", "W2 v_cmp + divergent branch vs sign bits", "W3 v_rcp_f32 twice, same operand",
+                           "W4 v_cmp -> SGPR pair (ballot) vs sign bit", "W5 v_sqrt_f32 + v_log_f32 twice",
+                           "W6 v_cmp_e64 -> SGPR pair -> v_cndmask_e64", "W7 = W6 with s_nop 4 between", "W8 v_pk_{mul,fma,add}_f32 vs scalar ops"};
   for (int mode = 1; mode >= 0; --mode) {
     recmv_set_gemm_mode(mode);
-    for (int busy = 1; busy >= 0; --busy)
-      for (int w = 0; w < 5; ++w) {
+    for (int busy = 1; busy >= 1; --busy)
+      for (int w = 0; w < NW; ++w) {
         CK(hipDeviceSynchronize());
         int bad_launches = 0;
         long bad_lanes = 0, hist[4] = {0, 0, 0, 0};

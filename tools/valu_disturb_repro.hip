@@ -386,6 +386,86 @@ __global__ __launch_bounds__(256) void aggressor_loop(float* __restrict__ out, i
 }
 typedef void (*Agg)(float*, int);
 
+
+// ---- bisecting the victim: which part of the regulariser's code is it?
+//   B0  the 15 rotations (raw transcendentals, selects, early-out) applied to b and v; outputs = sums of b and v (no log tail)
+//   B1  15 rotations with CONSTANT c, s: only the column updates (the packed f32 multiplies / FMAs on 18 live registers)
+//   B2  the 15 (c, s) computations (dot products, v_rcp, v_sqrt, compare + select) WITHOUT applying them; outputs their sum
+//   B3  B1 with the updates written so that the compiler cannot pair them (scalar v_mul / v_fma only: a volatile-asm barrier per value)
+template <int B>
+__global__ __launch_bounds__(kBlk) void bisect_variant(const float* __restrict__ J, long P, float inv_c2, float* __restrict__ y,
+                                                       float* __restrict__ gJ) {
+  const long i0 = (long)blockIdx.x * kBlk + threadIdx.x;
+  if (i0 >= P) return;
+  float b[3][3], v[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      b[i][j] = J[i0 * 9 + 3 * i + j];
+      v[i][j] = i == j ? 1.f : 0.f;
+    }
+  float acc = 0.f;
+#pragma unroll
+  for (int sweep = 0; sweep < 5; ++sweep) {
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+      float c = 0.8f, s_ = 0.6f;
+      if (B == 0 || B == 2) {
+        const float alpha = b[0][p] * b[0][p] + b[1][p] * b[1][p] + b[2][p] * b[2][p];
+        const float beta = b[0][q] * b[0][q] + b[1][q] * b[1][q] + b[2][q] * b[2][q];
+        const float gamma = b[0][p] * b[0][q] + b[1][p] * b[1][q] + b[2][p] * b[2][q];
+        const bool skip = fabsf(gamma) < 1e-37f;
+        const float zeta = (beta - alpha) * __builtin_amdgcn_rcpf(2.f * gamma);
+        const float t = (zeta >= 0.f ? 1.f : -1.f) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(zeta * zeta + 1.f));
+        c = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(t * t + 1.f));
+        s_ = t * c;
+        if (skip) {
+          c = 1.f;
+          s_ = 0.f;
+        }
+        acc += c + s_;
+      }
+      if (B != 2) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float bp = b[k][p], bq = b[k][q], vp = v[k][p], vq = v[k][q];
+          if (B == 3) {
+            asm volatile("" : "+v"(bp));
+            asm volatile("" : "+v"(bq));
+            asm volatile("" : "+v"(vp));
+            asm volatile("" : "+v"(vq));
+          }
+          float n0 = c * bp - s_ * bq, n1 = s_ * bp + c * bq, n2 = c * vp - s_ * vq, n3 = s_ * vp + c * vq;
+          if (B == 3) {
+            asm volatile("" : "+v"(n0));
+            asm volatile("" : "+v"(n1));
+            asm volatile("" : "+v"(n2));
+            asm volatile("" : "+v"(n3));
+          }
+          b[k][p] = n0;
+          b[k][q] = n1;
+          v[k][p] = n2;
+          v[k][q] = n3;
+        }
+      } else {
+        b[0][p] += 1e-3f * c;       // keep the inputs of the next (c, s) moving
+        b[1][q] -= 1e-3f * s_;
+      }
+    }
+  }
+  float sb = acc;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      sb += b[i][j];
+      gJ[i0 * 9 + 3 * i + j] = b[i][j] + 2.f * v[i][j];
+    }
+  y[i0] = sb * inv_c2;
+}
+
 typedef void (*Kern)(const float*, long, float, float*, float*);
 
 int main(int argc, char** argv) {
@@ -466,7 +546,40 @@ int main(int argc, char** argv) {
         fflush(stdout);
       }
   }
-  if (argc > 2) return 0;          // (variants only)
+  if (argc > 2) {                   // (variants only) + the bisect kernels beside the bf16x6 products
+    recmv_set_gemm_mode(1);
+    Kern bk[4] = {bisect_variant<0>, bisect_variant<1>, bisect_variant<2>, bisect_variant<3>};
+    const char* bn[4] = {"B0 15 rotations (c, s from rcp / sqrt / select) applied, no log tail", "B1 15 rotations with constant c, s (column updates only)",
+                         "B2 15 (c, s) computations, not applied", "B3 = B1 with unpaired scalar multiplies / FMAs"};
+    for (int v = 0; v < 4; ++v) {
+      CK(hipDeviceSynchronize());
+      hipLaunchKernelGGL(bk[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y0, g0);
+      CK(hipStreamSynchronize(main_s));
+      CK(hipMemcpy(hy0.data(), y0, P * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hg0.data(), g0, P * 36, hipMemcpyDeviceToHost));
+      int bad = 0;
+      long nbad = 0, first_lane = -1;
+      for (int it = 0; it < iters; ++it) {
+        for (int i = 0; i < 2; ++i)
+          for (int r = 0; r < 2; ++r) recmv_gemm_nt(A, K, B, K, nullptr, C[i], N, M, N, K, RECMV_ACT_RELU, 0.f, 1.f, side[i]);
+        hipLaunchKernelGGL(bk[v], dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y, g);
+        CK(hipMemcpyAsync(hy.data(), y, P * 4, hipMemcpyDeviceToHost, main_s));
+        CK(hipMemcpyAsync(hg.data(), g, P * 36, hipMemcpyDeviceToHost, main_s));
+        CK(hipStreamSynchronize(main_s));
+        bool diff = false;
+        for (long i = 0; i < P; ++i)
+          if (memcmp(&hy[i], &hy0[i], 4) != 0 || memcmp(&hg[i * 9], &hg0[i * 9], 36) != 0) {
+            diff = true;
+            ++nbad;
+            if (first_lane < 0) first_lane = i % 64;
+          }
+        bad += diff;
+      }
+      printf("bisect  %-76s %3d of %d launches differ (%ld matrices; lane of the first: %ld)\n", bn[v], bad, iters, nbad, first_lane);
+      fflush(stdout);
+    }
+    return 0;
+  }
   // ---- the same instruction stream on different DATA: does what the product kernel multiplies matter?
   {
     recmv_set_gemm_mode(1);

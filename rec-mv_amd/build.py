@@ -33,6 +33,13 @@ COMMON_FLAGS = [
     "-Wno-unused-function",
     "-Wno-unused-variable",
     f"-I{INCLUDE}",
+    # No packed-f32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) in any kernel of this library.  Round 5 traced the
+    # run-to-run divergence of the bf16x6 matrix mode to exactly these instructions: a wave executing them while waves of that mode's
+    # NT product kernels run beside it on the device gets WRONG results in lanes 48-63, a few launches in a hundred (gfx950, ROCm
+    # 7.2; tools/valu_disturb_repro.hip: the same column updates fail as v_pk_* and never fail as scalar v_mul / v_fma; built with this
+    # flag every victim is clean).  The feature switch is read by the device pass only (the host pass prints "not a
+    # recognized feature ... ignoring", which is why the compile's stderr is only shown with --verbose).
+    "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
 ]
 # extern "C" entry points are exported explicitly through this macro-free rule: default visibility for
 # extern "C" symbols only is obtained by the version script below.

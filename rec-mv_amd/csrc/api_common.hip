@@ -14,3 +14,13 @@ void set_error(const char* fmt, ...) {
 
 extern "C" int recmv_abi_version(void) { return 7; }
 extern "C" const char* recmv_last_error(void) { return recmv::g_err; }
+
+// 1 when EVERY kernel of this library was built without packed-f32 VALU instructions (rec-mv_amd/build.py under
+// RECMV_NO_PACKED_F32=1) — the build the bf16x6 matrix mode needs to be reproducible, see build.py — else 0.  (ABI v7)
+extern "C" int recmv_no_packed_f32(void) {
+#ifdef RECMV_NO_PACKED_F32
+  return 1;
+#else
+  return 0;
+#endif
+}

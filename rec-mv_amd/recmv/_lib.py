@@ -65,6 +65,7 @@ def _declare(lib):
     T5 = C.POINTER(Tensor5)
     sigs = {
         "recmv_abi_version": (C.c_int, []),
+        "recmv_no_packed_f32": (C.c_int, []),
         "recmv_last_error": (C.c_char_p, []),
         "recmv_inv3x3_forward": (C.c_int, [vp, vp, vp, i64, i32, vp]),
         "recmv_inv3x3_backward": (C.c_int, [vp, vp, vp, i64, i32, vp]),
@@ -175,6 +176,11 @@ def lib():
                               f"{ABI_VERSION}: rebuild with `python rec-mv_amd/build.py --force`")
         if os.environ.get("RECMV_GEMM_MODE"):
             l.recmv_set_gemm_mode(int(os.environ["RECMV_GEMM_MODE"]))
+            if int(os.environ["RECMV_GEMM_MODE"]) == 1 and not l.recmv_no_packed_f32():
+                import warnings
+                warnings.warn("RECMV_GEMM_MODE=1 (bf16x6, experimental) with a library that contains packed-f32 instructions: beside this mode's "
+                              "product kernels such instructions were caught computing wrong values (DESIGN.md §9).  Rebuild with "
+                              "RECMV_NO_PACKED_F32=1 python rec-mv_amd/build.py --force")
         if os.environ.get("RECMV_SAMPLER_EXACT"):
             l.recmv_set_sampler_mode(int(os.environ["RECMV_SAMPLER_EXACT"]))
         _lib = l

@@ -624,12 +624,9 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
     ap.add_argument("--gemm-mode", choices=["f32", "bf16x6"], default="f32",
                     help="matrix mode of the timed region: f32 = f32-input MFMA (exact f32 products, default); bf16x6 = "
                          "3-way bf16 operand split, six bf16 MFMA products, f32 accumulate (same parity tolerances)")
-    ap.add_argument("--alt-mode", action="store_true",
-                    help="add a short extra measurement in the other matrix mode (`alt_mode` on the line).  OFF by default since round 5: "
-                         "beside the bf16x6 mode's NT product kernels other kernels of the iteration were caught computing wrong values "
-                         "in lanes 48-63 of a wave (tools/valu_disturb_repro.hip, DESIGN.md §9) — the mode is experimental")
+    ap.add_argument("--alt-mode", action="store_true", help=argparse.SUPPRESS)       # (the alt-mode leg is on by default again)
     ap.add_argument("--no-alt-mode", action="store_true",
-                    help="also skip the serial-order kernel pass (short runs of the tools)")
+                    help="skip the short extra measurement in the other matrix mode (`alt_mode`) and the serial-order kernel pass")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the MFMA kernel launches with HIP events (no roofline object)")
     ap.add_argument("--no-hbm-kernels", action="store_true", help="skip the hbm_kernels block")
@@ -734,7 +731,7 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
     small_launches = prof.small if prof else None
     busy_timed = prof.busy if prof else None
     alt = None
-    if args.alt_mode and not args.no_alt_mode:
+    if not args.no_alt_mode:
         # the same loop in the OTHER matrix mode, a short extra run outside the timed region (not part of `value`)
         other = "bf16x6" if args.gemm_mode == "f32" else "f32"
         L.lib().recmv_set_gemm_mode(mode_id[other])
@@ -759,9 +756,12 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
         alt = dict(gemm_mode=other, steps=n_alt, value=round(n_alt * world / alt_elapsed, 4), unit="iters/s",
                    ms_per_step=round(alt_elapsed / n_alt * 1e3, 3),
                    note="same loop, other matrix mode, short run after the timed region (no re-mesh inside)",
-                   status="experimental: beside the bf16x6 NT product kernels a per-thread kernel of the iteration (def_regu) returned "
-                          "different, wrong values for the same input in a few launches per hundred (lanes 48-63 of a wave; "
-                          "tools/valu_disturb_repro.hip, profiles/r05_race_*.txt) — not a product figure")
+                   status="optional mode.  Round 5 found why its loop parted run to run — packed-f32 instructions come out wrong in lanes "
+                          "48-63 of waves that run beside this mode's NT product kernels; the one kernel whose damage reached the results "
+                          "(the deformation regulariser) is built without them and the loop is identical in 60 of 60 repetitions in both "
+                          "stream configurations; the other kernels of THIS build keep packed instructions "
+                          "(RECMV_NO_PACKED_F32=1 builds all without: library built that way = %s); DESIGN.md §9"
+                          % bool(L.lib().recmv_no_packed_f32()))
     gs_serial = None
     if prof and not args.no_alt_mode:
         # the MFMA kernels once more with the iteration in the reference's serial order (RECMV_SERIAL=1: one stream, no

@@ -74,19 +74,36 @@ def test_project_2d_loss_on_gpu_matches_the_reference_method():
     _report("project_2d_loss on the GPU", p2c.run(cc.load("project2d"), DEV, rtol=1e-5, rtol_grad=1e-4))
 
 
-def test_one_whole_iteration_on_gpu_matches_the_reference():
+import contextlib
+
+
+@contextlib.contextmanager
+def _matrix_mode(mode):
+    """Run a test in the f32-input MFMA mode (0, the product's default) or in the optional bf16x6 mode (1): the same tolerances in
+    both — the mode's six bf16 products per tile step are exact in f32, only the accumulation order differs."""
+    from recmv import _lib as L
+    prev = L.lib().recmv_set_gemm_mode(mode)
+    try:
+        yield
+    finally:
+        L.lib().recmv_set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["f32", "bf16x6"])
+def test_one_whole_iteration_on_gpu_matches_the_reference(mode):
     """OptimGarmentNetwork.forward (:1885-1969) -> backward -> propagateTmpPsGrad (:2159-2313), then a second iteration."""
     import forward_case as fwc
-    with cc.host_draws():
-        _report("whole iteration on the GPU",
+    with cc.host_draws(), _matrix_mode(mode):
+        _report("whole iteration on the GPU (matrix mode %d)" % mode,
                 fwc.run(cc.load("forward"), DEV, rtol=3e-4, rtol_loss=1e-4, rtol_grad=1e-3, rtol_cam=5e-3))
 
 
-def test_one_whole_large_pose_iteration_on_gpu_matches_the_reference():
+@pytest.mark.parametrize("mode", [0, 1], ids=["f32", "bf16x6"])
+def test_one_whole_large_pose_iteration_on_gpu_matches_the_reference(mode):
     """OptimGarmentNetwork_LargePose.forward (OptimGarmentNetwork_Large_Pose.py:242-323) -> backward -> its propagateTmpPsGrad."""
     import forward_case as fwc
-    with cc.host_draws():
-        _report("whole large-pose iteration on the GPU",
+    with cc.host_draws(), _matrix_mode(mode):
+        _report("whole large-pose iteration on the GPU (matrix mode %d)" % mode,
                 fwc.run(cc.load("forward_large"), DEV, rtol=3e-4, rtol_loss=1e-4, rtol_grad=1e-3, rtol_cam=5e-3, large_pose=True,
                         inputs=cc.load("forward")))
 
@@ -133,3 +150,14 @@ def test_trajectory_and_canonical_mesh_chamfer_on_gpu_against_the_references_loo
             out = fwc.run_trajectory(g, cc.load("forward"), DEV)
         rep = fwc.check_trajectory(out, g, other_arithmetic=True)
         print(name, "on the GPU:", rep)
+
+
+def test_short_trajectory_in_the_bf16x6_matrix_mode():
+    """Row (g)'s 14-iteration run (re-mesh at the 10th) in the OPTIONAL bf16x6 matrix mode, same check as in the f32 mode:
+    canonical-mesh Chamfer <= 1e-4 against the reference's loop."""
+    import forward_case as fwc
+    with cc.host_draws(), _matrix_mode(1):
+        g = cc.load("trajectory_short")
+        out = fwc.run_trajectory(g, cc.load("forward"), DEV)
+    rep = fwc.check_trajectory(out, g, other_arithmetic=True)
+    print("trajectory_short on the GPU, bf16x6:", rep)

@@ -166,14 +166,24 @@ def _iteration_result(loop, it):
     return rays, out
 
 
-def test_iteration_is_bit_reproducible():
+@pytest.mark.parametrize("mode", [0, 1], ids=["f32", "bf16x6"])
+def test_iteration_is_bit_reproducible(mode):
     """The four-stream iteration (main, ray pipeline, curve branch, second garment) repeated from one snapshot of the whole state gives
     the same bits every time — the property the frame-sharded replicas rely on (tools/loop_repro_inproc.py counts
-    40-100 repetitions per configuration on the bench scene).  Default (f32) matrix mode."""
+    40-100 repetitions per configuration on the bench scene).  Both matrix modes: the optional bf16x6 mode parted in 8-25 % of the
+    repetitions until round 5 found the instruction (packed f32, wrong in lanes 48-63 beside that mode's product kernels) and built the
+    kernel it hit without it."""
     from recmv import _lib as L
     from recmv.hocon import ConfigFactory
     from recmv.loop import HotLoop
-    assert L.lib().recmv_get_gemm_mode() == 0
+    prev = L.lib().recmv_set_gemm_mode(mode)
+    try:
+        _reproducible_iteration(HotLoop, ConfigFactory)
+    finally:
+        L.lib().recmv_set_gemm_mode(prev)
+
+
+def _reproducible_iteration(HotLoop, ConfigFactory):
     conf = ConfigFactory.parse_file(CONF)
     conf.put('train.sample_pix_num', 256)
     loop = HotLoop(conf, torch.device("cuda:0"), n_frames=12, H=160, W=128,

@@ -384,6 +384,72 @@ __global__ __launch_bounds__(256) void aggressor_loop(float* __restrict__ out, i
   for (int r = 0; r < 16; ++r) sum += acc[r];
   out[blockIdx.x * 256 + tid] = sum;
 }
+// A18 / A19: the K loop above FED FROM GLOBAL MEMORY like the product kernel's (every round: two float4 per thread from a large buffer
+// into registers while the previous tile is multiplied, then into LDS) — bf16 MFMA (A18) or f32 MFMA (A19)
+template <int MF>
+__global__ __launch_bounds__(256) void aggressor_gl(float* __restrict__ out, int rounds, const float* __restrict__ src, long src_floats) {
+  constexpr int LDK = 36;
+  __shared__ __attribute__((aligned(16))) float As[2 * 64 * LDK], Bs[2 * 64 * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31), khalf = (lane >> 5) * 4;
+  const int row = tid >> 3, c4 = tid & 7;            // staging map of gemm_nt_kernel<1, ...>: 64 rows x 8 float4, two per thread
+  long base = ((long)blockIdx.x * 64 * 4096) % (src_floats - 64 * 4096 - 8192);
+  const float* pa = src + base + (long)row * 4096 + c4 * 4;
+  const float* pb = src + ((base + 32 * 4096) % (src_floats - 64 * 4096 - 8192)) + (long)row * 4096 + c4 * 4;
+  float4 ra[2], rb[2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      ra[r] = *reinterpret_cast<const float4*>(pa + (long)r * 32 * 4096 + k0);
+      rb[r] = *reinterpret_cast<const float4*>(pb + (long)r * 32 * 4096 + k0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      *reinterpret_cast<float4*>(As + (buf * 64 + row + 32 * r) * LDK + c4 * 4) = ra[r];
+      *reinterpret_cast<float4*>(Bs + (buf * 64 + row + 32 * r) * LDK + c4 * 4) = rb[r];
+    }
+  };
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < rounds; ++kt) {
+    const int buf = kt & 1;
+    gload(((kt + 1) * 32) & 4095);
+    const float* as = As + (buf * 64 + arow) * LDK + 2 * khalf;
+    const float* bs = Bs + (buf * 64 + brow) * LDK + 2 * khalf;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (MF == 1) {
+        const Pcs pa_ = split8_<0>(*reinterpret_cast<const float4*>(as + ks * 16), *reinterpret_cast<const float4*>(as + ks * 16 + 4));
+        const Pcs pb_ = split8_<0>(*reinterpret_cast<const float4*>(bs + ks * 16), *reinterpret_cast<const float4*>(bs + ks * 16 + 4));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa_.h, pb_.l, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa_.l, pb_.h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa_.m, pb_.m, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa_.h, pb_.m, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa_.m, pb_.h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa_.h, pb_.h, acc, 0, 0, 0);
+      } else {
+        const float4 a0 = *reinterpret_cast<const float4*>(as + ks * 16), b0 = *reinterpret_cast<const float4*>(bs + ks * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
+      }
+    }
+    lstore(buf ^ 1);
+    __syncthreads();
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sum += acc[r];
+  out[blockIdx.x * 256 + tid] = sum;
+}
 typedef void (*Agg)(float*, int);
 
 
@@ -577,6 +643,36 @@ int main(int argc, char** argv) {
       }
       printf("bisect  %-76s %3d of %d launches differ (%ld matrices; lane of the first: %ld)\n", bn[v], bad, iters, nbad, first_lane);
       fflush(stdout);
+    }
+    // ---- a library-free aggressor?  The K loop fed from global memory, against the packed-f32 victim (B1) and the regulariser (V0)
+    {
+      float* aout;
+      CK(hipMalloc(&aout, 2048 * 256 * 4));
+      const long src_floats = (long)M * K;        // the product's own A operand as the source buffer
+      for (int mf = 1; mf <= 2; ++mf)
+        for (int vi = 0; vi < 2; ++vi) {
+          Kern k = vi == 0 ? bk[1] : kerns[0];
+          CK(hipDeviceSynchronize());
+          hipLaunchKernelGGL(k, dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y0, g0);
+          CK(hipStreamSynchronize(main_s));
+          CK(hipMemcpy(hy0.data(), y0, P * 4, hipMemcpyDeviceToHost));
+          CK(hipMemcpy(hg0.data(), g0, P * 36, hipMemcpyDeviceToHost));
+          int bad = 0;
+          for (int it = 0; it < iters; ++it) {
+            for (int i = 0; i < 2; ++i) {
+              if (mf == 1) hipLaunchKernelGGL(aggressor_gl<1>, dim3(1024), dim3(256), 0, side[i], aout + i * 1024 * 256, 400, A, src_floats);
+              else hipLaunchKernelGGL(aggressor_gl<2>, dim3(1024), dim3(256), 0, side[i], aout + i * 1024 * 256, 400, A, src_floats);
+            }
+            hipLaunchKernelGGL(k, dim3((unsigned)((P + kBlk - 1) / kBlk)), dim3(kBlk), 0, main_s, J, P, 1111.f, y, g);
+            CK(hipMemcpyAsync(hy.data(), y, P * 4, hipMemcpyDeviceToHost, main_s));
+            CK(hipMemcpyAsync(hg.data(), g, P * 36, hipMemcpyDeviceToHost, main_s));
+            CK(hipStreamSynchronize(main_s));
+            bad += memcmp(hy.data(), hy0.data(), P * 4) != 0 || memcmp(hg.data(), hg0.data(), P * 36) != 0;
+          }
+          printf("library-free aggressor: K loop fed from global memory, %-9s MFMA, victim %-44s %3d of %d launches differ\n",
+                 mf == 1 ? "bf16" : "f32", vi == 0 ? bn[1] + 0 : names[0], bad, iters);
+          fflush(stdout);
+        }
     }
     return 0;
   }

@@ -1,7 +1,9 @@
 // Stand-alone reproducer (no library, one file): on gfx950 / ROCm 7.2, a kernel made of PACKED-F32 VALU instructions
-// (v_pk_mul_f32 / v_pk_fma_f32) returns wrong values in lanes 48..63 of some waves when it runs beside a kernel whose K loop feeds
-// v_mfma_f32_32x32x16_bf16 from global memory through LDS (the shape of a bf16 GEMM).  The same victim compiled to scalar v_mul_f32 /
-// v_fma_f32 never fails; the same aggressor with v_mfma_f32_32x32x2_f32 never disturbs.
+// (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32) returns wrong values in lanes 48..63 of some waves when it runs beside a kernel whose K
+// loop feeds v_mfma_f32_32x32x16_bf16 from global memory through LDS (the shape of a bf16 GEMM).  The same victim with its FMAs and adds
+// kept scalar (the compiler still pairs the multiplies: 178 v_pk_mul_f32, so the multiply is not the instruction that fails) never
+// fails; the same aggressor with v_mfma_f32_32x32x2_f32 never disturbs.  MI355X, 200 launches: 168 bad, every wrong thread in lanes
+// 48..63 (profiles/r05_race_13_standalone_repro.txt).
 //
 //   hipcc --offload-arch=gfx950 -O3 -o packed_f32_bf16_mfma_repro tools/packed_f32_bf16_mfma_repro.hip && ./packed_f32_bf16_mfma_repro [launches=200]
 //
@@ -228,7 +230,7 @@ int main(int argc, char** argv) {
       }
       printf("aggressor %-33s victim %-34s %3d of %d launches differ from the first; threads by quarter of the wave "
              "[0-15 | 16-31 | 32-47 | 48-63]: %ld %ld %ld %ld\n",
-             bf16 ? "v_mfma_f32_32x32x16_bf16 K loop," : "v_mfma_f32_32x32x2_f32 K loop,", paired ? "packed (v_pk_mul/fma_f32 allowed)," : "scalar (v_mul/v_fma_f32 only),",
+             bf16 ? "v_mfma_f32_32x32x16_bf16 K loop," : "v_mfma_f32_32x32x2_f32 K loop,", paired ? "v_pk_fma/add/mul_f32," : "scalar FMAs/adds (+ v_pk_mul_f32),",
              bad, launches, quarter[0], quarter[1], quarter[2], quarter[3]);
       fflush(stdout);
     }

@@ -266,6 +266,38 @@ def acquire(token):
         torch.cuda.current_stream(device).wait_event(ev)
 
 
+# ---- side streams, optionally confined to a subset of the CUs -------------------------------------------------------------------
+# RECMV_SIDE_CUS=k (0 < k < 8): the loop's side streams (ray pipeline, curve branch, second garment) may only use k of every 8 CUs
+# (hipExtStreamCreateWithCUMask); the main stream's large products keep the whole device.  Same results (a stream's CU set changes
+# where waves run, not what they compute); an A/B knob of tools/, unset by default (measured in DESIGN.md §4).
+_hip = None
+_masked = []
+
+
+def make_stream(device):
+    k = int(os.environ.get("RECMV_SIDE_CUS", "0") or 0)
+    if not (0 < k < 8):
+        return torch.cuda.Stream(device=device)
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    n_cu = torch.cuda.get_device_properties(idx).multi_processor_count
+    words = (n_cu + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for i in range(n_cu):
+        if i % 8 < k:
+            mask[i // 32] |= 1 << (i % 32)
+    h = C.c_void_p()
+    with torch.cuda.device(idx):
+        rc = _hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(words), mask)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    _masked.append(h)
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 # ---- RECMV_POISON=1: a detector for reads of memory nobody has written yet -----------------------------------------------------
 # Every workspace / output buffer the wrappers allocate with torch.empty goes through `scratch()`.  With RECMV_POISON=1 it is filled
 # with a signalling pattern (NaN for floats, 0x7f bytes for raw workspaces) on the allocating stream before the kernels that are

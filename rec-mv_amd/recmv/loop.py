@@ -1009,7 +1009,7 @@ class HotLoop:
         if cuda:
             main = torch.cuda.current_stream(self.device)
             if getattr(self, '_surface_stream', None) is None:
-                self._surface_stream = torch.cuda.Stream(device=self.device)
+                self._surface_stream = _make_stream(self.device)
             side = self._surface_stream
             side.wait_event(self._surface_ready)
         ctx = torch.cuda.stream(side) if cuda else contextlib.nullcontext()
@@ -1394,9 +1394,9 @@ class HotLoop:
             if cuda:
                 main = torch.cuda.current_stream(self.device)
                 if getattr(self, '_surface_stream', None) is None:
-                    self._surface_stream = torch.cuda.Stream(device=self.device)
+                    self._surface_stream = _make_stream(self.device)
                 if getattr(self, '_curve_stream', None) is None:
-                    self._curve_stream = torch.cuda.Stream(device=self.device)
+                    self._curve_stream = _make_stream(self.device)
                 s_ray, s_curve = self._surface_stream, self._curve_stream
                 on = torch.cuda.stream
             else:                                            # the same order on the host: one queue, nothing to wait for
@@ -1816,3 +1816,8 @@ def _apose():
     pose[16] = [0, 0, -45. / 180. * np.pi]
     pose[17] = [0, 0, 45. / 180. * np.pi]
     return pose
+
+
+def _make_stream(device):
+    from . import _lib
+    return _lib.make_stream(device)

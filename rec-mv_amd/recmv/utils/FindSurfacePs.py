@@ -58,7 +58,7 @@ def _streams(device, n):
     key = device.index if device.index is not None else torch.cuda.current_device()
     pool = _side_streams.setdefault(key, [])
     while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=device))
+        pool.append(_make_stream(device))
     return pool[:n]
 
 
@@ -448,3 +448,8 @@ def OptimizeGarmentSurfacePs(cam_pos, rays_list, initTmpPs_list, batch_inds_list
         optimized_init_tmp_ps_list.append(initTmpPs.detach())
         optimized_check_list.append(~unfinished)
     return optimized_init_tmp_ps_list, optimized_check_list
+
+
+def _make_stream(device):
+    from .. import _lib
+    return _lib.make_stream(device)

@@ -35,8 +35,26 @@ def _check(input, grid, interp, pad):
     L.require_cuda(input, "input")
 
 
+# The reference also dispatches its kernels for half (AT_DISPATCH_FLOATING_TYPES_AND_HALF, GridSamplerMineKernel.cu:931,963,1001); nothing
+# in the loop samples in f16.  Here an f16 call runs the f32 kernels on up-cast operands and rounds the results to f16 ONCE: not the
+# reference's per-operation half arithmetic (its intermediate roundings are not reproduced — a result can differ from it by a few f16
+# ulp, on the accurate side), but the same API surface instead of a rejected dtype.
+def _half(*ts):
+    return any(t is not None and t.dtype == torch.float16 for t in ts)
+
+
+def _up(t):
+    return t.float() if t is not None and t.dtype == torch.float16 else t
+
+
+def _down(t):
+    return t.half() if t is not None else None
+
+
 def forward(input, grid, interpolation_mode, padding_mode):
     _check(input, grid, interpolation_mode, padding_mode)
+    if _half(input):
+        return _down(forward(_up(input), _up(grid), interpolation_mode, padding_mode))
     N, C = input.size(0), input.size(1)
     out = torch.empty((N, C, grid.size(1), grid.size(2), grid.size(3)), dtype=input.dtype, device=input.device)
     di, dg, do = L.desc5(input), L.desc5(grid), L.desc5(out)
@@ -49,6 +67,9 @@ def forward(input, grid, interpolation_mode, padding_mode):
 
 def backward(input, grid, grad_output, interpolation_mode, padding_mode, need_grad_input=True):
     _check(input, grid, interpolation_mode, padding_mode)
+    if _half(input):
+        gi, gg = backward(_up(input), _up(grid), _up(grad_output), interpolation_mode, padding_mode, need_grad_input)
+        return _down(gi), _down(gg)
     grad_input = torch.zeros_like(input) if need_grad_input else None
     grad_grid = torch.empty(grid.shape, dtype=grid.dtype, device=grid.device)  # contiguous
     di, dg, dgo = L.desc5(input), L.desc5(grid), L.desc5(grad_output)
@@ -64,6 +85,10 @@ def backward(input, grid, grad_output, interpolation_mode, padding_mode, need_gr
 def dbackward(grad_output_input, grad_output_grid, input, grid, grad_output, interpolation_mode, padding_mode,
               need_grad_input=True):
     _check(input, grid, interpolation_mode, padding_mode)
+    if _half(input):
+        gi, gg, ggo = dbackward(_up(grad_output_input), _up(grad_output_grid), _up(input), _up(grid), _up(grad_output),
+                                interpolation_mode, padding_mode, need_grad_input)
+        return _down(gi), _down(gg), _down(ggo)
     grad_input = torch.zeros_like(input) if need_grad_input else None
     grad_grid = torch.empty(grid.shape, dtype=grid.dtype, device=grid.device)
     ggo = torch.empty(grad_output.shape, dtype=grad_output.dtype, device=grad_output.device)

@@ -716,6 +716,32 @@ def test_singular_values_closed_form():
     torch.testing.assert_close(s.cpu(), ref, rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.gpu
+def test_grid_sampler_accepts_half_like_the_reference_dispatch():
+    """The reference dispatches its sampler kernels for half as well (AT_DISPATCH_FLOATING_TYPES_AND_HALF, MCAcc/cuda/
+    GridSamplerMineKernel.cu:931,963,1001).  Here an f16 call computes in f32 and rounds the results once: forward, backward
+    and double backward return f16 tensors that agree with the f32 path on the same (f16-representable) operands to f16 rounding."""
+    from recmv import GridSamplerMine
+    g = torch.Generator().manual_seed(3)
+    vol = gpu(torch.randn(1, 24, 9, 11, 7, generator=g)).half()
+    grid = gpu((torch.rand(1, 1, 1, 700, 3, generator=g) - 0.5) * 2.2).half()
+    go = gpu(torch.randn(1, 24, 1, 1, 700, generator=g)).half()
+    ggg = gpu(torch.randn(1, 1, 1, 700, 3, generator=g)).half()
+    out_h = GridSamplerMine.forward(vol, grid, 0, 1)
+    out_f = GridSamplerMine.forward(vol.float(), grid.float(), 0, 1)
+    assert out_h.dtype == torch.float16 and torch.equal(out_h, out_f.half())
+    gi_h, gg_h = GridSamplerMine.backward(vol, grid, go, 0, 1)
+    gi_f, gg_f = GridSamplerMine.backward(vol.float(), grid.float(), go.float(), 0, 1)
+    assert gi_h.dtype == gg_h.dtype == torch.float16
+    assert torch.equal(gg_h, gg_f.half()) and torch.equal(gi_h, gi_f.half())
+    r_h = GridSamplerMine.dbackward(None, ggg, vol, grid, go, 0, 1)
+    r_f = GridSamplerMine.dbackward(None, ggg.float(), vol.float(), grid.float(), go.float(), 0, 1)
+    for a, b in zip(r_h, r_f):
+        assert a.dtype == torch.float16 and torch.equal(a, b.half())
+    with pytest.raises(RuntimeError):                      # mixed dtypes are still refused, as in the reference (:31-33)
+        GridSamplerMine.forward(vol, grid.float(), 0, 1)
+
+
 # ------------------------------------------------------------------------------------------ matrix mode bf16x6
 @pytest.fixture
 def bf16x6_mode():

@@ -733,11 +733,16 @@ def test_grid_sampler_accepts_half_like_the_reference_dispatch():
     gi_h, gg_h = GridSamplerMine.backward(vol, grid, go, 0, 1)
     gi_f, gg_f = GridSamplerMine.backward(vol.float(), grid.float(), go.float(), 0, 1)
     assert gi_h.dtype == gg_h.dtype == torch.float16
-    assert torch.equal(gg_h, gg_f.half()) and torch.equal(gi_h, gi_f.half())
+    assert torch.equal(gg_h, gg_f.half())
+    torch.testing.assert_close(gi_h.float(), gi_f, rtol=2e-3, atol=2e-3)      # (atomics scatter, see below)
     r_h = GridSamplerMine.dbackward(None, ggg, vol, grid, go, 0, 1)
     r_f = GridSamplerMine.dbackward(None, ggg.float(), vol.float(), grid.float(), go.float(), 0, 1)
-    for a, b in zip(r_h, r_f):
-        assert a.dtype == torch.float16 and torch.equal(a, b.half())
+    for i, (a, b) in enumerate(zip(r_h, r_f)):
+        assert a.dtype == torch.float16
+        if i == 0:       # grad_input is a scatter with float atomics (as in the reference): two calls differ in the last f32 bits
+            torch.testing.assert_close(a.float(), b, rtol=2e-3, atol=2e-3)
+        else:
+            assert torch.equal(a, b.half())
     with pytest.raises(RuntimeError):                      # mixed dtypes are still refused, as in the reference (:31-33)
         GridSamplerMine.forward(vol, grid.float(), 0, 1)
 

@@ -339,6 +339,7 @@ def run_trajectory(g, inputs, device, iters=None):
         fine = Seg3dLossless(query_func=None, b_min=list(BOX[0]), b_max=list(BOX[1]), resolutions=canon_res,
                              align_corners=False, balance_value=0.0, use_cuda_impl=dev.type == 'cuda', faster=False).to(dev)
         vs, fs = optNet.discretizeSDF(pc.RATIO, fine, 0.)
+        out['canon_verts'] = {tag: v.detach().cpu() for tag, v in zip(('body', 'u', 'b'), vs)}
         for tag, v, f in zip(('body', 'u', 'b'), vs, fs):
             sq, lin = chamfer_vertices(v, g['canon_v_' + tag])
             out['canon_%s' % tag] = dict(chamfer_sq=sq, mean_dist=lin, moved_sq=float(g['canon_moved_' + tag][0]),
@@ -429,6 +430,16 @@ def reference_envelope():
     return dict(np.load(path))
 
 
+def disturbed_envelope():
+    """tests/golden/trajectory_perturbed.npz (make_golden_perturbed.py): canonical-mesh Chamfer distances between the reference's
+    35-iteration run and runs of the SAME reference loop whose matrix products' results carry a relative error of 1 .. 16 f32 ulp."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trajectory_perturbed.npz")
+    if not os.path.isfile(path):
+        return None
+    return dict(np.load(path))
+
+
 def _check_trajectory_device(out, g):
     """The same run on the DEVICE, whose matrix products (f32 MFMA fma chains) round differently from the torch-CPU sgemm the
     reference and the CPU port share: the first iteration differs by 1e-6 on the loss instead of 1e-8, and the map amplifies a
@@ -457,6 +468,7 @@ def _check_trajectory_device(out, g):
         return report
     short = total <= TRAJ_SHORT_ITERS
     env = reference_envelope() if not short else None
+    dis = disturbed_envelope() if not short and 'resolutions' not in g else None
     for tag in ('body', 'u', 'b'):
         c = out['canon_' + tag]
         ref_self = float(g['self_canon_chamfer_' + tag][0])
@@ -467,7 +479,10 @@ def _check_trajectory_device(out, g):
         # about four times the reference's largest pair: a different arithmetic (MFMA fma chains, hardware exp / log / sin) starts
         # 1e-6 away on the loss where a reordered sgemm starts 1e-8 away, and the map multiplies a difference by ~2.5 per iteration —
         # that garment is held to the old bound (a fifth of the distance its surface moved, at most 1e-3) and reported as OUTSIDE the
-        # envelope (`inside_reference_envelope`): the 35-iteration horizon is not claimed.
+        # envelope (`inside_reference_envelope`): the 35-iteration horizon is not claimed.  The explanation was measured on the
+        # reference itself (make_golden_perturbed.py -> trajectory_perturbed.npz): its own loop with a relative error of 6e-8 .. 1e-6
+        # on every product's result ends 1.1e-4 .. 3.0e-4 (upper garment, eight runs) from its undisturbed run — reported below as
+        # `reference_with_disturbed_products_min_median_max` / `inside_disturbed_products_range`, not asserted (a maximum of eight).
         inside = None
         if short:
             bound = 1e-4
@@ -488,6 +503,10 @@ def _check_trajectory_device(out, g):
             iu = d[np.triu_indices(d.shape[0], 1)]
             report['canon_' + tag].update(reference_envelope_min_median_max=[float(iu.min()), float(np.median(iu)), float(iu.max())],
                                           inside_reference_envelope=inside)
+        if dis is not None:           # the reference's loop with rounding-sized errors on its products' results (not asserted: reported)
+            d = dis['canon_chamfer_' + tag]
+            report['canon_' + tag].update(reference_with_disturbed_products_min_median_max=[float(d.min()), float(np.median(d)), float(d.max())],
+                                          inside_disturbed_products_range=bool(c['chamfer_sq'] <= max(float(d.max()), 1e-10)))
     report['remesh_faces_equal'] = out['remesh_faces_equal']
     report['explicit'] = {t: out['explicit_' + t] for t in ('u', 'b')}
     return report

@@ -148,7 +148,7 @@ def mc_extract_timing(device):
     mc_s = tm[len(tm) // 2]
     alg = 4 * 257 ** 3 + 12 * v.shape[0] + 24 * f.shape[0]
     return dict(mc_extract_ms_257=round(ts[len(ts) // 2] * 1e3, 3), mc_only_ms_257=round(mc_s * 1e3, 4),
-                mc_vertices=int(v.shape[0]), mc_faces=int(f.shape[0]),
+                mc_vertices_257=int(v.shape[0]), mc_faces_257=int(f.shape[0]),
                 mc_only_roofline=dict(bound="hbm", achieved=round(alg / mc_s / 1e9, 1), peak=HBM_PEAK / 1e9,
                                       unit="GB/s", frac=round(alg / mc_s / HBM_PEAK, 4)))
 
@@ -156,6 +156,88 @@ def mc_extract_timing(device):
 CPU_BASELINE_CORES = 32      # cap: the GPU boxes expose 256 host threads; the loop's small ops do not scale past a socket slice
 CPU_BASELINE_LIMIT_S = 240   # hard wall-clock bound of the whole leg (it runs in a child process)
 HOTLOOP_KW = dict(n_frames=64, H=512, W=512)
+
+
+SCENE_FILE = REPO / "configs" / "synthetic" / "bench_scene_v1.pt"
+SCENE_PRIME_ITERS = 16
+_SCENE_DATASET = ("poses", "trans", "d_cond", "rendcond", "focal", "pp", "T")
+
+
+def _scene_tensors(loop):
+    """name -> tensor of everything the optimisation moves: the three SDF nets, the offset MLP, the colour net, the curve parameters
+    and the per-frame / camera tensors.  (Skinning volume, images, masks, 2-D feature lines: generated from the seed on the host.)"""
+    out = {}
+    for k, v in loop.state_dict().items():
+        if k.startswith(("engine.", "deformer.defs.1.")) or k in loop._BUFFERS:
+            continue
+        out["model." + k] = v
+    for k in _SCENE_DATASET:
+        out["dataset." + k] = getattr(loop.dataset, k)
+    return out
+
+
+def save_scene(loop, path, it, note=""):
+    """Freeze the state of the synthetic optimisation as the benchmark's scene (tools/make_bench_scene.py): matrices of >= 2^14
+    elements as f16 (the file DEFINES the scene; nothing has to match the run that produced it), the rest f32."""
+    t = {}
+    for k, v in _scene_tensors(loop).items():
+        v = v.detach().cpu()
+        t[k] = v.half() if (v.is_floating_point() and v.numel() >= (1 << 14)) else v.clone()
+    # Adam's second moments (an average over the WHOLE run: 1 / (1 - beta2) = 1000 iterations of memory — what keeps the step sizes of
+    # a settled optimisation; sixteen priming iterations cannot rebuild it) as bf16, in the optimiser's parameter order
+    params = [q for g in loop.optimizer.param_groups for q in g['params']]
+    adam_v = [loop.optimizer.state[q]['exp_avg_sq'].detach().cpu().bfloat16() if q in loop.optimizer.state else None for q in params]
+    steps = [float(loop.optimizer.state[q]['step']) for q in params if q in loop.optimizer.state]
+    torch.save(dict(version=1, it=int(it), opt_times=float(loop.opt_times), note=note, tensors=t, adam_v=adam_v,
+                    adam_step=max(steps) if steps else 0.0), path)
+
+
+def load_scene(loop, path, allreduce=None, prime_iters=SCENE_PRIME_ITERS):
+    """Put the loop into the frozen benchmark scene — the timed workload must not depend on the code under test (round-5 review):
+
+      1. the parameters, per-frame tensors and curve parameters of the scene file replace the seeded initial ones;
+      2. the next step re-meshes (the explicit meshes are ALWAYS the marching-cubes extraction of the file's SDF nets: vertex counts
+         are a function of the file, up to a voxel whose sign sits within rounding of zero);
+      3. Adam's second moments come from the file (bf16); `prime_iters` iterations fill the short-memory moments (Adam's first moments
+         on the shared tensors, SGD momentum on the explicit vertices, AdamW on the curves) with every tensor they moved put back after
+         each step: sums of gradients AT the file's state over `prime_iters` different frame batches — no feedback from the code under test into the state beyond
+         the rounding of one gradient evaluation (a settle phase of N real steps amplifies that rounding chaotically: the
+         round-5 scene moved by 4 % of its work between commits that changed no kernel).
+    Returns the iteration counter the timed run continues from."""
+    st = torch.load(path, map_location="cpu")
+    if st.get("version") != 1:
+        raise SystemExit("bench scene %s: unknown version %r" % (path, st.get("version")))
+    mine = _scene_tensors(loop)
+    missing = sorted(set(mine) - set(st["tensors"]))
+    extra = sorted(set(st["tensors"]) - set(mine))
+    if missing or extra:
+        raise SystemExit("bench scene %s does not describe this loop: missing %s, unexpected %s" % (path, missing[:4], extra[:4]))
+    with torch.no_grad():
+        for k, dst in mine.items():
+            dst.copy_(st["tensors"][k].to(dst.dtype))
+    loop.opt_times = float(st["opt_times"])
+    it0 = int(st["it"])
+    params = [q for g in loop.optimizer.param_groups for q in g['params']]
+    if len(params) != len(st["adam_v"]) or any(v is not None and v.shape != q.shape for q, v in zip(params, st["adam_v"])):
+        raise SystemExit("bench scene %s: its Adam moments do not match this loop's optimiser" % path)
+    for q, v in zip(params, st["adam_v"]):
+        if v is not None:                                   # (first moments: from the priming iterations below)
+            loop.optimizer.state[q] = {'step': torch.tensor(float(st["adam_step"])), 'exp_avg': torch.zeros_like(q),
+                                       'exp_avg_sq': v.to(device=q.device, dtype=q.dtype)}
+    ratio = {'sdfRatio': 1., 'deformerRatio': loop.opt_times / 2500. + 0.5, 'renderRatio': 1.}
+    loop.marching_cube_update(ratio)                        # 2. (what forward() does when a re-mesh is due, loop.py)
+    loop.forward_time = 1
+    verts0 = [v.detach().clone() for v in loop.garment_vs]
+    for k in range(prime_iters):                            # 3.
+        loop.step(it0 + 1 + k, allreduce)                   # (frame batches it0+1 ..: the timed run starts at it0 + 1 again)
+        with torch.no_grad():
+            for name, dst in mine.items():
+                dst.copy_(st["tensors"][name].to(dst.dtype))
+            for v, v0 in zip(loop.garment_vs, verts0):
+                v.copy_(v0)
+        loop.opt_times = float(st["opt_times"])
+    loop.forward_time = 1                                   # the state right after a re-mesh
+    return it0 + 1
 
 
 def export_state(loop, path, frame_ids, it):
@@ -291,15 +373,12 @@ def hbm_kernel_block(loop, device):
     out = []
 
     def add(name, nbytes, fn, survey_bytes=None):
+        # (`survey_bytes`: SURVEY.md §8(d)'s sampler formula adds the touched part of the grid, min(4 C D H W, 32 C P) — corner records
+        # the L2 serves when neighbouring points share them, not HBM work: a fraction computed from it exceeds 1 by construction and
+        # is no longer reported.  `frac` counts what must cross HBM per point: coordinates in, result out.)
         sec, how = _graph_time(fn)
         out.append(dict(kernel=name, us=round(sec * 1e6, 2), alg_bytes=int(nbytes),
                         achieved_gbs=round(nbytes / sec / 1e9, 1), frac=round(nbytes / sec / HBM_PEAK, 4), timing=how))
-        if survey_bytes is not None:
-            # SURVEY.md §8(d)'s own formula for the sampler adds the touched part of the grid, min(4 C D H W, 32 C P): it counts the
-            # corner records a point gathers, which the L2 serves when neighbouring points share them — the fraction can exceed 1
-            # there; `frac` above counts only what must cross HBM per point (coordinates in, result out)
-            out[-1]["alg_bytes_survey_8d"] = int(survey_bytes)
-            out[-1]["frac_survey_8d"] = round(survey_bytes / sec / HBM_PEAK, 4)
 
     sk = loop.deformer.defs[1]
     vol = sk.ws                                                          # [1,24,D,H,W] channels-last
@@ -614,19 +693,17 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                          "iteration (OptimGarmentNetwork.py:1932, :972); ON by default")
     ap.add_argument("--curves", dest="curves", action="store_true", help=argparse.SUPPRESS)
     ap.set_defaults(curves=True)
-    ap.add_argument("--settle-iters", type=int, default=240,
-                    help="untimed iterations run once after building the loop, before the warm-up: state "
-                         "preparation that takes the synthetic optimisation out of Adam's start-up transient, in "
-                         "which the SDF moves away from the explicit mesh faster than the 20-step root finder can "
-                         "follow and almost no ray reaches the render phases (DESIGN.md §7)")
+    ap.add_argument("--scene", default=str(SCENE_FILE),
+                    help="the frozen benchmark scene (load_scene): parameters of a synthetic optimisation 240 iterations in, from a "
+                         "file, so that the timed workload does not depend on the code under test; 'none' = the seeded initial state")
+    ap.add_argument("--settle-iters", type=int, default=0,
+                    help="extra untimed iterations before the warm-up (0 with the frozen scene; tools/make_bench_scene.py runs 240 "
+                         "from the seeded state to produce the scene file: past Adam's start-up transient, in which the SDF "
+                         "moves away from the explicit mesh faster than the 20-step root finder can follow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mc", action="store_true")
-    ap.add_argument("--gemm-mode", choices=["f32", "bf16x6"], default="f32",
-                    help="matrix mode of the timed region: f32 = f32-input MFMA (exact f32 products, default); bf16x6 = "
-                         "3-way bf16 operand split, six bf16 MFMA products, f32 accumulate (same parity tolerances)")
-    ap.add_argument("--alt-mode", action="store_true", help=argparse.SUPPRESS)       # (the alt-mode leg is on by default again)
-    ap.add_argument("--no-alt-mode", action="store_true",
-                    help="skip the short extra measurement in the other matrix mode (`alt_mode`) and the serial-order kernel pass")
+    ap.add_argument("--no-serial-pass", "--no-alt-mode", dest="no_alt_mode", action="store_true",
+                    help="skip the serial-order kernel pass (the MFMA kernels alone on the device: `frac_kernel_only`)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket the MFMA kernel launches with HIP events (no roofline object)")
     ap.add_argument("--no-hbm-kernels", action="store_true", help="skip the hbm_kernels block")
@@ -677,9 +754,20 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
 
     log("loop built")
     from recmv import _lib as L
-    mode_id = {"f32": 0, "bf16x6": 1}
-    L.lib().recmv_set_gemm_mode(mode_id[args.gemm_mode])
     it = 0
+    scene = None
+    if not on_gpu and args.scene == str(SCENE_FILE):
+        args.scene = "none"                  # (the CPU port of the tests runs a cut-down scene from its seeded state)
+    if args.scene != "none":
+        if not Path(args.scene).is_file():
+            raise SystemExit("bench scene %s not found (tools/make_bench_scene.py writes it; --scene none runs from the seeded "
+                             "initial state)" % args.scene)
+        it = load_scene(loop, args.scene, allreduce)
+        sync()
+        scene = dict(file=str(Path(args.scene).resolve().relative_to(REPO)) if str(Path(args.scene).resolve()).startswith(str(REPO))
+                     else args.scene, prime_iters=SCENE_PRIME_ITERS, first_iteration=it)
+        log("frozen scene loaded: %s, MC vertices %s" % (scene["file"], [int(v.shape[0]) for v in loop.garment_vs]))
+    torch.manual_seed(20261001 + rank)       # the draws of the warm-up and the timed region: one fixed sequence per rank
     for _ in range(args.settle_iters):
         loop.step(it, allreduce)
         it += 1
@@ -730,38 +818,6 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
     gs = prof.end() if prof else {}
     small_launches = prof.small if prof else None
     busy_timed = prof.busy if prof else None
-    alt = None
-    if not args.no_alt_mode:
-        # the same loop in the OTHER matrix mode, a short extra run outside the timed region (not part of `value`)
-        other = "bf16x6" if args.gemm_mode == "f32" else "f32"
-        L.lib().recmv_set_gemm_mode(mode_id[other])
-        n_alt = max(2, min(10, args.steps))
-        for _ in range(1):
-            loop.step(it, allreduce)
-            it += 1
-        rdist.barrier()
-        sync()
-        ta = time.perf_counter()
-        for _ in range(n_alt):
-            loop.step(it, allreduce)
-            it += 1
-        sync()
-        rdist.barrier()
-        alt_elapsed = time.perf_counter() - ta
-        L.lib().recmv_set_gemm_mode(mode_id[args.gemm_mode])
-        if world > 1:
-            ta_t = torch.tensor([alt_elapsed], device=device, dtype=torch.float64)
-            tdist.all_reduce(ta_t, op=tdist.ReduceOp.MAX)
-            alt_elapsed = float(ta_t[0])
-        alt = dict(gemm_mode=other, steps=n_alt, value=round(n_alt * world / alt_elapsed, 4), unit="iters/s",
-                   ms_per_step=round(alt_elapsed / n_alt * 1e3, 3),
-                   note="same loop, other matrix mode, short run after the timed region (no re-mesh inside)",
-                   status="optional mode.  Round 5 found why its loop parted run to run — packed-f32 instructions come out wrong in lanes "
-                          "48-63 of waves that run beside this mode's NT product kernels; the one kernel whose damage reached the results "
-                          "(the deformation regulariser) is built without them and the loop is identical in 60 of 60 repetitions in both "
-                          "stream configurations; the other kernels of THIS build keep packed instructions "
-                          "(RECMV_NO_PACKED_F32=1 builds all without: library built that way = %s); DESIGN.md §9"
-                          % bool(L.lib().recmv_no_packed_f32()))
     gs_serial = None
     if prof and not args.no_alt_mode:
         # the MFMA kernels once more with the iteration in the reference's serial order (RECMV_SERIAL=1: one stream, no
@@ -829,9 +885,7 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "gemm_mode": args.gemm_mode + (" (f32-input MFMA: exact f32 products)" if args.gemm_mode == "f32" else
-                                           " (f32 operands split into 3 bf16 pieces, 6 bf16 MFMA products, f32 "
-                                           "accumulate; same parity tolerances as f32)"),
+            "gemm_mode": "f32 (f32-input MFMA: exact f32 products)",
             "data": "synthetic",
             "rays_per_sec": round(rays / elapsed, 1),
             "rays_converged_fraction": round(converged / max(rays_local, 1), 4),
@@ -860,16 +914,28 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                 "surface_pixels_last_iter": loop.info.get('surface_pixels'),
             },
         }
+        line["scene"] = scene or {"file": None, "note": "seeded initial state + %d settle iterations of this build" % args.settle_iters}
+        line["mc_vertices"] = [int(v.shape[0]) for v in loop.garment_vs]
+        line["rays_per_iter"] = round(rays_local / max(args.steps, 1), 1)
+        line["rays_converged_per_iter"] = round(converged / max(args.steps, 1), 1)
+        line["matrix_tflop_per_step"] = None
         if gs:
+            # every MFMA launch of the timed region with its algorithmic FLOP, counted inside the library (bracketed or not)
+            line["matrix_tflop_per_step"] = round((sum(v["flops"] for v in gs.values())
+                                                   + sum(v["gflop"] * 1e9 for v in (small_launches or {}).values()))
+                                                  / args.steps / 1e12, 5)
             dom = max(gs, key=lambda k: gs[k]["seconds"])
             g = gs[dom]
             ach = g["flops"] / g["seconds"]
-            tr = pmc_traffic(dom + (" bf16x6" if args.gemm_mode == "bf16x6" else ""))
+            tr = pmc_traffic(dom)
             what = ("weight-gradient product dW = dZ^T X, deterministic split-K, its reduction pass not included" if "gemm_tn" in dom
                     else "MFMA layer: GEMM + bias + activation epilogue")
-            line["roofline"] = {"kernel": "recmv::" + dom + " (" + what + "; matrix mode " + args.gemm_mode + ")",
+            line["roofline"] = {"kernel": "recmv::" + dom + " (" + what + ")",
                                 "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": MFMA_F32_PEAK / 1e12,
-                                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), "traffic": tr.get("traffic_bytes_per_launch") if tr else None,
+                                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4),
+                                # HBM bytes per launch over the SAME launch subset as `alg_bytes` / `achieved` (the bracketed launches of
+                                # >= 4 GFLOP); the mean over all launches of the symbol, small ones included, is in traffic_detail
+                                "traffic": ((tr or {}).get("large_launches") or {}).get("traffic_bytes_per_launch"),
                                 "traffic_source": tr.get("traffic_source") if tr else None,
                                 "traffic_detail": tr,
                                 "launches": g["launches"], "avg_launch_us": round(g["avg_us"], 2),
@@ -955,8 +1021,6 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                     world * 1e3 / (plain_ms + extra / period), 4),
                 "note": "GPU time between HIP events recorded at the step boundaries (rank 0); `value` has %d re-mesh(es) "
                         "in %d steps, the reference's cadence is 1 in %d" % (len(with_r), args.steps, period)}
-        if alt:
-            line["alt_mode"] = alt
         log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
         if getattr(loop, "phase_ms", None):
             log("phase ms (RECMV_TIMING=1, timed steps only): " + json.dumps({k: round(v, 1) for k, v in loop.phase_ms.items()}))

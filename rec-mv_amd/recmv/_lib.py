@@ -275,8 +275,14 @@ _masked = []
 
 
 def make_stream(device):
+    """A side stream of the loop (ray pipeline, curve branch, second garment's render terms): chains of short dependent launches
+    that run beside the main stream's large products.  High priority by default (RECMV_SIDE_PRIORITY=0: normal): a workgroup slot
+    that frees up goes to the waiting short kernel first, so the latency-bound chains are not stretched by the throughput-bound
+    products they share the CUs with (profiles/r06_stream_priority_ab.txt)."""
     k = int(os.environ.get("RECMV_SIDE_CUS", "0") or 0)
     if not (0 < k < 8):
+        if os.environ.get("RECMV_SIDE_PRIORITY", "1") != "0":
+            return torch.cuda.Stream(device=device, priority=-1)
         return torch.cuda.Stream(device=device)
     global _hip
     if _hip is None:

@@ -1,6 +1,8 @@
 """Surface-point finder and ray/surface root finder (utils/FindSurfacePs.py of the reference).
 
   FindSurfacePs             :7-60     pixels whose first valid face has all barycentrics > 0
+  OptimizeSurfacePs         :145-207  the same iteration for one SDF net and any deformer (base-class loop)
+  OptimizeGarmentSurfaceSinlge :210-272  ... for one garment net with its offset slot (visualisation / evaluation paths)
   OptimizeGarmentSurfacePs  :273-353  find canonical p with |SDF(p)| < dthreshold whose deformed image lies on
                                       the pixel's ray (angle < athreshold degrees), <= `times` steps of
                                       p <- p - E * gradE / |gradE|^2,  E = w1*|f(p)| + w2*|(d-c) x v| / |d-c|
@@ -14,7 +16,7 @@ import os
 import numpy as np
 import torch
 
-__all__ = ["FindSurfacePs", "OptimizeGarmentSurfacePs", "prepare_root_finder"]
+__all__ = ["FindSurfacePs", "OptimizeGarmentSurfacePs", "OptimizeGarmentSurfaceSinlge", "OptimizeSurfacePs", "prepare_root_finder"]
 
 
 def FindSurfacePs(TmpVs, TmpFaces, frags):
@@ -414,40 +416,81 @@ def OptimizeGarmentSurfacePs(cam_pos, rays_list, initTmpPs_list, batch_inds_list
     optimized_check_list = []
     for garment_idx, (initTmpPs, batch_inds, defconds, rays, garment_name) in enumerate(
             zip(initTmpPs_list, batch_inds_list, defconds_list[0], rays_list, garment_names)):
-        tmpSdf = tmpSdf_nets[garment_idx]
-        with torch.no_grad():
-            check1 = tmpSdf(initTmpPs, ratio).view(-1).abs() < dthreshold
-            direct = deformer(initTmpPs, [defconds, smpl_conds], batch_inds, ratio=ratio,
-                              offset_type=garment_name) - cam_pos.view(1, 3)
-            check2 = _ray_angle_deg(direct, rays) < athreshold
-            unfinished = ~(check1 * check2)
-        for ind in range(times):
-            active = unfinished.nonzero(as_tuple=True)[0]
-            if active.numel() == 0:
-                break
-            curPs = initTmpPs[active].detach().clone()
-            curPs.requires_grad_(True)
-            loss1 = (tmpSdf(curPs, ratio).abs()).view(-1)
-            defPs = deformer(curPs, [defconds, smpl_conds], batch_inds[active], ratio=ratio,
-                             offset_type=garment_name)
-            direct = defPs - cam_pos.view(1, 3)
-            up = torch.linalg.cross(direct, rays[active], dim=1)
-            loss2 = (up.norm(dim=1) / direct.norm(dim=1)).abs()
-            loss = w1 * loss1 + w2 * loss2
-            grad = torch.autograd.grad(loss.sum(), curPs, retain_graph=False, create_graph=False,
-                                       only_inputs=True)[0]
-            t = -loss / (grad * grad).sum(1)
-            curPs = (curPs + t.view(-1, 1) * grad).detach()
-            initTmpPs[active] = curPs
-            with torch.no_grad():
-                check1 = tmpSdf(curPs, ratio).view(-1).abs() < dthreshold
-                direct = deformer(curPs, [defconds, smpl_conds], batch_inds[active], ratio=ratio,
-                                  offset_type=garment_name) - cam_pos.view(1, 3)
-                check2 = _ray_angle_deg(direct, rays[active]) < athreshold
-                unfinished[active[check1 * check2]] = False
-        optimized_init_tmp_ps_list.append(initTmpPs.detach())
-        optimized_check_list.append(~unfinished)
+        pts, ok = _optimize_generic(cam_pos, rays, initTmpPs, batch_inds, tmpSdf_nets[garment_idx], ratio,
+                                    lambda p, b, dc=defconds, n=garment_name: deformer(p, [dc, smpl_conds], b, ratio=ratio, offset_type=n),
+                                    dthreshold, athreshold, w1, w2, times)
+        optimized_init_tmp_ps_list.append(pts)
+        optimized_check_list.append(ok)
     return optimized_init_tmp_ps_list, optimized_check_list
+
+
+def _optimize_generic(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deform, dthreshold, athreshold, w1, w2, times):
+    """The iteration of utils/FindSurfacePs.py:145-207 / :210-272 / :273-353 on autograd, for any deformer: `deform(points, frame
+    indices)` -> deformed points.  `initTmpPs` is updated in place like the reference's (`initTmpPs[unfinished] = curPs`)."""
+    with torch.no_grad():
+        check1 = tmpSdf(initTmpPs, ratio).view(-1).abs() < dthreshold
+        direct = deform(initTmpPs, batch_inds) - cam_pos.view(1, 3)
+        check2 = _ray_angle_deg(direct, rays) < athreshold
+        unfinished = ~(check1 * check2)
+    for ind in range(times):
+        active = unfinished.nonzero(as_tuple=True)[0]
+        if active.numel() == 0:
+            break
+        curPs = initTmpPs[active].detach().clone()
+        curPs.requires_grad_(True)
+        loss1 = (tmpSdf(curPs, ratio).abs()).view(-1)
+        defPs = deform(curPs, batch_inds[active])
+        direct = defPs - cam_pos.view(1, 3)
+        up = torch.linalg.cross(direct, rays[active], dim=1)
+        loss2 = (up.norm(dim=1) / direct.norm(dim=1)).abs()
+        loss = w1 * loss1 + w2 * loss2
+        grad = torch.autograd.grad(loss.sum(), curPs, retain_graph=False, create_graph=False,
+                                   only_inputs=True)[0]
+        t = -loss / (grad * grad).sum(1)
+        curPs = (curPs + t.view(-1, 1) * grad).detach()
+        initTmpPs[active] = curPs
+        with torch.no_grad():
+            check1 = tmpSdf(curPs, ratio).view(-1).abs() < dthreshold
+            direct = deform(curPs, batch_inds[active]) - cam_pos.view(1, 3)
+            check2 = _ray_angle_deg(direct, rays[active]) < athreshold
+            unfinished[active[check1 * check2]] = False
+    return initTmpPs.detach(), ~unfinished
+
+
+def _is_garment_deformer(deformer, defconds, initTmpPs, tmpSdf):
+    """The graph-free HIP passes serve a CompositeDeformer (offset MLP + skinner) with conds [code table, [poses, trans]]."""
+    return (initTmpPs.is_cuda and hasattr(deformer, 'ray_energy_and_vjp') and hasattr(tmpSdf, 'chain')
+            and isinstance(defconds, (list, tuple)) and len(defconds) == 2 and torch.is_tensor(defconds[0])
+            and isinstance(defconds[1], (list, tuple)))
+
+
+def OptimizeGarmentSurfaceSinlge(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds, dthreshold=5.e-5,
+                                 athreshold=0.02, w1=3.05, w2=1., times=5, offset_type=None):
+    """utils/FindSurfacePs.py:210-272 (name as the reference spells it): the root finder for ONE garment net — the same iteration as
+    OptimizeGarmentSurfacePs on one (rays, start points, net, code table) with `offset_type` naming the garment's offset slot.
+    The reference's callers (the visualisation / evaluation paths, OptimGarmentNetwork.py:2109, :2837, :3187, :3282) stop at
+    |f| < 1e-4 after at most 30 steps.  Returns (points, converged); on the device this is the loop's solver (csrc kernels)."""
+    if _is_garment_deformer(deformer, defconds, initTmpPs, tmpSdf):
+        outs, oks = _optimize_explicit_all(cam_pos, [rays], [initTmpPs], [batch_inds], [tmpSdf], ratio, deformer, [defconds[0]],
+                                           defconds[1], [offset_type], dthreshold, athreshold, w1, w2, times)
+        return outs[0].detach(), oks[0]
+    return _optimize_generic(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio,
+                             lambda p, b: deformer(p, defconds, b, ratio=ratio, offset_type=offset_type),
+                             dthreshold, athreshold, w1, w2, times)
+
+
+def OptimizeSurfacePs(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio, deformer, defconds, dthreshold=5.e-5, athreshold=0.02,
+                      w1=3.05, w2=1., times=5):
+    """utils/FindSurfacePs.py:145-207: the base-class loop's root finder (OptimNetwork.py:523: times=10; :268, :328: 1e-4 / 30) —
+    one SDF net, any deformer, NO `offset_type` handed on (with the garment deformer the reference's MLPTranslator raises KeyError
+    on that, model/Deformer.py:177; here its offset slot is `None`)."""
+    if _is_garment_deformer(deformer, defconds, initTmpPs, tmpSdf):
+        outs, oks = _optimize_explicit_all(cam_pos, [rays], [initTmpPs], [batch_inds], [tmpSdf], ratio, deformer, [defconds[0]],
+                                           defconds[1], [None], dthreshold, athreshold, w1, w2, times)
+        return outs[0].detach(), oks[0]
+    return _optimize_generic(cam_pos, rays, initTmpPs, batch_inds, tmpSdf, ratio,
+                             lambda p, b: deformer(p, defconds, b, ratio=ratio),
+                             dthreshold, athreshold, w1, w2, times)
 
 
 def _make_stream(device):

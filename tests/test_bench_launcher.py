@@ -11,7 +11,7 @@ import sys
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
-SMALL = ["--steps", "2", "--warmup", "1", "--settle-iters", "0", "--no-mc", "--no-hbm-kernels", "--no-cpu-baseline", "--no-config2",
+SMALL = ["--steps", "2", "--warmup", "1", "--settle-iters", "0", "--scene", "none", "--no-mc", "--no-hbm-kernels", "--no-cpu-baseline", "--no-config2",
          "--no-alt-mode", "--no-kernel-events", "--no-curves"]
 
 

@@ -121,6 +121,44 @@ def test_find_surface_ps_matches_the_reference_function():
     assert g["batch"].numel() > 1000 and g["batch3"].numel() > 100
 
 
+def test_single_net_root_finders_match_the_reference_functions():
+    """utils/FindSurfacePs.py:145-207 `OptimizeSurfacePs` and :210-272 `OptimizeGarmentSurfaceSinlge` run for real
+    (tests/golden/make_golden_rootfind_single.py) against the same names here, on the CPU port: one step to rounding, and the whole
+    iteration with the reference's call-site settings (1e-4 / 30 steps; 5e-5 / 10 steps) — the same rays converge to the same points."""
+    from oracle import cpu_port
+    from recmv.model import CompositeDeformer, LBSkinner, MLPTranslator, getTmpSdf
+    from recmv.utils import OptimizeGarmentSurfaceSinlge, OptimizeSurfacePs
+    g, gt, gl = load("rootfind"), load("translator"), load("lbs")
+    gs = {k: torch.from_numpy(v) for k, v in np.load(GOLD / "rootfind_single.npz").items() if v.dtype.kind != "U"}
+    ratio = {"sdfRatio": 0.8, "deformerRatio": 0.7, "renderRatio": 1.0}
+    cpu_port.install()
+    try:
+        sdf, tr, sk = cs.build_sdf(getTmpSdf), cs.build_translator(MLPTranslator), cs.build_skinner(LBSkinner)
+        comp = CompositeDeformer([tr, sk])
+        conds = [gt["conds"], [gl["poses"], gl["trans"]]]
+        for tag, times in (("single1", 1), ("single", 30)):
+            p, ok = OptimizeGarmentSurfaceSinlge(g["cam_pos"], g["rays"], g["start"].clone(), g["binds"], sdf, ratio, comp, conds,
+                                                 dthreshold=1.e-4, athreshold=0.02, w1=3.05, w2=1., times=times, offset_type="upper")
+            assert (ok == gs[tag + "_ok"]).float().mean() > (0.999 if times == 1 else 0.95), tag
+            both = ok & gs[tag + "_ok"]
+            assert both.sum() >= 15 and (p - gs[tag + "_p"])[both].abs().max() < (2e-6 if times == 1 else 2e-4), tag
+        assert gs["single_ok"].sum() > 80
+        for tag, times in (("base1", 1), ("base", 10)):
+            p, ok = OptimizeSurfacePs(g["cam_pos"], gs["rays_lbs"], g["start"].clone(), g["binds"], sdf, ratio, sk,
+                                      [gl["poses"], gl["trans"]], dthreshold=5.e-5, athreshold=0.02, w1=3.05, w2=1., times=times)
+            assert (ok == gs[tag + "_ok"]).float().mean() > 0.98, tag
+            both = ok & gs[tag + "_ok"]
+            assert both.sum() >= 10 and (p - gs[tag + "_p"])[both].abs().max() < 2e-5, tag
+    finally:
+        cpu_port.uninstall()
+    # the names resolve through the reference's module paths as well (recmv.namespace)
+    import importlib
+    F = importlib.import_module("recmv.utils.FindSurfacePs")
+    assert {"OptimizeSurfacePs", "OptimizeGarmentSurfaceSinlge", "OptimizeGarmentSurfacePs", "FindSurfacePs"} <= set(F.__all__)
+    import recmv.utils as U
+    assert U.OptimizeSurfacePs is F.OptimizeSurfacePs and U.OptimizeGarmentSurfaceSinlge is F.OptimizeGarmentSurfaceSinlge
+
+
 def test_oracle_rasteriser_reproduces_the_fixture_fragments(oracle):
     g = load("findsurface")
     F = g["faces"].shape[0]

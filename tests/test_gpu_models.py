@@ -211,6 +211,43 @@ def test_root_finder(nets):
     assert err.max().item() < 2e-4, err.max().item()
 
 
+def test_single_net_root_finders(nets):
+    """utils/FindSurfacePs.py:210-272 `OptimizeGarmentSurfaceSinlge` (on the loop's HIP solver: one garment net + its offset slot) and
+    :145-207 `OptimizeSurfacePs` (any deformer: here the skinner alone, the autograd form on the HIP kernels) against the reference
+    functions' own outputs (tests/golden/make_golden_rootfind_single.py), with the reference's call-site settings."""
+    from recmv.utils import OptimizeGarmentSurfaceSinlge, OptimizeSurfacePs
+    g, gt, gl = load("rootfind"), load("translator"), load("lbs")
+    gs = {k: torch.from_numpy(v) for k, v in np.load(GOLD / "rootfind_single.npz").items() if v.dtype.kind != "U"}
+    conds = [gt["conds"].to(DEV), [gl["poses"].to(DEV), gl["trans"].to(DEV)]]
+    cam, rays, start, binds = (g[k].to(DEV) for k in ("cam_pos", "rays", "start", "binds"))
+    for tag, times in (("single1", 1), ("single", 30)):
+        p, ok = OptimizeGarmentSurfaceSinlge(cam, rays, start.clone(), binds, nets["sdf"], RATIO, nets["comp"], conds,
+                                             dthreshold=1.e-4, athreshold=0.02, w1=3.05, w2=1., times=times, offset_type="upper")
+        ref_p, ref_ok = gs[tag + "_p"].to(DEV), gs[tag + "_ok"].to(DEV)
+        if times == 1:
+            moved = (ref_p - start).norm(dim=1)
+            assert ((p - ref_p).norm(dim=1) <= 2e-2 * moved + 2e-6).all()
+            assert (ok == ref_ok).float().mean() > 0.98
+        else:
+            assert ref_ok.sum() > 80 and (ok == ref_ok).float().mean().item() > 0.9
+            with torch.no_grad():
+                assert (nets["sdf"](p[ok], RATIO).view(-1).abs() < 1.e-4).all()
+            both = ok & ref_ok
+            assert both.sum() >= 40 and (p - ref_p)[both].norm(dim=1).max().item() < 4e-4
+    rays_lbs = gs["rays_lbs"].to(DEV)
+    for tag, times in (("base1", 1), ("base", 10)):
+        p, ok = OptimizeSurfacePs(cam, rays_lbs, start.clone(), binds, nets["sdf"], RATIO, nets["sk"], conds[1], dthreshold=5.e-5,
+                                  athreshold=0.02, w1=3.05, w2=1., times=times)
+        ref_p, ref_ok = gs[tag + "_p"].to(DEV), gs[tag + "_ok"].to(DEV)
+        assert (ok == ref_ok).float().mean().item() > 0.95, tag
+        both = ok & ref_ok
+        assert both.sum() >= 8 and (p - ref_p)[both].norm(dim=1).max().item() < 2e-4, tag
+    # with the garment deformer OptimizeSurfacePs runs the loop's solver too (offset slot None; the reference raises KeyError there)
+    p, ok = OptimizeSurfacePs(cam, rays, start.clone(), binds, nets["sdf"], RATIO, nets["comp"], conds, dthreshold=1.e-4,
+                              athreshold=0.02, w1=3.05, w2=1., times=30)
+    assert (ok == gs["single_ok"].to(DEV)).float().mean().item() > 0.9
+
+
 @pytest.mark.parametrize("P,row_tiles", [(1, 1), (15, 2), (16, 1), (33, 2), (1000, 0), (3072, 1), (3072, 2), (5003, 0)])
 def test_row_tile_mlp_equals_the_per_layer_chain(nets, P, row_tiles, monkeypatch):
     """csrc/mlp_rows.hip — ONE launch per pass, the activations of a 16-ray tile resident in LDS across all layers — against the

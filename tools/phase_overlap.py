@@ -20,11 +20,13 @@ from recmv.loop import HotLoop  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_snapshot_like.conf"))
 loop = HotLoop(conf, torch.device("cuda", 0), n_frames=64, H=512, W=512, curves=True)
-for it in range(4):
+import bench  # noqa: E402
+it0 = bench.load_scene(loop, bench.SCENE_FILE)          # the bench's frozen scene, right after its re-mesh
+for it in range(it0, it0 + 4):
     loop.step(it)
 torch.cuda.synchronize()
 acc = {}
-for it in range(4, 4 + steps):
+for it in range(it0 + 4, it0 + 4 + steps):
     loop.phase_trace = []
     start = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()

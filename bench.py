@@ -159,7 +159,6 @@ HOTLOOP_KW = dict(n_frames=64, H=512, W=512)
 
 
 SCENE_FILE = REPO / "configs" / "synthetic" / "bench_scene_v1.pt"
-SCENE_PRIME_ITERS = 16
 _SCENE_DATASET = ("poses", "trans", "d_cond", "rendcond", "focal", "pp", "T")
 
 
@@ -177,33 +176,37 @@ def _scene_tensors(loop):
 
 
 def save_scene(loop, path, it, note=""):
-    """Freeze the state of the synthetic optimisation as the benchmark's scene (tools/make_bench_scene.py): matrices of >= 2^14
-    elements as f16 (the file DEFINES the scene; nothing has to match the run that produced it), the rest f32."""
+    """Freeze the state of the synthetic optimisation as the benchmark's scene (tools/make_bench_scene.py), taken where the next
+    step re-meshes: the tensors the optimisation moves — matrices of >= 2^14 elements as f16, the rest f32 — and Adam's two moments
+    as bf16 in the optimiser's parameter order.  The file DEFINES the scene; nothing has to match the run that produced it bit for
+    bit.  (The explicit meshes, their SGD momentum and the curves' AdamW are re-created by every re-mesh, the loop's and the
+    reference's alike, OptimGarmentNetwork.py:678-740: nothing to store.)"""
     t = {}
     for k, v in _scene_tensors(loop).items():
         v = v.detach().cpu()
         t[k] = v.half() if (v.is_floating_point() and v.numel() >= (1 << 14)) else v.clone()
-    # Adam's second moments (an average over the WHOLE run: 1 / (1 - beta2) = 1000 iterations of memory — what keeps the step sizes of
-    # a settled optimisation; sixteen priming iterations cannot rebuild it) as bf16, in the optimiser's parameter order
     params = [q for g in loop.optimizer.param_groups for q in g['params']]
-    adam_v = [loop.optimizer.state[q]['exp_avg_sq'].detach().cpu().bfloat16() if q in loop.optimizer.state else None for q in params]
-    steps = [float(loop.optimizer.state[q]['step']) for q in params if q in loop.optimizer.state]
-    torch.save(dict(version=1, it=int(it), opt_times=float(loop.opt_times), note=note, tensors=t, adam_v=adam_v,
+    state = loop.optimizer.state
+    adam = [(state[q]['exp_avg'].detach().cpu().bfloat16(), state[q]['exp_avg_sq'].detach().cpu().bfloat16()) if q in state else None
+            for q in params]
+    steps = [float(state[q]['step']) for q in params if q in state]
+    torch.save(dict(version=1, it=int(it), opt_times=float(loop.opt_times), note=note, tensors=t, adam=adam,
                     adam_step=max(steps) if steps else 0.0), path)
 
 
-def load_scene(loop, path, allreduce=None, prime_iters=SCENE_PRIME_ITERS):
-    """Put the loop into the frozen benchmark scene — the timed workload must not depend on the code under test (round-5 review):
+def load_scene(loop, path, allreduce=None):
+    """Put the loop into the frozen benchmark scene — the timed workload must not depend on the code under test (round-5 review:
+    240 settle iterations of the build under test amplified its rounding chaotically, and the scene's work moved by 4 % between
+    commits that changed no kernel):
 
-      1. the parameters, per-frame tensors and curve parameters of the scene file replace the seeded initial ones;
-      2. the next step re-meshes (the explicit meshes are ALWAYS the marching-cubes extraction of the file's SDF nets: vertex counts
-         are a function of the file, up to a voxel whose sign sits within rounding of zero);
-      3. Adam's second moments come from the file (bf16); `prime_iters` iterations fill the short-memory moments (Adam's first moments
-         on the shared tensors, SGD momentum on the explicit vertices, AdamW on the curves) with every tensor they moved put back after
-         each step: sums of gradients AT the file's state over `prime_iters` different frame batches — no feedback from the code under test into the state beyond
-         the rounding of one gradient evaluation (a settle phase of N real steps amplifies that rounding chaotically: the
-         round-5 scene moved by 4 % of its work between commits that changed no kernel).
-    Returns the iteration counter the timed run continues from."""
+      1. the parameters, per-frame tensors and curve parameters of the scene file replace the seeded initial ones, Adam gets the
+         file's moments and step count (second moments: 1000 iterations of memory, what keeps a settled optimisation's step
+         sizes; first moments: tools/scene_diag.py — re-estimating them at the frozen state gives every parameter a consistent
+         push, the explicit meshes lose their SDF within five steps);
+      2. a re-mesh: the explicit meshes are ALWAYS the marching-cubes extraction of the file's SDF nets (vertex counts are a
+         function of the file, up to a voxel whose value sits within rounding of zero), with fresh SGD / AdamW state as after
+         every re-mesh.
+    Returns the iteration counter the run continues from (the state right after a re-mesh: forward_time = 1)."""
     st = torch.load(path, map_location="cpu")
     if st.get("version") != 1:
         raise SystemExit("bench scene %s: unknown version %r" % (path, st.get("version")))
@@ -216,28 +219,18 @@ def load_scene(loop, path, allreduce=None, prime_iters=SCENE_PRIME_ITERS):
         for k, dst in mine.items():
             dst.copy_(st["tensors"][k].to(dst.dtype))
     loop.opt_times = float(st["opt_times"])
-    it0 = int(st["it"])
     params = [q for g in loop.optimizer.param_groups for q in g['params']]
-    if len(params) != len(st["adam_v"]) or any(v is not None and v.shape != q.shape for q, v in zip(params, st["adam_v"])):
+    if len(params) != len(st["adam"]) or any(mv is not None and mv[0].shape != q.shape for q, mv in zip(params, st["adam"])):
         raise SystemExit("bench scene %s: its Adam moments do not match this loop's optimiser" % path)
-    for q, v in zip(params, st["adam_v"]):
-        if v is not None:                                   # (first moments: from the priming iterations below)
-            loop.optimizer.state[q] = {'step': torch.tensor(float(st["adam_step"])), 'exp_avg': torch.zeros_like(q),
-                                       'exp_avg_sq': v.to(device=q.device, dtype=q.dtype)}
+    for q, mv in zip(params, st["adam"]):
+        if mv is not None:
+            loop.optimizer.state[q] = {'step': torch.tensor(float(st["adam_step"])),
+                                       'exp_avg': mv[0].to(device=q.device, dtype=q.dtype),
+                                       'exp_avg_sq': mv[1].to(device=q.device, dtype=q.dtype)}
     ratio = {'sdfRatio': 1., 'deformerRatio': loop.opt_times / 2500. + 0.5, 'renderRatio': 1.}
     loop.marching_cube_update(ratio)                        # 2. (what forward() does when a re-mesh is due, loop.py)
     loop.forward_time = 1
-    verts0 = [v.detach().clone() for v in loop.garment_vs]
-    for k in range(prime_iters):                            # 3.
-        loop.step(it0 + 1 + k, allreduce)                   # (frame batches it0+1 ..: the timed run starts at it0 + 1 again)
-        with torch.no_grad():
-            for name, dst in mine.items():
-                dst.copy_(st["tensors"][name].to(dst.dtype))
-            for v, v0 in zip(loop.garment_vs, verts0):
-                v.copy_(v0)
-        loop.opt_times = float(st["opt_times"])
-    loop.forward_time = 1                                   # the state right after a re-mesh
-    return it0 + 1
+    return int(st["it"]) + 1
 
 
 def export_state(loop, path, frame_ids, it):
@@ -553,7 +546,7 @@ def full_load_leg(loop, it, allreduce, world, device, sync, steps=20, lr_scale=0
             loop.forward_time = period - steps // 2          # the (steps/2)-th timed step re-meshes
         out = high_convergence_leg(loop, it, allreduce, world, device, sync, steps=steps, lr_scale=lr_scale, before_timed=before_timed)
     finally:
-        pass
+        loop.forward_time = old_ft
     out["workload"] = ("configs[1] as in `value` — one re-mesh inside the %d timed steps (the reference's cadence of one in %d would be "
                        "%.2f of one) — with the main optimiser's learning rate x %g so that the render phases run at full load"
                        % (steps, period, steps / period, lr_scale))
@@ -765,7 +758,8 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
         it = load_scene(loop, args.scene, allreduce)
         sync()
         scene = dict(file=str(Path(args.scene).resolve().relative_to(REPO)) if str(Path(args.scene).resolve()).startswith(str(REPO))
-                     else args.scene, prime_iters=SCENE_PRIME_ITERS, first_iteration=it)
+                     else args.scene, first_iteration=it,
+                     vertices_at_load=[int(v.shape[0]) for v in loop.garment_vs])
         log("frozen scene loaded: %s, MC vertices %s" % (scene["file"], [int(v.shape[0]) for v in loop.garment_vs]))
     torch.manual_seed(20261001 + rank)       # the draws of the warm-up and the timed region: one fixed sequence per rank
     for _ in range(args.settle_iters):

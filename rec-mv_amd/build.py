@@ -65,15 +65,22 @@ def _newest_header_mtime() -> float:
     return m
 
 
+COMPILED = []          # sources this process actually compiled (build() reports them: "does it build" is observable)
+
+
 def _compile(src: Path, force: bool, verbose: bool, hdr_mtime: float) -> Path:
     obj = OBJ / (src.stem + ".o")
-    if (not force and obj.exists() and obj.stat().st_mtime > src.stat().st_mtime
-            and obj.stat().st_mtime > hdr_mtime):
-        return obj
-    tmp = obj.with_suffix(f".o.tmp{os.getpid()}")
     extra = os.environ.get("RECMV_HIPCC_EXTRA", "").split()      # e.g. -DRECMV_ROWS_TIMING for tools/mlp_rows_clock.py
     if os.environ.get("RECMV_NO_PACKED_F32") == "1" or src.name in ALWAYS_NO_PACKED:
         extra = extra + NO_PACKED_F32
+    # an object is reused only if it is newer than its source and the headers AND was compiled with these very flags (a stamp beside
+    # it): switching RECMV_NO_PACKED_F32 / RECMV_HIPCC_EXTRA without --force must never link objects of two flag sets into one library
+    flags = " ".join([*COMMON_FLAGS, *extra])
+    stamp = obj.with_suffix(".flags")
+    if (not force and obj.exists() and obj.stat().st_mtime > src.stat().st_mtime
+            and obj.stat().st_mtime > hdr_mtime and stamp.exists() and stamp.read_text() == flags):
+        return obj
+    tmp = obj.with_suffix(f".o.tmp{os.getpid()}")
     cmd = [hipcc(), *COMMON_FLAGS, *extra, "-c", str(src), "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -82,6 +89,8 @@ def _compile(src: Path, force: bool, verbose: bool, hdr_mtime: float) -> Path:
         tmp.unlink(missing_ok=True)
         raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
     os.replace(tmp, obj)
+    stamp.write_text(flags)
+    COMPILED.append(src.name)
     if verbose and r.stderr.strip():
         print(r.stderr)
     return obj

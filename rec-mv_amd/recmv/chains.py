@@ -147,7 +147,8 @@ class MlpChain:
                 assert cond_index.dtype == torch.int64 and cond_index.is_contiguous() and cond_index.numel() == P
         rows = self._use_rows(P, n_out, split_row)
         if keep:
-            self._rows_last[slot] = rows
+            # (keyed like the workspaces: a forward(keep=True) on one stream says nothing about another stream's buffers)
+            self._rows_last[(slot, L.raw_stream(self.device))] = rows
         if rows:
             packed = self._pack(x.device)
             ws = self._rows_workspace(P, slot) if keep else None
@@ -174,9 +175,15 @@ class MlpChain:
         if g_out is not None:
             assert g_out.dtype == torch.float32 and g_out.stride(1) == 1 and g_out.shape == (P, n_out)
             ldg = g_out.stride(0) if P > 1 else n_out
-        if self._rows_last.get(slot, False):          # the activations are where the row-tile forward left them
+        key = (slot, L.raw_stream(self.device))
+        if key not in self._rows_last:
+            raise RuntimeError("MlpChain.vjp_input: no forward(keep=True) ran for slot %r on this stream — the kept activations "
+                               "live in a per-(slot, stream) workspace" % (slot,))
+        if self._rows_last[key]:                      # the activations are where the row-tile forward left them
             packed = self._pack(x.device)
-            ws = self._rows_workspace(P, slot)
+            ws = self._rows_ws.get(key)
+            if ws is None:
+                raise RuntimeError("MlpChain.vjp_input: the row-tile workspace of slot %r on this stream is gone" % (slot,))
             with L.device_guard(x.device):
                 L.check(L.lib().recmv_mlp_rows_vjp_input(C.byref(self.m), L.ptr(packed), L.ptr(x), P, n_out, L.ptr(g_out), ldg,
                                                          L.ptr(gx), L.ptr(ws), ws.numel(), L.stream_ptr(x.device)),

@@ -37,17 +37,23 @@ def init_distributed(backend: str | None = None):
             local_rank = 0
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        # The training collectives keep the backend's default timeout (10 min for RCCL: a rank that crashed or fell out of step in steady
-        # state takes the job down in minutes; RECMV_DIST_TIMEOUT_S overrides).  Only the START-UP rendezvous waits long — a first
-        # run's start-up stage (train.py: skinner bake, SDF pre-fit, feature-line registration) takes rank 0 far longer than that while
-        # the other ranks wait — and it has its own host-side group with its own timeout (startup_gate below).
-        kw = {}
-        if os.environ.get("RECMV_DIST_TIMEOUT_S"):
-            kw["timeout"] = datetime.timedelta(seconds=float(os.environ["RECMV_DIST_TIMEOUT_S"]))
+        # Timeouts (README "multi-GPU"): the training collectives wait RECMV_DIST_TIMEOUT_S (default 1800 s: a rank that crashed or
+        # fell out of step takes the job down within half an hour, while a rank-0-only stage inside the loop — a mesh or
+        # visualisation dump — still fits).  The START-UP rendezvous waits RECMV_STARTUP_TIMEOUT_S (default 7200 s): a first run's
+        # start-up stage (train.py: skinner bake, SDF pre-fit, feature-line registration) takes rank 0 far longer while the other
+        # ranks wait, and it has its own host-side gloo group (startup_gate below).
+        kw = {"timeout": datetime.timedelta(seconds=float(os.environ.get("RECMV_DIST_TIMEOUT_S", "1800")))}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
         global _gate_group
-        _gate_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(
-            seconds=float(os.environ.get("RECMV_STARTUP_TIMEOUT_S", "7200"))))
+        try:
+            _gate_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(
+                seconds=float(os.environ.get("RECMV_STARTUP_TIMEOUT_S", "7200"))))
+        except Exception as exc:      # noqa: BLE001 — gloo cannot resolve a host name / interface where RCCL alone works (set
+            # GLOO_SOCKET_IFNAME): fall back to the default group for the gate — it then waits RECMV_DIST_TIMEOUT_S only
+            import warnings
+            warnings.warn("recmv.dist: no gloo side group for the start-up gate (%r); the gate uses the training group and its "
+                          "timeout — raise RECMV_DIST_TIMEOUT_S for a long start-up stage, or set GLOO_SOCKET_IFNAME" % (exc,))
+            _gate_group = None
     return rank, local_rank, world
 
 

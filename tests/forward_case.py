@@ -490,7 +490,9 @@ def _check_trajectory_device(out, g):
             bound = max(float(env['canon_chamfer_' + tag].max()), 1e-12) if tag != 'body' else 1e-4
             inside = True
         else:
-            bound = 1e-4 if tag == 'body' else min(1e-3, 0.2 * c['moved_sq'])
+            # upper garment, 35 iterations: measured 2.3e-4; the reference's own loop with rounding-sized errors on its products ends up
+            # to 3.0e-4 away (twelve runs) -> 5e-4 catches a regression beyond that range, the envelope result stays reported below
+            bound = 1e-4 if tag == 'body' else min(5e-4, 0.2 * c['moved_sq'])
         if env is not None:
             inside = bool(c['chamfer_sq'] <= max(float(env['canon_chamfer_' + tag].max()), 1e-10))      # (1e-10: vertices 1e-5 apart — f32 evaluation of the untrained body net)
         assert c['chamfer_sq'] <= bound, ("canonical-mesh Chamfer", tag, c, bound)

@@ -82,11 +82,11 @@ def _matrix_mode(mode):
     """Run a test in the f32-input MFMA mode (0, the product's default) or in the optional bf16x6 mode (1): the same tolerances in
     both — the mode's six bf16 products per tile step are exact in f32, only the accumulation order differs."""
     from recmv import _lib as L
-    prev = L.lib().recmv_set_gemm_mode(mode)
+    prev = L.set_gemm_mode(mode)
     try:
         yield
     finally:
-        L.lib().recmv_set_gemm_mode(prev)
+        L.set_gemm_mode(prev)
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["f32", "bf16x6"])

@@ -752,11 +752,11 @@ def test_grid_sampler_accepts_half_like_the_reference_dispatch():
 def bf16x6_mode():
     """Switch librecmv_hip.so to the 3-way-bf16-split matrix mode for one test (recmv_set_gemm_mode)."""
     from recmv import _lib as L
-    prev = L.lib().recmv_set_gemm_mode(1)
+    prev = L.set_gemm_mode(1)
     try:
         yield
     finally:
-        L.lib().recmv_set_gemm_mode(prev)
+        L.set_gemm_mode(prev)
 
 
 @pytest.mark.parametrize("M,N,K", [(5, 3, 39), (300, 473, 512), (4096, 512, 512), (129, 130, 167), (20000, 512, 512),
@@ -903,7 +903,7 @@ def test_def_regu_value_and_gradient_match_the_host_svd(P, spread):
     # elements of the largest case sits at 3.8e-3 with the rotations' column updates compiled to packed f32 instructions and at 5.3e-3
     # compiled to scalar ones (round 5: the kernel is built without packed instructions) — the same few roundings of
     # log(sigma) taken in another order
-    assert bool((err <= 2e-3 * scale + 8e-3).all()), float((err - 2e-3 * scale).max())
+    assert bool((err <= 2e-3 * scale + 6e-3).all()), float((err - 2e-3 * scale).max())     # (measured worst 5.3e-3)
     if P > 300:
         assert float(y[7]) == 0.0 and float(Jg.grad[7].abs().max()) == 0.0
         assert float(y[9]) < 1e-6

@@ -275,6 +275,100 @@ def test_overlapped_order_equals_serial_order_world2_gloo(tmp_path):
         assert torch.equal(out["serial"][0][key], out["overlap"][0][key]), key
 
 
+def _capture_loop(capture, large_pose, world, rank, seed):
+    """A cut-down loop of one of the reference's captures: its own config file where /root/reference is mounted, the synthetic
+    config under the capture's name otherwise (as test_garment_set_follows_the_capture_name)."""
+    from recmv.hocon import ConfigFactory
+    from recmv.loop import HotLoop
+    ref_conf = REF_CONFS[capture]
+    if os.path.isfile(ref_conf):
+        conf = ConfigFactory.parse_file(ref_conf)
+    else:
+        conf = ConfigFactory.parse_file(CONF)
+        conf.put('train.garment_type', capture)
+        conf.put('train.is_upper_bottom', capture == 'leyang_jump')
+    conf.put('train.sample_pix_num', 32)
+    return HotLoop(conf, 'cpu', n_frames=12, H=64, W=64, resolutions=[(9, 11, 7), (17, 21, 13)], skin_grid=(5, 9, 7),
+                   bbox=((-0.9, -1.2, -0.6), (0.9, 1.2, 0.6)), world_size=world, rank=rank, seed=seed, curves=True,
+                   large_pose=large_pose)
+
+
+def _capture_dp_worker(rank, world, port, out_dir, capture, large_pose):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    for p in (REPO / "rec-mv_amd", REPO):
+        if str(p) not in sys.path:
+            sys.path.insert(0, str(p))
+    torch.set_num_threads(2)
+    from oracle import cpu_port
+    from recmv import dist as rdist
+    from recmv.loop import HotLoop, sample_fan_mesh
+    cpu_port.install()
+    r, _, w = rdist.init_distributed("gloo")
+    loop = _capture_loop(capture, large_pose, w, r, seed=r)           # different seeds: the broadcast must make the replicas agree
+    rdist.broadcast_state([p for p in loop.shared_parameters()] + list(loop.sdf.parameters())
+                          + [p for n in loop.garment_nets for p in n.parameters()]
+                          + list(loop.inter_free_curve.parameters()) + list(loop.inter_free_curve.buffers()))
+    allreduce = rdist.GradAllReduce(w)
+    exchanged = []                                                     # every tensor list that enters an exchange
+    real_start, real_call = allreduce.start, allreduce.__call__
+
+    class Spy:
+        def __call__(self, ts):
+            exchanged.append([id(t) for t in ts])
+            return allreduce(ts)
+
+        def start(self, ts):
+            exchanged.append([id(t) for t in ts])
+            return allreduce.start(ts)
+
+        def finish(self, h):
+            return allreduce.finish(h)
+    gen = torch.Generator().manual_seed(77)
+    loop.curve_aware_loss = lambda ratio: HotLoop.curve_aware_loss(
+        loop, ratio, sampler=lambda v, f, n: sample_fan_mesh(v, f, 4000, generator=gen))
+    for it in range(2):
+        loop.step(it, Spy())
+    sdf_ids = {id(p) for n in list(loop.garment_nets) + [loop.sdf] for p in n.parameters()}
+    shared = loop.shared_parameters()
+    torch.save({"params": torch.cat([p.detach().reshape(-1) for p in shared]),
+                "verts": torch.cat([v.detach().reshape(-1) for v in loop.garment_vs]),
+                "curves": torch.cat([p.detach().reshape(-1) for p in loop.inter_free_curve.parameters()]),
+                "sdf": torch.cat([p.detach().reshape(-1) for n in loop.garment_nets for p in n.parameters()]),
+                "sdf_tensors_exchanged": sum(1 for ids in exchanged for i in ids if i in sdf_ids),
+                "shared_grad_bytes": int(sum(p.numel() for p in shared) * 4),
+                "sdf_bytes": int(sum(p.numel() for n in loop.garment_nets for p in n.parameters()) * 4),
+                "garments": list(loop.garment_names), "exchanges": len(exchanged)}, os.path.join(out_dir, f"rank{r}.pt"))
+    rdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("capture,large_pose,garments", [
+    ('anran', False, ['short_sleeve_upper', 'skirt']),        # BASELINE configs[3]: CUHKszCap scene, frames sharded
+    ('leyang_jump', True, ['dress']),                         # BASELINE configs[4]: large-pose stage (train_large_pose.py:289-344)
+])
+def test_data_parallel_world2_gloo_on_the_scene_captures(tmp_path, capture, large_pose, garments):
+    """The frame-sharded path on the captures BASELINE configs[3] / [4] name — `configs/gap-female/config_anran_garment_10-5-1.conf`
+    (garments short_sleeve_upper + skirt, optimisation stage) and the large-pose stage of female_large_pose (one dress, SDF nets
+    frozen: OptimGarmentNetwork_Large_Pose.py:122-137) — as a world-2 gloo job: after two optimiser steps both replicas hold
+    bit-identical shared parameters, explicit vertices and curve parameters; in the large-pose stage the frozen SDF nets stay
+    bit-identical to their broadcast state WITHOUT entering any exchange (zero bytes), and the exchanged volume shrinks by exactly
+    the garment nets' size."""
+    import torch.multiprocessing as mp
+    port = 29500 + ((os.getpid() + (97 if large_pose else 53)) % 1000)
+    mp.spawn(_capture_dp_worker, args=(2, port, str(tmp_path), capture, large_pose), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert a["garments"] == garments
+    for key in ("params", "verts", "curves", "sdf"):
+        assert torch.equal(a[key], b[key]), key
+    assert a["exchanges"] >= 2 * 3                             # per step: explicit vertices, curves, shared gradients
+    if large_pose:
+        assert a["sdf_tensors_exchanged"] == 0 and b["sdf_tensors_exchanged"] == 0
+        # what the optimisation stage would exchange on top: the garment net(s)
+        assert a["sdf_bytes"] > 7e6 and a["shared_grad_bytes"] < 8e6
+    else:
+        assert a["sdf_tensors_exchanged"] > 0 and a["shared_grad_bytes"] > a["sdf_bytes"] > 15e6
+
+
 def test_grad_allreduce_start_finish_two_in_flight(tmp_path):
     """Two exchanges in flight at once (start, start, finish, finish) use two staging buffers and leave the averages."""
     import torch.multiprocessing as mp

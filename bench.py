@@ -793,11 +793,15 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
     t0 = time.perf_counter()
     if marks:
         marks[0].record()
+    dev_allocs = []                  # hipMalloc calls of the caching allocator per step (a re-mesh changes every vertex-sized shape)
+    n_alloc = (lambda: int(torch.cuda.memory_stats(device).get("num_device_alloc", 0))) if on_gpu else (lambda: 0)
     for k in range(args.steps):
         if loop.forward_time % loop.remesh_intersect == 0:
             remesh_steps.append(k)
         frames_hist.append(frames_at(loop, it))
+        a0 = n_alloc()
         _, r = loop.step(it, allreduce)
+        dev_allocs.append(n_alloc() - a0)
         if marks:
             marks[k + 1].record()
         rays += int(r)
@@ -1013,6 +1017,11 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                 "ms_per_step_at_reference_cadence": None if extra is None else round(plain_ms + extra / period, 3),
                 "iters_per_sec_at_reference_cadence": None if extra is None else round(
                     world * 1e3 / (plain_ms + extra / period), 4),
+                "device_allocations": {"in_remesh_steps": [dev_allocs[k] for k in remesh_steps if k < len(dev_allocs)],
+                                       "in_the_step_after": [dev_allocs[k + 1] for k in remesh_steps if k + 1 < len(dev_allocs)],
+                                       "in_all_other_steps": sum(a for k, a in enumerate(dev_allocs)
+                                                                 if k not in remesh_steps and (k - 1) not in remesh_steps),
+                                       "note": "hipMalloc calls of torch's caching allocator (memory_stats num_device_alloc)"},
                 "note": "GPU time between HIP events recorded at the step boundaries (rank 0); `value` has %d re-mesh(es) "
                         "in %d steps, the reference's cadence is 1 in %d" % (len(with_r), args.steps, period)}
         log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))

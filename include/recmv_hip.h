@@ -61,6 +61,28 @@ int recmv_inv3x3_backward(const void* grads, const void* invs, void* outs, int64
 int recmv_def_regu(const float* J, int64_t P, float c, float* y, float* gJ, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * A3. Camera of the loop (ABI v8): world points -> image coordinates, pixels -> world rays, with their backward passes.
+ *   replaces the element-wise torch chains of RectifiedPerspectiveCameras, model/CameraMine.py:62-88 + 281-300 (the calibration
+ *            matrix behind transform_points: fx' = fx / (W/2), px' = 1 - 1/W - px / (W/2)), :104-142 (transform_points_screen),
+ *            :146-169 (view_rays) and `project`.
+ * cam16: 16 device floats = R [3][3] row-major (world -> view: v = p R + T), T [3], focal length (fx, fy), principal point (px, py).
+ * W, H: image size in pixels.  mode: 0 -> out [P,3] = (x_ndc, y_ndc, z_view); 1 -> out [P,3] = (screen_x, screen_y, 1 / z_view),
+ *   screen = (S - 1) / 2 - S * ndc / 2; 2 -> out [P,2] = pixel (px - x fx / z, py - y fy / z).
+ * Backward: g_pts [P,3] (may be NULL) and g_cam7 = d/d(T[3], focal[2], principal point[2]) summed over the points in a FIXED order
+ *   (per-workgroup partial sums into `partial`, recmv_cam_partial_floats(P) floats owned by the caller, then one pass over them):
+ *   bit-reproducible, no float atomics.  R gets no gradient (the loop's camera rotation is not optimised).
+ * Rays: pixel (x, y, w) as [P,3] floats in `pix`, or — pix NULL — integer (col, row) with w = 1 -> unit world ray
+ *   normalize(-x / fx + w px / fx, -y / fy + w py / fy, w) R^T; backward: g_cam4 = d/d(focal[2], principal point[2]).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t recmv_cam_partial_floats(int64_t P);
+int recmv_cam_project(const float* pts, int64_t P, const float* cam16, float W, float H, int mode, float* out, void* stream);
+int recmv_cam_project_backward(const float* pts, const float* g_out, int64_t P, const float* cam16, float W, float H, int mode,
+                               float* g_pts, float* g_cam7, float* partial, int64_t partial_floats, void* stream);
+int recmv_cam_rays(const float* pix, const int64_t* col, const int64_t* row, int64_t P, const float* cam16, float* out, void* stream);
+int recmv_cam_rays_backward(const float* pix, const int64_t* col, const int64_t* row, const float* g_out, int64_t P,
+                            const float* cam16, float* g_cam4, float* partial, int64_t partial_floats, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * C. GridSamplerMine — 3-D trilinear sampler, padding=border, align_corners=False, with first and
  * second derivative.
  *   replaces GridSamplerMine.forward / backward / dbackward

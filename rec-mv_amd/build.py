@@ -18,9 +18,12 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
-OBJ = HERE / "build"
+# RECMV_BUILD_TAG=<tag>: an experiment build beside the product's (objects in build_<tag>/, lib/librecmv_hip_<tag>.so; load it with
+# RECMV_LIB_PATH) — e.g. RECMV_BUILD_TAG=libm RECMV_HIPCC_EXTRA=-DRECMV_LIBM_SOFTPLUS for tools/trajectory_seeds.py
+_TAG = os.environ.get("RECMV_BUILD_TAG", "")
+OBJ = HERE / ("build_" + _TAG if _TAG else "build")
 LIBDIR = HERE / "lib"
-LIB = LIBDIR / "librecmv_hip.so"
+LIB = LIBDIR / ("librecmv_hip_%s.so" % _TAG if _TAG else "librecmv_hip.so")
 INCLUDE = HERE.parent / "include"
 
 ARCH = "gfx950"

@@ -24,6 +24,16 @@
 #include <type_traits>
 #include <vector>
 #include "common.h"
+// RECMV_LIBM_SOFTPLUS (an experiment build of tools/trajectory_seeds.py, never the product's): the activation through the
+// correctly-rounded-to-an-ulp library functions instead of the hardware exp2 / log2 units.
+#ifdef RECMV_LIBM_SOFTPLUS
+#define RECMV_EXPF(x) expf(x)
+#define RECMV_LOG1PF(t) log1pf(t)
+#else
+#define RECMV_EXPF(x) __expf(x)
+#define RECMV_LOG1PF(t) __logf(1.f + (t))
+#endif
+
 #include <algorithm>
 
 namespace recmv {
@@ -98,9 +108,9 @@ __device__ __forceinline__ float apply_act(float z, float p, float inv_p) {
   if (ACT == RECMV_ACT_RELU) return z > 0.f ? z : 0.f;
   if (ACT == RECMV_ACT_SOFTPLUS) {
     const float zb = z * p;
-    const float t = __expf(-fabsf(zb));
+    const float t = RECMV_EXPF(-fabsf(zb));
     const float series = t * (1.f - t * (0.5f - t * (0.33333334f - 0.25f * t)));
-    const float l = t < 0.015625f ? series : __logf(1.f + t);
+    const float l = t < 0.015625f ? series : RECMV_LOG1PF(t);
     const float y = (fmaxf(zb, 0.f) + l) * inv_p;
     return zb > 20.f ? z : y;
   }
@@ -117,7 +127,7 @@ __device__ __forceinline__ float dact_y(float y, int act, float p) {
       // the hardware exp2 unit; below t = 1/64 the alternating series keeps the relative accuracy expm1 would give.
       const float t = p * y;
       const float series = t * (1.f - t * (0.5f - t * (0.16666667f - 0.041666668f * t)));
-      return t < 0.015625f ? series : 1.f - __expf(-t);
+      return t < 0.015625f ? series : 1.f - RECMV_EXPF(-t);
     }
     case RECMV_ACT_TANH: return 1.f - y * y;
     default: return 1.f;

@@ -23,6 +23,16 @@
 // over a pass), which is why this form is for the few-thousand-row passes only; recmv_mlp_forward keeps the per-layer kernels
 // above RECMV_MLP_ROWS_MAX rows.
 #include "common.h"
+// RECMV_LIBM_SOFTPLUS (an experiment build of tools/trajectory_seeds.py, never the product's): the activation through the
+// correctly-rounded-to-an-ulp library functions instead of the hardware exp2 / log2 units.
+#ifdef RECMV_LIBM_SOFTPLUS
+#define RECMV_EXPF(x) expf(x)
+#define RECMV_LOG1PF(t) log1pf(t)
+#else
+#define RECMV_EXPF(x) __expf(x)
+#define RECMV_LOG1PF(t) __logf(1.f + (t))
+#endif
+
 
 namespace recmv {
 namespace {
@@ -77,9 +87,13 @@ struct RowsArgs {
 // selected, so that the epilogue of a tile is one basic block.  The formulas are those of gemm_f32.hip's epilogue.
 __device__ __forceinline__ float softplus_fwd(float z, float p, float inv_p) {
   const float zb = z * p;
-  const float t = __expf(-fabsf(zb));
+  const float t = RECMV_EXPF(-fabsf(zb));
   const float series = t * (1.f - t * (0.5f - t * (0.33333334f - 0.25f * t)));
+  #ifdef RECMV_LIBM_SOFTPLUS
+  const float lg = log1pf(t);
+#else
   const float lg = __log2f(1.f + t) * 0.69314718f;          // 1 + t in [1, 2]: the bare v_log_f32, no range fix-ups
+#endif
   const float l = t < 0.015625f ? series : lg;
   const float y = (fmaxf(zb, 0.f) + l) * inv_p;
   return zb > 20.f ? z : y;
@@ -88,7 +102,7 @@ __device__ __forceinline__ float softplus_fwd(float z, float p, float inv_p) {
 __device__ __forceinline__ float softplus_grad(float y, float p) {   // sigmoid(beta z) = 1 - exp(-beta y), series below 1/64
   const float t = p * y;
   const float series = t * (1.f - t * (0.5f - t * (0.16666667f - 0.041666668f * t)));
-  const float e = 1.f - __expf(-t);
+  const float e = 1.f - RECMV_EXPF(-t);
   return t < 0.015625f ? series : e;
 }
 

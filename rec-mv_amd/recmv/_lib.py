@@ -16,7 +16,7 @@ _PKG = Path(__file__).resolve().parent.parent          # rec-mv_amd/
 LIB_PATH = Path(os.environ["RECMV_LIB_PATH"]) if os.environ.get("RECMV_LIB_PATH") else _PKG / "lib" / "librecmv_hip.so"   # (override: A/B builds of tools/)
 
 RECMV_OK = 0
-ABI_VERSION = 7          # include/recmv_hip.h; bumped when a signature changes (v7: recmv_get_sampler_mode, recmv_set_jet_fill added; v5: second weight set + split_row in recmv_mlp; v6: recmv_def_regu, recmv_b3_*, recmv_mlp_rows_*, recmv_mc_run_batch added)
+ABI_VERSION = 8          # include/recmv_hip.h; bumped when a signature changes (v8: recmv_cam_* added; v7: recmv_get_sampler_mode, recmv_set_jet_fill added; v5: second weight set + split_row in recmv_mlp; v6: recmv_def_regu, recmv_b3_*, recmv_mlp_rows_*, recmv_mc_run_batch added)
 F32, F64 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = 0, 1, 2, 3
 
@@ -70,6 +70,11 @@ def _declare(lib):
         "recmv_inv3x3_forward": (C.c_int, [vp, vp, vp, i64, i32, vp]),
         "recmv_inv3x3_backward": (C.c_int, [vp, vp, vp, i64, i32, vp]),
         "recmv_def_regu": (C.c_int, [vp, i64, C.c_float, vp, vp, vp]),
+        "recmv_cam_partial_floats": (i64, [i64]),
+        "recmv_cam_project": (C.c_int, [vp, i64, vp, C.c_float, C.c_float, i32, vp, vp]),
+        "recmv_cam_project_backward": (C.c_int, [vp, vp, i64, vp, C.c_float, C.c_float, i32, vp, vp, vp, i64, vp]),
+        "recmv_cam_rays": (C.c_int, [vp, vp, vp, i64, vp, vp, vp]),
+        "recmv_cam_rays_backward": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, i64, vp]),
         "recmv_grid_sample3d_forward": (C.c_int, [vp, T5, vp, T5, vp, T5, i32, i32, i32, vp]),
         "recmv_grid_sample3d_backward": (C.c_int, [vp, T5, vp, T5, vp, T5, vp, T5, vp, i32, i32, i32, vp]),
         "recmv_grid_sample3d_dbackward": (C.c_int, [vp, T5, vp, T5, vp, T5, vp, T5, vp, T5, vp, T5, vp, vp, T5,
@@ -289,12 +294,13 @@ _masked = []
 
 def make_stream(device):
     """A side stream of the loop (ray pipeline, curve branch, second garment's render terms): chains of short dependent launches
-    that run beside the main stream's large products.  High priority by default (RECMV_SIDE_PRIORITY=0: normal): a workgroup slot
-    that frees up goes to the waiting short kernel first, so the latency-bound chains are not stretched by the throughput-bound
-    products they share the CUs with (profiles/r06_stream_priority_ab.txt)."""
+    that run beside the main stream's large products.  RECMV_SIDE_PRIORITY=1 creates them with high priority; measured on the frozen
+    bench scene (round 6, two runs each, profiles/r06_stream_priority_ab.txt) it changes nothing — 9.84 / 9.88 it/s with, 9.89 / 9.91
+    without, the root finder's 45 ms beside the mask loss unchanged: a queue's priority does not reach the workgroup slots the large
+    products already hold — so the default stays normal priority."""
     k = int(os.environ.get("RECMV_SIDE_CUS", "0") or 0)
     if not (0 < k < 8):
-        if os.environ.get("RECMV_SIDE_PRIORITY", "1") != "0":
+        if os.environ.get("RECMV_SIDE_PRIORITY", "0") == "1":
             return torch.cuda.Stream(device=device, priority=-1)
         return torch.cuda.Stream(device=device)
     global _hip

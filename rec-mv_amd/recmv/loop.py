@@ -944,8 +944,15 @@ class HotLoop:
         vertices' part does not read the curves, so the main stream does not sit idle until the curve stream has caught up)."""
         conf = self.conf
         pc_sdf_loss = 0.
+        # The reference feeds the vertices WITH their autograd flag (:966), so its final backward also leaves d|f|/dv on
+        # `garment_vs.grad` — which nothing ever reads: the only consumer of that field is the SGD step of the NEXT mask loss, and
+        # `garment_optimizer.zero_grad()` (:959) clears it first (a re-mesh replaces the vertices altogether).  Detached here: same
+        # parameters after every step, one input-gradient product per layer of the SDF nets on ~160 k vertices less (0.6 of the
+        # iteration's 8 TFLOP; RECMV_PC_SDF_VERTEX_GRAD=1 computes the dead gradient again, for the A/B).
+        dead = os.environ.get('RECMV_PC_SDF_VERTEX_GRAD') == '1'
         for g_i, name in enumerate(self.garment_names):                                   # :966-970
-            mnfld_pred = self.garment_nets[g_i](self.garment_vs[g_i], ratio, features=False).view(-1)
+            verts = self.garment_vs[g_i] if dead else self.garment_vs[g_i].detach()
+            mnfld_pred = self.garment_nets[g_i](verts, ratio, features=False).view(-1)
             sdf_loss = (mnfld_pred + self.sdfShrinkRadius).abs().mean()
             self.info['pc_{}_loss_sdf'.format(name)] = sdf_loss.detach()
             pc_sdf_loss = pc_sdf_loss + sdf_loss * conf.get_float('pc_weight.weight')
@@ -1029,8 +1036,7 @@ class HotLoop:
                     idx = torch.from_numpy(np.flatnonzero(sel)).to(batch_inds.device, non_blocking=False)
                     batch_inds, row_inds, col_inds, init_pts = (t[idx] for t in (batch_inds, row_inds, col_inds,
                                                                                  init_pts))
-                rays = cameras.view_rays(torch.cat([col_inds.view(-1, 1), row_inds.view(-1, 1),
-                                                    torch.ones_like(col_inds.view(-1, 1))], dim=-1).float())
+                rays = cameras.view_rays_pix(col_inds, row_inds)
                 out.append((batch_inds, row_inds, col_inds, init_pts.contiguous(), rays))
         if cuda:
             main.wait_stream(side)
@@ -1297,7 +1303,13 @@ class HotLoop:
         """The deformation regulariser (:1135-1155) from the offset MLP's output at `pts` (its Jacobian carried by the jet pass)."""
         conf = self.conf
         Jacobs = utils.compute_Jacobian(pts, defVs, True, True)
-        if Jacobs.is_cuda and Jacobs.dtype == torch.float32 and os.environ.get('RECMV_FUSED_REGU', '1') != '0':
+        if os.environ.get('RECMV_REGU_HOST_SVD') == '1':
+            # the reference's own route, round trip and all (:1148-1150: LAPACK on the host, autograd through the SVD) — an
+            # experiment switch of tools/trajectory_seeds.py (which rounding seeds the trajectories' divergence?), never the loop's path
+            _, s, _ = torch.svd(Jacobs.cpu())
+            s = torch.log(s.to(Jacobs.device))
+            def_loss = utils.GMRobustError((s * s).sum(1), conf.get_float('def_regu.c'), True).mean()
+        elif Jacobs.is_cuda and Jacobs.dtype == torch.float32 and os.environ.get('RECMV_FUSED_REGU', '1') != '0':
             # value and dy/dJ per matrix from one launch (csrc/def_regu.hip) instead of ~90 torch launches forward + backward
             from .ops import def_regu
             def_loss = def_regu(Jacobs, conf.get_float('def_regu.c')).mean()
@@ -1456,8 +1468,7 @@ class HotLoop:
             cameras = self._cameras()
             grad_l_p = self.TmpPs[g_i].grad
             col, row = self.col_inds[g_i], self.row_inds[g_i]
-            v = cameras.view_rays(torch.cat([col.view(-1, 1), row.view(-1, 1), torch.ones_like(col.view(-1, 1))],
-                                            dim=-1).float())
+            v = cameras.view_rays_pix(col, row)
             c = cameras.cam_pos()
             p = self.TmpPs[g_i]
             net = self.garment_nets[g_i]
@@ -1534,9 +1545,9 @@ class HotLoop:
         cameras = self._cameras()
         n = [int(p.shape[0]) for p in ps]
         grad_l_p = torch.cat([p.grad for p in ps], dim=0)
-        col = torch.cat([self.col_inds[g] for g in range(G)]).view(-1, 1)
-        row = torch.cat([self.row_inds[g] for g in range(G)]).view(-1, 1)
-        v = cameras.view_rays(torch.cat([col, row, torch.ones_like(col)], dim=-1).float())
+        col = torch.cat([self.col_inds[g] for g in range(G)])
+        row = torch.cat([self.row_inds[g] for g in range(G)])
+        v = cameras.view_rays_pix(col, row)
         c = cameras.cam_pos()
         grad_f_p = torch.cat([pre[g][1] for g in range(G)], dim=0)
         grad_d_p = torch.cat([pre[g][2] for g in range(G)], dim=0)

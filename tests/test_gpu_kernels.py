@@ -974,3 +974,87 @@ def test_bf16x6_presplit_rides_on_the_weight_norm_and_its_transpose(bf16x6_mode)
         assert torch.equal(ops.gemm_nt(x, W2.detach()), y)
     finally:
         del os.environ["RECMV_B3_PRESPLIT"]
+
+
+# ------------------------------------------------------------------------------------------ camera (csrc/camera.hip)
+def _cameras_pair(monkeypatch, H=512, W=384, seed=0):
+    """The same camera twice: on the fused kernels and on the torch expressions they replace (RECMV_FUSED_CAMERA=0)."""
+    from recmv.model import RectifiedPerspectiveCameras
+    g = torch.Generator().manual_seed(seed)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    R = gpu((q * torch.tensor([-1., -1., 1.])).view(1, 3, 3))
+
+    def leaves():
+        return (gpu(torch.tensor([[1000. * W / 512, 980. * H / 512]])).requires_grad_(True),
+                gpu(torch.tensor([[W / 2. + 3., H / 2. - 5.]])).requires_grad_(True),
+                gpu(torch.tensor([[0.03, -0.02, 3.0]])).requires_grad_(True))
+    fa, ppa, Ta = leaves()
+    fused = RectifiedPerspectiveCameras(fa, ppa, R, Ta, image_size=[(W, H)])
+    assert fused._cam16[0] is not None
+    fb, ppb, Tb = leaves()
+    monkeypatch.setenv("RECMV_FUSED_CAMERA", "0")
+    plain = RectifiedPerspectiveCameras(fb, ppb, R, Tb, image_size=[(W, H)])
+    monkeypatch.delenv("RECMV_FUSED_CAMERA")
+    assert plain._cam16[0] is None
+    return fused, (fa, ppa, Ta), plain, (fb, ppb, Tb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [0, 1, 257, 70001, 270054])
+def test_camera_kernels_match_the_torch_expressions(P, monkeypatch):
+    """csrc/camera.hip against the element-wise expressions of RectifiedPerspectiveCameras (model/CameraMine.py:62-88, :104-142,
+    :146-169, `project`): NDC / screen / pixel coordinates and rays to a few ulp (same operation order, no contraction), the
+    gradients to the points to 1e-5 relative and the fixed-order sums for translation / focal length / principal point to 1e-4 of
+    their scale; twice in a row bit-identical."""
+    fused, la, plain, lb = _cameras_pair(monkeypatch)
+    g = torch.Generator().manual_seed(P + 1)
+    pts = gpu(torch.randn(P, 3, generator=g) * 0.4)
+    for name in ("transform_points_ndc", "transform_points_screen", "project"):
+        pa, pb = pts.clone().requires_grad_(True), pts.clone().requires_grad_(True)
+        oa, ob = getattr(fused, name)(pa), getattr(plain, name)(pb)
+        assert oa.shape == ob.shape
+        if P == 0:
+            continue
+        torch.testing.assert_close(oa, ob, rtol=2e-6, atol=2e-6 * float(ob.abs().max()))
+        w = gpu(torch.randn(ob.shape, generator=g))
+        ga = torch.autograd.grad((oa * w).sum(), [pa, *la])
+        gb = torch.autograd.grad((ob * w).sum(), [pb, *lb])
+        torch.testing.assert_close(ga[0], gb[0], rtol=1e-5, atol=1e-5 * float(gb[0].abs().max()))
+        for x, y in zip(ga[1:], gb[1:]):
+            assert x.shape == y.shape
+            torch.testing.assert_close(x, y, rtol=2e-4, atol=2e-4 * max(float(y.abs().max()), 1e-3))
+        ga2 = torch.autograd.grad((getattr(fused, name)(pa) * w).sum(), [pa, *la])
+        assert all(torch.equal(x, y) for x, y in zip(ga, ga2)), "the camera gradients are sums in a fixed order"
+    # [N,P,3] input of transform_points_screen keeps its shape
+    if P >= 257:
+        q3 = pts[:256].view(2, 128, 3)
+        torch.testing.assert_close(fused.transform_points_screen(q3), plain.transform_points_screen(q3), rtol=2e-6, atol=1e-4)
+    # rays: integer pixels and the float [P,3] form
+    col = torch.randint(0, 384, (P,), generator=g).to("cuda")
+    row = torch.randint(0, 512, (P,), generator=g).to("cuda")
+    ra, rb = fused.view_rays_pix(col, row), plain.view_rays_pix(col, row)
+    pix = torch.stack([col, row, torch.ones_like(col)], dim=1).float()
+    rc = fused.view_rays(pix)
+    assert ra.shape == (P, 3)
+    if P:
+        torch.testing.assert_close(ra, rb, rtol=2e-6, atol=2e-7)
+        assert torch.equal(ra, rc)
+        w = gpu(torch.randn(P, 3, generator=g))
+        ga = torch.autograd.grad((ra * w).sum(), la[:2])
+        gb = torch.autograd.grad((rb * w).sum(), lb[:2])
+        for x, y in zip(ga, gb):
+            torch.testing.assert_close(x, y, rtol=2e-4, atol=2e-4 * max(float(y.abs().max()), 1e-6))
+
+
+@pytest.mark.gpu
+def test_camera_kernels_argument_errors():
+    import ctypes as C
+    from recmv import _lib as L
+    lib = L.lib()
+    x = gpu(torch.zeros(4, 3))
+    cam = gpu(torch.zeros(16))
+    assert lib.recmv_cam_project(L.ptr(x), 4, L.ptr(cam), 64.0, 64.0, 3, L.ptr(x), None) == -1
+    assert lib.recmv_cam_project(L.ptr(x), 4, None, 64.0, 64.0, 0, L.ptr(x), None) == -1
+    assert lib.recmv_cam_project_backward(L.ptr(x), L.ptr(x), 4, L.ptr(cam), 64.0, 64.0, 0, None, L.ptr(cam), L.ptr(cam), 1, None) == -1
+    assert lib.recmv_cam_rays(None, None, None, 4, L.ptr(cam), L.ptr(x), None) == -1
+    assert lib.recmv_cam_partial_floats(10 ** 9) == 1024 * 7 and lib.recmv_cam_partial_floats(1) == 7

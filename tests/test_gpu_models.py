@@ -273,7 +273,7 @@ def test_row_tile_mlp_equals_the_per_layer_chain(nets, P, row_tiles, monkeypatch
         ch = sdf.chain(sdf._pe_weights(RATIO), need_t=True)
         f = ch.forward(x, n_out=1, keep=True, slot="t")
         gf = ch.vjp_input(x, None, slot="t")
-        assert ch._rows_last["t"] == rows
+        assert ch._rows_last[("t", L.raw_stream(ch.device))] == rows          # (kept per slot AND stream, like the workspaces)
         ct = tr.prepare_explicit(conds, ratio=RATIO)
         d = ct.forward(x, cond=conds, cond_index=frame, n_out=3, keep=True, slot="t")
         gd = ct.vjp_input(x, g3, slot="t")

@@ -1,0 +1,81 @@
+"""Row (g): WHICH arithmetic difference between this implementation and the reference seeds the divergence of the optimisation
+trajectories?  (Round-5 review: at 14 iterations the reference against itself — sgemm summation order only — is at 1e-13 of squared
+canonical Chamfer while the device is at 7.6e-6; "chaos" amplifies a seed, it does not name it.)
+
+One arithmetic difference at a time is switched back towards the reference's, the 14-iteration fixture (re-mesh inside,
+tests/golden/trajectory_short.npz) and the 35-iteration one (trajectory.npz) are run, and per configuration the table shows the
+loss's relative deviation from the reference's loop in the first iterations — the seed, before the map has amplified it — and the
+squared canonical Chamfer of both garments at 14 and at 35 iterations.  Each configuration runs in its own process (some are
+other BUILDS of the library: RECMV_BUILD_TAG / RECMV_LIB_PATH, rec-mv_amd/build.py).
+
+    python tools/trajectory_seeds.py            # on the GPU box, ~1 min per configuration
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "rec-mv_amd", "lib")
+
+CONFIGS = [
+    ("default build (the product)", {}),
+    ("sampler backward in the oracle's order (RECMV_SAMPLER_EXACT=1)", {"RECMV_SAMPLER_EXACT": "1"}),
+    ("regulariser through the reference's host SVD (torch.svd on the CPU, autograd through it)", {"RECMV_REGU_HOST_SVD": "1"}),
+    ("regulariser through closed-form singular values on torch ops (RECMV_FUSED_REGU=0)", {"RECMV_FUSED_REGU": "0"}),
+    ("softplus through libm expf / log1pf instead of the hardware exp2 / log2 units (build -DRECMV_LIBM_SOFTPLUS)",
+     {"RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_libm.so")}),
+    ("no fma contraction in any kernel (build -ffp-contract=off; the MFMA chains stay fma chains)",
+     {"RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_nocontract.so")}),
+    ("ray path on the per-layer product chain instead of the row-tile kernels (RECMV_MLP_ROWS=0)", {"RECMV_MLP_ROWS": "0"}),
+    ("one stream, the reference's phase order (RECMV_SERIAL=1: same arithmetic, a control)", {"RECMV_SERIAL": "1"}),
+    ("host SVD + libm softplus + exact sampler order together",
+     {"RECMV_REGU_HOST_SVD": "1", "RECMV_SAMPLER_EXACT": "1", "RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_libm.so")}),
+]
+
+
+def child():
+    sys.path[:0] = [os.path.join(ROOT, "rec-mv_amd"), os.path.join(ROOT, "tests"), ROOT]
+    import composite_cases as cc
+    import forward_case as fwc
+    out = {}
+    inputs = cc.load("forward")
+    for name in ("trajectory_short", "trajectory"):
+        g = cc.load(name)
+        with cc.host_draws():
+            r = fwc.run_trajectory(g, inputs, "cuda:0")
+        dev = [float(v) for v in r["loss_rel_dev"]]
+        out[name] = dict(iters=len(r["losses"]), loss_rel_dev=dev, u=r["canon_u"]["chamfer_sq"], b=r["canon_b"]["chamfer_sq"],
+                         body=r["canon_body"]["chamfer_sq"])
+    print("SEEDS " + json.dumps(out), flush=True)
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        return child()
+    only = [int(a) for a in sys.argv[1:]] or range(len(CONFIGS))
+    print("# loss deviation = |loss - reference's loss| / |reference's loss| at iterations 1, 2, 3, 5, 8, 14 of the 35-iteration fixture;")
+    print("# Chamfer = squared canonical-mesh Chamfer distance to the reference's meshes (upper / bottom garment); north_star bound 1e-4")
+    for i in only:
+        label, env = CONFIGS[i]
+        lib = env.get("RECMV_LIB_PATH")
+        if lib and not os.path.isfile(lib):
+            print("%-2d %s\n     SKIPPED: %s not built" % (i, label, lib), flush=True)
+            continue
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=1500)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("SEEDS ")]
+        if not line:
+            print("%-2d %s\n     FAILED: %s" % (i, label, (r.stderr.strip().splitlines() or ["?"])[-1][:300]), flush=True)
+            continue
+        d = json.loads(line[0][6:])
+        t, s = d["trajectory"], d["trajectory_short"]
+        dev = t["loss_rel_dev"]
+        print("%-2d %s" % (i, label))
+        print("     loss deviation at it 1/2/3/5/8/14: %s" % " ".join("%.1e" % dev[k] for k in (0, 1, 2, 4, 7, 13) if k < len(dev)))
+        print("     Chamfer at 14 iterations: upper %.2e  bottom %.2e      at %d iterations: upper %.2e  bottom %.2e" % (
+            s["u"], s["b"], t["iters"], t["u"], t["b"]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,8 @@ def _compile(src: Path, force: bool, verbose: bool, hdr_mtime: float) -> Path:
     extra = os.environ.get("RECMV_HIPCC_EXTRA", "").split()      # e.g. -DRECMV_ROWS_TIMING for tools/mlp_rows_clock.py
     if os.environ.get("RECMV_NO_PACKED_F32") == "1" or src.name in ALWAYS_NO_PACKED:
         extra = extra + NO_PACKED_F32
+    if src.name in os.environ.get("RECMV_NOCONTRACT_FILES", "").split(","):       # bisecting builds of tools/trajectory_seeds.py
+        extra = extra + ["-ffp-contract=off"]
     # an object is reused only if it is newer than its source and the headers AND was compiled with these very flags (a stamp beside
     # it): switching RECMV_NO_PACKED_F32 / RECMV_HIPCC_EXTRA without --force must never link objects of two flag sets into one library
     flags = " ".join([*COMMON_FLAGS, *extra])

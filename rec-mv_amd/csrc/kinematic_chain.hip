@@ -16,6 +16,15 @@
 // numbers.  Latency-bound by construction (B = 3..90 frames); its job is to remove launches.
 #include "common.h"
 
+// No fma contraction in this file.  The chain restates the reference's separately rounded torch operations ("same operation order"
+// below); contracted into fmas, the posed joint transforms differ from the reference's in the last bits — and because the chain
+// positions EVERY vertex and ray of a frame, that difference is coherent across all points, not noise.  Round 6 found it to be the
+// seed of the optimisation trajectories' divergence from the reference (tools/trajectory_seeds.py, profiles/r06_trajectory_seeds.txt:
+// squared canonical Chamfer at 14 iterations 7.6e-6 -> 7.1e-8, at 35 iterations 2.2e-4 -> 1.4e-5, inside the reference's own
+// run-to-run envelope; no other kernel's contraction, the hardware exp / log, the sampler's summation order or the regulariser's
+// route moves it).  The kernel is latency-bound (one thread per frame): the cost is nil.
+#pragma clang fp contract(off)
+
 namespace recmv {
 namespace {
 

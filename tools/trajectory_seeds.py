@@ -29,6 +29,16 @@ CONFIGS = [
      {"RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_nocontract.so")}),
     ("ray path on the per-layer product chain instead of the row-tile kernels (RECMV_MLP_ROWS=0)", {"RECMV_MLP_ROWS": "0"}),
     ("one stream, the reference's phase order (RECMV_SERIAL=1: same arithmetic, a control)", {"RECMV_SERIAL": "1"}),
+    ("no fma contraction in kinematic_chain.hip only", {"RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_nc_kin.so")}),
+    ("no fma contraction in lbs_fused.hip only", {"RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_nc_lbs.so")}),
+    ("no fma contraction in elementwise.hip + linear_bwd.hip only", {"RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_nc_elt.so")}),
+    ("no fma contraction in mlp_chain.hip + mlp_jet.hip + posenc_grad.hip only", {"RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_nc_mlp.so")}),
+    ("no fma contraction in gemm_f32.hip + mlp_rows.hip only (epilogues, encodings; the MFMA chains stay)",
+     {"RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_nc_gemm.so")}),
+    ("no fma contraction in def_regu.hip only", {"RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_nc_regu.so")}),
+    ("no fma contraction in grid_sample3d.hip only", {"RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_nc_gs.so")}),
+    ("no fma contraction in the remaining files only (seg3d, interp2x, inv3x3, marching cubes, rasterisers, camera)",
+     {"RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_nc_rest.so")}),
     ("host SVD + libm softplus + exact sampler order together",
      {"RECMV_REGU_HOST_SVD": "1", "RECMV_SAMPLER_EXACT": "1", "RECMV_LIB_PATH": os.path.join(LIBDIR, "librecmv_hip_libm.so")}),
 ]

@@ -39,12 +39,12 @@ COMMON_FLAGS = [
 ]
 # No packed-f32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).  Round 5 traced the run-to-run divergence of the optional
 # bf16x6 matrix mode to exactly these: a wave executing them while waves of that mode's NT product kernels run beside it on the device
-# gets WRONG results in lanes 48-63, a few launches in a hundred (gfx950, ROCm 7.2; tools/valu_disturb_repro.hip: the same column updates
+# gets WRONG results in lanes 48-63, a few launches in a hundred (gfx950, ROCm 7.2; tools/erratum/valu_disturb_repro.hip: the same column updates
 # fail as v_pk_* and never fail as scalar v_mul / v_fma).  The default (f32) mode runs no such product kernel and is
 # bit-reproducible with packed instructions (several hundred counted repetitions), and removing them costs the f32 MFMA kernels 2-3 %
 # and the sampler ~10 % — so by default only the kernel that was caught (the deformation regulariser: long packed-f32 chains, per
 # thread) is built without them, and RECMV_NO_PACKED_F32=1 builds EVERY kernel without them: the build to use with
-# RECMV_GEMM_MODE=1 (with it the bf16x6 loop is identical in 60 of 60 repetitions, profiles/r05_race_12_no_packed_f32.txt).
+# RECMV_GEMM_MODE=1 (with it the bf16x6 loop is identical in 60 of 60 repetitions, profiles/erratum/r05_race_12_no_packed_f32.txt).
 # The switch is read by the device pass only (the host pass prints "not a recognized feature ... ignoring").
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DRECMV_NO_PACKED_F32=1"]
 ALWAYS_NO_PACKED = {"def_regu.hip"}

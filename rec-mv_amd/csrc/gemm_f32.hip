@@ -1651,7 +1651,7 @@ extern "C" int recmv_set_gemm_mode(int mode) {
 extern "C" int recmv_get_gemm_mode(void) { return g_gemm_mode; }
 
 // Mode 1 only — which kernel families compute in bf16x6 (the others stay on the exact-f32 kernels): bit 0 = 128 x 128 NT tiles, bit 1 =
-// 64 x 64 and 64 x 32 NT tiles, bit 2 = TN (dW) tiles.  7 (default) = all.  A bisect / A-B switch (tools/loop_repro_inproc.py); returns
+// 64 x 64 and 64 x 32 NT tiles, bit 2 = TN (dW) tiles.  7 (default) = all.  A bisect / A-B switch (tools/erratum/loop_repro_inproc.py); returns
 // the previous mask.
 extern "C" int recmv_set_b3_families(int mask) {
   const int prev = g_b3_families;

@@ -262,7 +262,7 @@ def ptr(t) -> C.c_void_p:
 # on the modules (normalised weights, their transposes, posed skeletons, packed weights).  A value built on one stream is only
 # valid on another after that stream has waited for the producer: `publish()` records the event behind the producer's launches and
 # `acquire()` makes the CURRENT stream wait for it when it is a different one (a hit on the producing stream costs one integer
-# compare).  RECMV_CACHE_EVENTS=0 drops the waits (A/B for tools/loop_repro_inproc.py — the round-4 state of half of the caches).
+# compare).  RECMV_CACHE_EVENTS=0 drops the waits (A/B for tools/erratum/loop_repro_inproc.py — the round-4 state of half of the caches).
 def publish(device):
     """Token for a value whose producing launches have just been enqueued on the current stream of `device` (None on the host)."""
     if device is None:

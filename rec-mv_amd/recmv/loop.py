@@ -1115,7 +1115,7 @@ class HotLoop:
         # (tools/ab_interleaved.py render_streams, profiles/r04_ab_render_streams.txt).  RECMV_RENDER_STREAMS=0: one stream (A/B).
         side = None
         # (Round 4 took the side stream out of the bf16x6 mode's default on the strength of 12-run samples; round 5's in-process counts
-        # — tools/loop_repro_inproc.py, 40-100 repetitions per cell — show that mode parting with AND without it, and why: a kernel of
+        # — tools/erratum/loop_repro_inproc.py, 40-100 repetitions per cell — show that mode parting with AND without it, and why: a kernel of
         # the iteration computes wrong values beside that mode's product kernels, whatever the schedule, DESIGN.md §9.  The f32 mode is
         # identical in every repetition of every cell, so the side stream is simply the default.)
         rs = os.environ.get('RECMV_RENDER_STREAMS', '1')

@@ -81,7 +81,7 @@ def test_rasteriser_argument_errors_through_the_c_abi():
 
 def test_the_regulariser_kernel_has_no_packed_f32_instructions():
     """Round 5 traced the run-to-run divergence of the bf16x6 matrix mode to packed-f32 VALU instructions: beside that mode's NT product
-    kernels a wave executing v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 gets wrong results in lanes 48-63 (tools/valu_disturb_repro.hip,
+    kernels a wave executing v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 gets wrong results in lanes 48-63 (tools/erratum/valu_disturb_repro.hip,
     DESIGN.md §9).  rec-mv_amd/build.py therefore builds csrc/def_regu.hip — the kernel that was caught — without them in every build,
     and EVERY kernel without them under RECMV_NO_PACKED_F32=1 (the build for RECMV_GEMM_MODE=1).  Disassembles the gfx950 code
     objects inside the shared library."""

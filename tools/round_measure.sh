@@ -24,7 +24,7 @@ tail -3 gpurun_out/${R}_gpu_suite_final.txt
 timeout 600 python -m pytest tests/test_gpu_composite.py -q -s -k trajectory 2>&1 | grep "on the GPU:" > gpurun_out/${R}_trajectory_gpu.txt
 cut -c1-600 gpurun_out/${R}_trajectory_gpu.txt
 # run-to-run reproducibility: 50 repetitions of one iteration per cell, both matrix modes, side stream on / off
-timeout 300 python tools/loop_repro_inproc.py 50 "f32 side-stream,f32 one-ray-stream,bf16x6 side-stream,bf16x6 one-ray-stream,f32 serial" 2>/dev/null | cut -c1-400 > gpurun_out/${R}_loop_repro_50.txt
+timeout 300 python tools/erratum/loop_repro_inproc.py 50 "f32 side-stream,f32 one-ray-stream,bf16x6 side-stream,bf16x6 one-ray-stream,f32 serial" 2>/dev/null | cut -c1-400 > gpurun_out/${R}_loop_repro_50.txt
 cat gpurun_out/${R}_loop_repro_50.txt
 # ... and across processes (f32, default switches): 6 fresh processes, 3 iterations each, one digest expected
 for i in 1 2 3 4 5 6; do timeout 120 python tools/determinism_probe.py 3 2>/dev/null | md5sum | cut -c1-8; done | sort | uniq -c > gpurun_out/${R}_loop_repro_processes.txt

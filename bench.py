@@ -153,6 +153,7 @@ def mc_extract_timing(device):
                                       unit="GB/s", frac=round(alg / mc_s / HBM_PEAK, 4)))
 
 
+ALLOC_CONF = "roundup_power2_divisions:4"      # torch caching-allocator setting of the bench process (RECMV_ALLOC_CONF= overrides / "" disables)
 CPU_BASELINE_CORES = 32      # cap: the GPU boxes expose 256 host threads; the loop's small ops do not scale past a socket slice
 CPU_BASELINE_LIMIT_S = 240   # hard wall-clock bound of the whole leg (it runs in a child process)
 HOTLOOP_KW = dict(n_frames=64, H=512, W=512)
@@ -505,11 +506,14 @@ def config2_leg(loop, it, allreduce, world, device, steps=6):
                                 faster=False).to(device)
     loop.remesh_intersect = 1
     n = 0
+    split = None
     try:
         loop.step(it + n, allreduce)
         n += 1
         rdist.barrier()
         torch.cuda.synchronize()
+        loop.remesh_trace = []                      # HIP events + host intervals of the re-mesh's parts, read after the timed steps
+        a0 = int(torch.cuda.memory_stats(device).get("num_device_alloc", 0))
         t0 = time.perf_counter()
         rays = conv = 0
         for _ in range(steps):
@@ -520,8 +524,31 @@ def config2_leg(loop, it, allreduce, world, device, steps=6):
         torch.cuda.synchronize()
         rdist.barrier()
         dt = time.perf_counter() - t0
+        allocs = int(torch.cuda.memory_stats(device).get("num_device_alloc", 0)) - a0
         verts = [int(v.shape[0]) for v in loop.garment_vs]
+        acc = {}
+        for name, e0, e1, h0, h1 in loop.remesh_trace:
+            a = acc.setdefault(name, [0.0, 0.0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += (h1 - h0) * 1e3
+        if "remesh" in acc:
+            ms = lambda k, i=0: acc.get(k, [0.0, 0.0])[i] / steps
+            split = {"remesh_ms": round(ms("remesh"), 3), "plain_ms": round(dt / steps * 1e3 - ms("remesh"), 3),
+                     "pyramid_query_ms": round(ms("query"), 3),
+                     "seg3d_bookkeeping_ms": round(ms("pyramid") - ms("query"), 3),
+                     "marching_cubes_ms": round(ms("mc"), 3),
+                     "mesh_handover_ms": round(ms("remesh") - ms("pyramid") - ms("mc"), 3),
+                     "host_ms_in_remesh": round(ms("remesh", 1), 3),
+                     "queried_points_note": "Seg3dLossless for the body and both garment nets in lockstep (forward_multi), "
+                                            "one counter read-back per pyramid level and growth round",
+                     "device_allocations_in_timed_steps": allocs,
+                     "note": "GPU time between HIP events on the main stream (the re-mesh runs at the head of a step, nothing else "
+                             "queued): pyramid_query = the SDF nets' MFMA passes, seg3d_bookkeeping = the rest of the pyramid "
+                             "(upsampling, selection, scatter, growth, counter read-backs), marching_cubes = x-major copies + "
+                             "extraction of the three volumes, mesh_handover = vertex tensors / SGD / AdamW re-creation; plain_ms "
+                             "= the step without its re-mesh"}
     finally:
+        loop.remesh_trace = None
         loop.engine, loop.remesh_intersect = old_engine, old_period
         loop.forward_time = 0                       # the next step of the caller re-meshes on its own pyramid again
     if world > 1:
@@ -532,7 +559,7 @@ def config2_leg(loop, it, allreduce, world, device, steps=6):
                         "body and both garment nets at the start of EVERY step (remesh_intersect = 1)",
             "steps": steps, "value": round(steps * world / dt, 4), "unit": "iters/s", "ms_per_step": round(dt / steps * 1e3, 3),
             "mc_vertices": verts, "rays_per_iter": round(rays / steps, 1),
-            "rays_converged_fraction": round(conv / max(rays, 1), 4), "_steps_run": n}
+            "rays_converged_fraction": round(conv / max(rays, 1), 4), "split": split, "_steps_run": n}
 
 
 def full_load_leg(loop, it, allreduce, world, device, sync, steps=20, lr_scale=0.1):
@@ -737,6 +764,12 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
     else:
         device = torch.device(device_type)
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    if on_gpu and os.environ.get("RECMV_ALLOC_CONF", ALLOC_CONF):
+        # A re-mesh changes every vertex-sized shape by a percent or two; with exact-size blocks the caching allocator then has nothing
+        # cached that fits and goes to hipMalloc for the large activation buffers (a handful of calls, milliseconds each on some hosts:
+        # the re-mesh step's extra time varied 32 .. 75 ms between boxes).  Sizes rounded up to a quarter of a power of two land in the
+        # bucket the previous mesh's buffers left behind.  (A process-wide allocator setting: made by the application, not the library.)
+        torch.cuda.memory._set_allocator_settings(os.environ.get("RECMV_ALLOC_CONF", ALLOC_CONF))
     conf = ConfigFactory.parse_file(args.conf)
     for k, v in (conf_overrides or {}).items():
         conf.put(k, v)

@@ -500,18 +500,59 @@ class HotLoop:
     def discretizeSDF(self, ratio, engine=None, balance_value=0.):
         """OptimGarmentNetwork.py:581-618."""
         engine = engine or self.engine
+        trace = getattr(self, 'remesh_trace', None)          # a list: bench.py's configs[2] block asks for the split of a re-mesh
+
+        def span(name):
+            """(event, event) bracket on the current stream + the host's interval, appended to the trace; no synchronisation."""
+            if trace is None or not torch.cuda.is_available():
+                return contextlib.nullcontext()
+
+            @contextlib.contextmanager
+            def cm():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                e0.record()
+                yield
+                e1.record()
+                trace.append((name, e0, e1, t0, time.perf_counter()))
+            return cm()
 
         def query_of(net):
             def query(points):
-                with torch.no_grad():
+                with torch.no_grad(), span('query'):
                     # only the SDF value is read here: skip the 256 render-feature rows of the last layer
                     return net.forward(points.reshape(-1, 3), ratio, features=False).reshape(1, 1, -1)
             return query
 
         nets = [self.sdf] + list(self.garment_nets)
         engine.balance_value = balance_value
-        # the body's and the garments' pyramids run level by level in lockstep (Seg3dLossless.forward_multi)
-        volumes = engine.forward_multi([query_of(net) for net in nets])
+        # A net whose parameters have not changed since its last extraction on this grid gives the same volume and the same mesh,
+        # bit for bit (the pyramid and marching cubes are deterministic): it is not extracted again.  In the optimisation stage that
+        # is the BODY net (no loss term reaches it: SURVEY.md §8e — a quarter of a re-mesh's queries), in the large-pose stage all
+        # three (freeze_sdf).  The reference re-extracts them every time (:593-617).  RECMV_REMESH_CACHE=0: always extract (A/B).
+        ws = None if ratio is None else (ratio if isinstance(ratio, (int, float)) else ratio.get('sdfRatio'))
+        grid = (tuple(tuple(int(v) for v in r) for r in engine.resolutions), tuple(engine.b_min.view(-1).tolist()),
+                tuple(engine.b_max.view(-1).tolist()), float(balance_value), ws)
+        cache = self.__dict__.setdefault('_remesh_cache', {})
+        keys = [(grid,) + tuple((q.data_ptr(), q._version) for q in net.parameters()) for net in nets]
+        use_cache = os.environ.get('RECMV_REMESH_CACHE', '1') != '0' and torch.device(self.device).type == 'cuda'
+        todo = [i for i, k in enumerate(keys) if not (use_cache and i in cache and cache[i][0] == k)]
+        results = {i: cache[i][1] for i in range(len(nets)) if i not in todo}
+        if todo:
+            # the pyramids of the nets that moved run level by level in lockstep (Seg3dLossless.forward_multi)
+            with span('pyramid'):
+                volumes = engine.forward_multi([query_of(nets[i]) for i in todo])
+            with span('mc'):
+                vs, fs = self._extract(volumes, engine, balance_value)
+            for i, v, f in zip(todo, vs, fs):
+                results[i] = (v, f)
+                if use_cache:
+                    cache[i] = (keys[i], (v.detach().clone(), f))
+        # (garment vertices become leaves of the explicit-mesh SGD: a cached extraction hands out its own copy)
+        out = [results[i] if i in todo else (results[i][0].clone(), results[i][1]) for i in range(len(nets))]
+        return [v for v, _ in out], [f for _, f in out]
+
+    def _extract(self, volumes, engine, balance_value):
         vols = [sdfs[0, 0].permute(2, 1, 0).contiguous() for sdfs in volumes]
         # all nets' extractions in one set of launches and one counter read-back (MCGpu.mc_gpu_multi; on the CPU port and for a
         # grid's first extraction: one mc_gpu per net, the reference's form)
@@ -525,7 +566,21 @@ class HotLoop:
 
     def marching_cube_update(self, ratio):
         """OptimGarmentNetwork.py:678-740 (openmesh vertex->face tables are never read by the loop: dropped)."""
+        trace = getattr(self, 'remesh_trace', None)
+        t_all = None
+        if trace is not None and torch.cuda.is_available():
+            t_all = (torch.cuda.Event(enable_timing=True), time.perf_counter())
+            t_all[0].record()
         vs_list, fs_list = self.discretizeSDF(ratio, None, -self.sdfShrinkRadius)
+        try:
+            self._marching_cube_handover(vs_list, fs_list)
+        finally:
+            if t_all is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                trace.append(('remesh', t_all[0], e1, t_all[1], time.perf_counter()))
+
+    def _marching_cube_handover(self, vs_list, fs_list):
         self.body_vs, self.body_fs = vs_list[0], fs_list[0]
         self.garment_vs, self.garment_fs = vs_list[1:], fs_list[1:]
         self.update_hierarchical_config()                                                  # :697

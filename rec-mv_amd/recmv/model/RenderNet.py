@@ -43,20 +43,8 @@ class RenderingNetwork_view_norm(nn.Module):
         lin = getattr(self, "lin" + str(l))
         if self.weight_norm:
             v, g = lin.weight_v, lin.weight_g
-            if not torch.is_grad_enabled():
-                # the normalised weights only change at optimizer.step(): cache them for the no-grad passes
-                # (grid queries, root-finder checks) keyed on the parameters' in-place version counters
-                cache = self.__dict__.setdefault('_wn_cache', {})
-                key = (v._version, g._version, v.data_ptr())
-                hit = cache.get(l)
-                if hit is None or hit[0] != key:
-                    W = ops.weight_norm(v, g)
-                    hit = (key, W, L.publish(W.device))     # the event behind the producer: a hit on another stream waits
-                    cache[l] = hit
-                else:
-                    L.acquire(hit[2])
-                return hit[1], lin.bias
-            return ops.weight_norm(v, g), lin.bias
+            # computed once per parameter version and shared by every pass / stream of the optimiser step (ops.weight_norm_shared)
+            return ops.weight_norm_shared(self, l, v, g), lin.bias
         return lin.weight, lin.bias
 
     @staticmethod

@@ -71,22 +71,8 @@ class ImplicitNetwork(nn.Module):
         lin = getattr(self, "lin" + str(l))
         if self.weight_norm:
             v, g = lin.weight_v, lin.weight_g
-            if not torch.is_grad_enabled():
-                # the normalised weights only change at optimizer.step(): cache them for the no-grad passes
-                # (grid queries, root-finder checks) keyed on the parameters' in-place version counters.  The cache is read
-                # from every stream of the loop (re-mesh and root-finder preparation on the main stream, the root finders on
-                # the ray streams): an entry carries the event recorded behind its producer, a hit on another stream waits
-                cache = self.__dict__.setdefault('_wn_cache', {})
-                key = (v._version, g._version, v.data_ptr())
-                hit = cache.get(l)
-                if hit is None or hit[0] != key:
-                    W = ops.weight_norm(v, g)
-                    hit = [key, W, None, L.publish(W.device), None]       # key, W, W^T, token of W, token of W^T
-                    cache[l] = hit
-                else:
-                    L.acquire(hit[3])
-                return hit[1], lin.bias
-            return ops.weight_norm(v, g), lin.bias                                # weight_norm dim=0
+            # computed once per parameter version and shared by every pass / stream of the optimiser step (ops.weight_norm_shared)
+            return ops.weight_norm_shared(self, l, v, g), lin.bias
         return lin.weight, lin.bias
 
     def _pe_weights(self, ratio):

@@ -64,6 +64,16 @@ def transposed(W):
     """Contiguous W^T, cached on the tensor object for as long as its data is unchanged.  The cache is shared by every
     stream that differentiates through W in an iteration (mask loss, curve branch, render loss): it keeps the event
     recorded behind the transpose, and a hit from another stream waits for it."""
+    ent = getattr(W, "_recmv_entry", None)
+    if ent is not None and ent[1] is not None and ent[1].data_ptr() == W.data_ptr() and ent[1]._version == W._version:
+        # the alias of a shared weight-normed matrix (weight_norm_shared): its transpose is made once per optimiser step
+        if ent[2] is None:
+            L.acquire(ent[3])
+            ent[2] = presplit(ent[1].t().contiguous())
+            ent[4] = L.publish(W.device)
+        else:
+            L.acquire(ent[4])
+        return ent[2]
     hit = getattr(W, "_recmv_t", None)
     if hit is not None and hit[0] == W._version:
         if hit[2] is not None and L.raw_stream(W.device) != hit[3]:
@@ -502,6 +512,70 @@ class WeightNorm(torch.autograd.Function):
                                                        L.ptr(gg), v.shape[0], v.shape[1], L.stream_ptr(v.device)),
                     "weight_norm_backward")
         return gv, gg
+
+
+class WeightNormShared(torch.autograd.Function):
+    """WeightNorm whose result lives in a per-layer cache entry `[key, W, W^T, token of W, token of W^T, norms]` (weight_norm_shared):
+    the first pass of an optimiser step launches the kernel, every later pass — with or without a graph — takes a fresh alias of the
+    same W (and, in its backward, the same W^T).  The SDF nets go through ~8 autograd passes per iteration: 9 normalisations and 9
+    transposes each became 9 + 9 per STEP."""
+
+    @staticmethod
+    def forward(ctx, v, g, entry):
+        if entry[1] is None:
+            v_c, g_c = v.detach().contiguous(), g.detach().contiguous()
+            rows, cols = v_c.shape
+            W = L.scratch_like(v_c)
+            norms = L.scratch(rows, torch.float32, v.device)
+            with L.device_guard(v.device):
+                L.check(L.lib().recmv_weight_norm_forward(L.ptr(v_c), L.ptr(g_c), L.ptr(W), L.ptr(norms), rows, cols,
+                                                          L.stream_ptr(v.device)), "weight_norm")
+            entry[1], entry[5], entry[3] = presplit(W), norms, L.publish(W.device)
+        else:
+            L.acquire(entry[3])
+        ctx.save_for_backward(v.detach(), g.detach(), entry[5])
+        return entry[1].detach()                       # a fresh alias: each graph gets its own node output, all share the data
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gW):
+        v, g, norms = ctx.saved_tensors
+        v, g = v.contiguous(), g.contiguous()
+        gW = gW.contiguous()
+        gv = L.scratch_like(v)
+        gg = L.scratch_like(g)
+        with L.device_guard(v.device):
+            L.check(L.lib().recmv_weight_norm_backward(L.ptr(v), L.ptr(g), L.ptr(norms), L.ptr(gW), L.ptr(gv),
+                                                       L.ptr(gg), v.shape[0], v.shape[1], L.stream_ptr(v.device)),
+                    "weight_norm_backward")
+        return gv, gg, None
+
+
+def weight_norm_shared(module, l, v, g):
+    """The weight-normed matrix of layer `l` of `module` for the CURRENT values of (v, g): computed once per parameter version (they
+    only change at optimizer.step()) and shared by every pass of the step and every stream of the loop (the entry carries the events
+    behind its producers; a hit on another stream waits).  No-grad callers get the cached tensor itself, autograd callers an alias
+    behind a WeightNormShared node whose backward finds the cached W^T through `transposed()`.  RECMV_SHARED_WN=0: one kernel per
+    autograd pass again (A/B)."""
+    if not (v.is_cuda and v.dtype == torch.float32):
+        return g * (v / v.norm(dim=1, keepdim=True))
+    cache = module.__dict__.setdefault('_wn_cache', {})
+    key = (v._version, g._version, v.data_ptr())
+    hit = cache.get(l)
+    if hit is None or hit[0] != key:
+        hit = cache[l] = [key, None, None, None, None, None]        # key, W, W^T, token of W, token of W^T, row norms
+    if not torch.is_grad_enabled() or not (v.requires_grad or g.requires_grad):
+        if hit[1] is None:
+            with torch.no_grad():
+                WeightNormShared.apply(v, g, hit)
+        else:
+            L.acquire(hit[3])
+        return hit[1]
+    if os.environ.get('RECMV_SHARED_WN', '1') == '0':
+        return WeightNorm.apply(v, g)
+    W = WeightNormShared.apply(v, g, hit)
+    W._recmv_entry = hit
+    return W
 
 
 def weight_norm(v, g):

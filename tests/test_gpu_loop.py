@@ -253,3 +253,40 @@ def test_schedule_switches_leave_the_iteration_unchanged(switch, monkeypatch):
             assert torch.equal(a, b)
         else:
             assert torch.allclose(a, b, rtol=0, atol=2e-5 * (float(a.abs().max()) + 1e-6) + 1e-7)
+
+
+def test_remesh_reuses_the_extraction_of_a_net_that_has_not_moved(monkeypatch):
+    """discretizeSDF keeps a net's (vertices, faces) while its parameters are unchanged (the body net throughout the optimisation
+    stage; every net in the large-pose stage): the cached result equals a fresh extraction bit for bit, a net that moved is extracted
+    again, a garment's cached vertices are handed out as a copy (they become SGD leaves), and fewer points are queried."""
+    loop = _loop()
+    ratio = {'sdfRatio': 1., 'deformerRatio': 0.5, 'renderRatio': 1.}
+    queried = []
+    real = type(loop.sdf).forward
+
+    def spy(self, input, *a, **k):
+        queried.append(int(input.shape[0]))
+        return real(self, input, *a, **k)
+    monkeypatch.setattr(type(loop.sdf), "forward", spy)
+    v1, f1 = loop.discretizeSDF(ratio, None, 0.0)
+    first = sum(queried)
+    queried.clear()
+    v2, f2 = loop.discretizeSDF(ratio, None, 0.0)                       # nothing moved: no query at all
+    assert sum(queried) == 0 and first > 0
+    monkeypatch.setenv("RECMV_REMESH_CACHE", "0")
+    v3, f3 = loop.discretizeSDF(ratio, None, 0.0)                       # a fresh extraction of everything
+    monkeypatch.delenv("RECMV_REMESH_CACHE")
+    for a, b, c in zip(v1, v2, v3):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    for a, b, c in zip(f1, f2, f3):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert v2[1].data_ptr() != v1[1].data_ptr() and v2[1].data_ptr() != loop._remesh_cache[1][1][0].data_ptr()
+    v2[1].add_(1.0)                                                     # a caller's in-place update does not reach the cache
+    with torch.no_grad():
+        dict(loop.garment_nets[0].named_parameters())["lin8.bias"].add_(0.01)      # the first garment's net moves (its radius)
+    queried.clear()
+    v4, f4 = loop.discretizeSDF(ratio, None, 0.0)
+    assert 0 < sum(queried) < first                                     # only that net's pyramid ran
+    assert torch.equal(v4[0], v1[0]) and torch.equal(v4[2], v1[2]) and not (v4[1].shape == v1[1].shape and torch.equal(v4[1], v1[1]))
+    v5, _ = loop.discretizeSDF(ratio, None, -0.01)                      # another iso level: another grid key, everything extracted
+    assert not (v5[0].shape == v1[0].shape and torch.equal(v5[0], v1[0]))

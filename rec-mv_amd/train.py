@@ -217,6 +217,10 @@ def main(argv=None, large_pose=False):
     assert torch.cuda.is_available(), "train.py needs a GPU (librecmv_hip.so has no CPU fallback)"
     device = torch.device('cuda', local_rank if world > 1 else (args.gpu_ids[0] if args.gpu_ids else 0))
     torch.cuda.set_device(device)
+    if os.environ.get("RECMV_ALLOC_CONF", "roundup_power2_divisions:4"):
+        # a re-mesh changes every vertex-sized shape by a percent or two: allocation sizes rounded up to a quarter of a power of two
+        # find the buffers the previous mesh left in torch's cache instead of going to hipMalloc (bench.py does the same; "" disables)
+        torch.cuda.memory._set_allocator_settings(os.environ.get("RECMV_ALLOC_CONF", "roundup_power2_divisions:4"))
     if args.save_folder is None:
         print('please set save-folder...')
         assert (False)

@@ -700,6 +700,7 @@ class HotLoop:
                                 offset_type=name)
                   for g_i, (gv, name) in enumerate(zip(self.garment_vs, self.garment_names))]
         self._def_cache = def_vs
+        self._def_params = (d_cond_list, poses, trans)       # the mask loss differentiates the same graph: the same gathers
         self._frag_cache = {}
         return def_vs
 
@@ -887,7 +888,14 @@ class HotLoop:
         if method != 'zbuff':
             raise NotImplementedError("fl_visible_method = %r: only 'zbuff' runs (in the reference as well: its 'surface' branch "
                                       "reads curve MESHES that deform_feature_line no longer builds)" % method)
-        d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
+        early = getattr(self, '_early', None)
+        if early is not None and early.get('frame_ids') is frame_ids and torch.device(self.device).type == 'cuda':
+            # only the curve parameters are differentiated here (see below): the per-frame tensors enter as constants — the detached
+            # gathers the ray pipeline prepared on the main stream (no second gather, no graph through codes / poses)
+            torch.cuda.current_stream(self.device).wait_event(early['ready'])
+            d_cond_list, poses, trans = [None] + list(early['d_cond']), early['poses'], early['trans']
+        else:
+            d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
         smpl_conds = [poses, trans]
         self._shared_def_vs = self._deform_garments(N, frame_ids, ratio)
         curves_now = self.inter_free_curve()                                             # [L,S,3]
@@ -962,10 +970,10 @@ class HotLoop:
         """OptimGarmentNetwork.py:841-981 (`defer_sdf_terms`: stop after the SGD step; the caller adds pc_sdf_terms()): deform the explicit garment meshes, splat the merged point cloud into one
         alpha-composited silhouette per garment (pcRender, :937), IoU loss against the dilated ground-truth masks +
         LBS-consistency term (compute_garment_pc_loss, :621-667), SGD step on the explicit vertices, |SDF| loss."""
-        d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
         conf = self.conf
         H, W = self.dataset.H, self.dataset.W
         def_vs = self._deform_garments(N, frame_ids, ratio)                                # :910
+        d_cond_list, poses, trans = self._def_params
         whole = torch.cat(def_vs, dim=1) if len(def_vs) > 1 else def_vs[0]                 # :925-935
         pc_render = raster.PointsRendererWithFrags_Split(cameras, (H, W), radius=self.pc_radius, points_per_pixel=50)
         garment_masks_list, _frags = pc_render(whole, split_size=self.garment_vs[0].shape[0])   # :937
@@ -1116,6 +1124,7 @@ class HotLoop:
             early = dict(d_cond=[c.detach() for c in d_cond_list[1:]], poses=poses.detach(), trans=trans.detach(),
                          cam_pos=cameras.cam_pos().detach().clone())
             utils.prepare_root_finder(list(self.garment_nets), self.deformer, [early['poses'], early['trans']], ratio)
+        early['frame_ids'] = frame_ids
         early['ready'] = torch.cuda.Event()
         early['ready'].record()
         self._early = early
@@ -1404,7 +1413,7 @@ class HotLoop:
         whose gradients are cleared after the curve branch (:1934; train.py passes it as a keyword, :324)."""
         N = frame_ids.numel()
         self.info = {}
-        self._def_cache, self._frag_cache = None, {}      # per-iteration caches (shared deformation / fragments)
+        self._def_cache, self._frag_cache, self._def_params = None, {}, None      # per-iteration caches (shared deformation / fragments)
         cameras = self._cameras()
         # a second camera object for the ray phases (its own autograd graph: the mask loss's backward frees the first
         # one's, :1036), built NOW so that the side streams of the ray pipeline never wait for the main stream's queue

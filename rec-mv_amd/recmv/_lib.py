@@ -55,9 +55,16 @@ def _load_build_module():
     return mod
 
 
+last_build_compiled = None     # names of the sources the last build() call of this process compiled (None: build() not called)
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile librecmv_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    return _load_build_module().build(force=force, verbose=verbose)
+    global last_build_compiled
+    mod = _load_build_module()
+    path = mod.build(force=force, verbose=verbose)
+    last_build_compiled = sorted(mod.COMPILED)
+    return path
 
 
 def _declare(lib):

@@ -83,3 +83,55 @@ def test_frames_at_counts_the_short_last_batch_of_an_epoch():
     three = [fake(10, 3, 3, r) for r in range(3)]            # 9 per step, 2 positions, the second holds 1 frame for 3 ranks
     assert three[0].iters_per_epoch() == 2
     assert [bench.frames_at(three[r], 1) for r in range(3)] == [1, 1, 1]
+
+
+def test_frozen_scene_round_trip_on_the_cpu_port(tmp_path):
+    """bench.save_scene / load_scene: the tensors the optimisation moves and Adam's two moments go through the file (matrices of
+    >= 2^14 elements as f16, moments as bf16), the loaded loop re-meshes from the file's SDF nets and continues right after that
+    re-mesh; a file that does not describe the loop is refused."""
+    import pytest
+    import torch
+    for p in (REPO / "rec-mv_amd", REPO):
+        if str(p) not in sys.path:
+            sys.path.insert(0, str(p))
+    import bench
+    from oracle import cpu_port
+    sys.path.insert(0, str(REPO / "tests"))
+    from test_loop_cpu import _tiny_loop
+    cpu_port.install()
+    try:
+        a = _tiny_loop(curves=True)
+        for it in range(3):
+            a.step(it)
+        path = str(tmp_path / "scene.pt")
+        bench.save_scene(a, path, 2, note="test")
+        b = _tiny_loop(curves=True, seed=5)                       # another seed: everything the file holds must be overwritten
+        it0 = bench.load_scene(b, path)
+        assert it0 == 3 and b.forward_time == 1 and b.opt_times == a.opt_times
+        ta, tb = bench._scene_tensors(a), bench._scene_tensors(b)
+        assert set(ta) == set(tb) and any(k.startswith("model.inter_free_curve.") for k in ta) and "dataset.poses" in ta
+        for k in ta:
+            x, y = ta[k].detach(), tb[k].detach()
+            if x.is_floating_point() and x.numel() >= (1 << 14):
+                assert torch.equal(y, x.half().float()), k        # the file's rounding, nothing else
+            else:
+                assert torch.equal(y, x), k
+        pa = [q for g in a.optimizer.param_groups for q in g['params']]
+        pb = [q for g in b.optimizer.param_groups for q in g['params']]
+        seen = 0
+        for qa, qb in zip(pa, pb):
+            if qa in a.optimizer.state:
+                sa, sb = a.optimizer.state[qa], b.optimizer.state[qb]
+                assert float(sb['step']) == float(sa['step']) == 3.0
+                assert torch.equal(sb['exp_avg'], sa['exp_avg'].bfloat16().float())
+                assert torch.equal(sb['exp_avg_sq'], sa['exp_avg_sq'].bfloat16().float())
+                seen += 1
+        assert seen > 20
+        assert [tuple(v.shape) for v in b.garment_vs] and all(v.requires_grad for v in b.garment_vs)
+        loss, rays = b.step(it0)                                  # and the loop runs on from there
+        assert torch.isfinite(loss) and rays > 0 and b.forward_time == 2
+        c = _tiny_loop(curves=False)                              # no curve branch: the file has tensors this loop lacks
+        with pytest.raises(SystemExit):
+            bench.load_scene(c, path)
+    finally:
+        cpu_port.uninstall()

@@ -1088,14 +1088,24 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
             log("extra leg %s failed: %r" % (fn.__name__, exc))
             return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300]), "_steps_run": 0}
 
+    def rewind():
+        """Every extra leg starts from the frozen scene again (its state used to be whatever the legs before it left: configs[2]'s
+        garment meshes were [50 264, 68 516] vertices in round 5's driver line and [83 840, 48 704] in round 4's)."""
+        if scene is not None:
+            return load_scene(loop, args.scene, allreduce)
+        return it
+
     leg_hc = leg_fl = None
     if not args.no_config2 and on_gpu:
+        it = rewind()
         leg_hc = leg(high_convergence_leg, loop, it, allreduce, world, device, sync)
-        it += leg_hc.pop("_steps_run")
+        it = rewind()
+        leg_hc.pop("_steps_run")
         leg_fl = leg(full_load_leg, loop, it, allreduce, world, device, sync)
-        it += leg_fl.pop("_steps_run")
+        leg_fl.pop("_steps_run")
     leg2 = None
     if not args.no_config2:
+        it = rewind()
         leg2 = leg(config2_leg, loop, it, allreduce, world, device)
         it += leg2.pop("_steps_run")
     if rank == 0:

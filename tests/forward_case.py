@@ -308,7 +308,8 @@ def run_trajectory(g, inputs, device, iters=None):
     from recmv.MCAcc import Seg3dLossless
     from recmv.loop import HotLoop
     T = int(g['losses'].shape[0]) if iters is None else iters
-    optNet, ds, opt, _, (sdfs, tr, sk, rn, curve) = build(g, device, inputs=inputs, trajectory=True, lr=TRAJ_LR)
+    optNet, ds, opt, _, (sdfs, tr, sk, rn, curve) = build(g, device, inputs=inputs, trajectory=True,
+                                                          lr=float(g['lr']) if 'lr' in g else TRAJ_LR)
     optNet.remesh_intersect = int(g['remesh_period']) if 'remesh_period' in g else 30
     dev = torch.device(device)
     losses, rays, verts_n, faces_equal = [], [], [], None
@@ -455,7 +456,10 @@ def _check_trajectory_device(out, g):
     n = len(out['losses'])
     total = int(g['losses'].shape[0])
     dev = out['loss_rel_dev']
-    assert max(dev[:4]) <= 1e-4, ("loss over the first four iterations", dev[:4])
+    # the first four iterations to 1e-4 — or to three times what the reference's own two runs differ by there (at the config's own
+    # learning rate, trajectory_lr.npz, a ray changes sides in the reference's second run at iteration 4: 8e-4 against itself)
+    own = [float(v) for v in g['self_loss_rel_dev'][:4]] if 'self_loss_rel_dev' in g else [0.0] * 4
+    assert all(d <= max(1e-4, 3.0 * o) for d, o in zip(dev[:4], own)), ("loss over the first four iterations", dev[:4], own)
     rays_eq = [bool(v) for v in g['self_rays_equal']]
     for i, (mine, ref) in enumerate(zip(out['rays'], out['rays_ref'])):
         if not rays_eq[i]:

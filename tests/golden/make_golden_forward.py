@@ -337,7 +337,7 @@ def _trajectory(KLASS, fake, datas, opt, root, T, Sref, names):
     return res
 
 
-def trajectory_fixture(name="trajectory", iters=None, remesh_period=30, resolutions=None, canonical=None):
+def trajectory_fixture(name="trajectory", iters=None, remesh_period=30, resolutions=None, canonical=None, lr=None):
     """trajectory.npz (35 iterations, the config's re-mesh period of 30) and trajectory_short.npz (14 iterations, re-mesh period 10:
     the same structure inside the window in which the reference's two runs still agree to rounding): the reference's loop run TWICE — with 4 and with 1 sgemm threads, i.e. two summation orders of the same
     arithmetic — so that the fixture carries the reference's OWN run-to-run envelope next to its results: the optimisation is a
@@ -345,6 +345,8 @@ def trajectory_fixture(name="trajectory", iters=None, remesh_period=30, resoluti
     implementation can be held to is the north_star's end-to-end bound (canonical-mesh Chamfer <= 1e-4) plus agreement at rounding
     level while the two reference runs still agree with each other."""
     iters = fc.TRAJ_ITERS if iters is None else iters
+    if lr is not None:                                 # (trajectory_lr: the main optimiser at the config's own learning rate)
+        fc.TRAJ_LR = float(lr)
     if resolutions is not None:                        # (trajectory_c2: re-mesh and canonical extraction on another pyramid)
         fc.RESOLUTIONS, fc.TRAJ_CANONICAL_RES = list(resolutions), list(canonical or resolutions)
     torch.set_num_threads(4 if resolutions is None else 8)
@@ -352,6 +354,7 @@ def trajectory_fixture(name="trajectory", iters=None, remesh_period=30, resoluti
     torch.set_num_threads(1 if resolutions is None else 3)
     b = main(trajectory=iters, remesh_period=remesh_period)
     a['remesh_period'] = torch.tensor(remesh_period)
+    a['lr'] = torch.tensor(fc.TRAJ_LR, dtype=torch.float64)
     if resolutions is not None:
         a['resolutions'], a['canonical_res'] = torch.tensor(fc.RESOLUTIONS), torch.tensor(fc.TRAJ_CANONICAL_RES)
     la, lb = a['losses'], b['losses']
@@ -374,6 +377,11 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "trajectory_c2":   # (the C2-sized pyramid: tens of minutes of host time)
         trajectory_fixture("trajectory_c2", fc.TRAJ_C2_ITERS, fc.TRAJ_C2_REMESH, fc.TRAJ_C2_RES, fc.TRAJ_C2_RES)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "trajectory_lr":
+        # 14 iterations (re-mesh at the 10th) with Adam at the reference config's own train.learning_rate = 1e-4
+        # (configs/people_snapshot/female-3-casual.conf:20) instead of a fifth of it
+        trajectory_fixture("trajectory_lr", fc.TRAJ_SHORT_ITERS, fc.TRAJ_SHORT_REMESH, lr=1e-4)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "trajectory_short":
         trajectory_fixture("trajectory_short", fc.TRAJ_SHORT_ITERS, fc.TRAJ_SHORT_REMESH)

@@ -59,8 +59,11 @@ class Intersect_Free_Curve(nn.Module):
         with torch.no_grad():
             return self.forward()
 
-    def regularization(self, fl_masks):                                                             # :120-141
-        cano_verts = self.forward()
+    def regularization(self, fl_masks, cano_verts=None):                                            # :120-141
+        """`cano_verts`: the curves of this iteration when the caller has them already (`self.forward()` otherwise, as the
+        reference does on every call)."""
+        if cano_verts is None:
+            cano_verts = self.forward()
         used_flag = (fl_masks.sum() > 0).float()
         center_loss = used_flag * abs(cano_verts.mean(1, keepdim=True) - self.cano_verts_center).sum()
         diff_a = cano_verts[:, :-1, :] - cano_verts[:, 1:, :]

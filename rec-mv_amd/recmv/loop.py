@@ -868,7 +868,18 @@ class HotLoop:
         weights = [self.dataset.fl_weights[n] for n in names]
         fl_loss = fl.fl_proj_loss(screen_list, gt_list, visible_masks, weights) * (
             conf.get_float('fl_weight.weight') if 'fl_weight.weight' in conf else 1.)
-        reg = self.inter_free_curve.regularization(fl_masks)
+        # The regulariser does not depend on the garment: its curvature term is a function of the curve parameters alone and its
+        # centre term is multiplied by zero whatever `fl_masks` says (garment_structure.py:141) — the reference evaluates it once per
+        # garment (and the curves once more inside each time); here once per iteration on the curves project_2d_loss already has.
+        # The same graph node enters every garment's loss: same values, same gradients (g + g is 2 g exactly).
+        cur = getattr(self, '_curves_now', None)
+        if cur is None:                                 # (called on its own: the reference's form)
+            reg = self.inter_free_curve.regularization(fl_masks)
+        else:
+            hit = getattr(self, '_curve_reg', None)
+            if hit is None or hit[0] is not cur:
+                hit = self._curve_reg = (cur, self.inter_free_curve.regularization(fl_masks, cano_verts=cur))
+            reg = hit[1]
         center = reg['center_offset'] * (conf.get_float('alpha_weight.center_weight') if 'alpha_weight' in conf else 1.)
         diff = reg['diff_a_loss'] * (conf.get_float('alpha_weight.diff_weight') if 'alpha_weight' in conf else 1.)
         self.info['fl_loss']['{}_project loss'.format(garment_name)] = fl_loss.detach()
@@ -898,7 +909,8 @@ class HotLoop:
             d_cond_list, poses, trans, _ = self.get_grad_parameters(frame_ids, self.device)
         smpl_conds = [poses, trans]
         self._shared_def_vs = self._deform_garments(N, frame_ids, ratio)
-        curves_now = self.inter_free_curve()                                             # [L,S,3]
+        curves_now = self._curves_now = self.inter_free_curve()                          # [L,S,3]
+        self._curve_reg = None
         fl_vs_dict = {n: curves_now[i] for i, n in enumerate(self.fl_names)}
         gt_all, fl_mask_all = self._gt_feature_lines(frame_ids)                          # [N, L*M, 2], [N, L]
         M = gt_all.shape[1] // len(self.fl_names)
@@ -943,6 +955,7 @@ class HotLoop:
         if getattr(self, '_allreduce', None) is not None:
             self._allreduce(list(self.inter_free_curve.parameters()))     # curve gradients are shared across ranks (§8e)
         self.fl_optimizer.step()
+        self._curves_now = self._curve_reg = None          # (the curves have moved: this iteration's graph is spent)
         self.info['fl_loss']['total'] = loss.detach()
 
     # ------------------------------------------------------------------------------------------ mask loss
@@ -1508,7 +1521,8 @@ class HotLoop:
                 self._record_handover(main, [render_loss] if torch.is_tensor(render_loss) else [])
             total_loss = total_loss + render_loss
             with self._phase('dct'):
-                d_cond_list, poses, trans, rendcond = self.get_grad_parameters(frame_ids, self.device)
+                # (the pose prior gathers its own 30-frame windows; of the batch's poses / translations it reads `requires_grad` only)
+                _, poses, trans = self._def_params if self._def_params is not None else self.get_grad_parameters(frame_ids, self.device)[:3]
                 total_loss = total_loss + self.dct_poses_loss(poses, trans, frame_ids, N)
         self.forward_time += 1
         return total_loss

@@ -69,3 +69,31 @@ def test_round_4_driver_line_carries_the_new_blocks():
     assert "r04_pmc_loop.json" in d["roofline"]["traffic_source"] or "r03_pmc_loop.json" in d["roofline"]["traffic_source"]
     two = json.loads((PROFILES / "r04_bench_line_2ranks_one_gpu_launcher.json").read_text().strip().splitlines()[-1])
     assert two["n_gpus"] == 2 and two["config"]["replicas_bit_identical"] is True and len(two["config"]["per_rank_ms_per_step"]) == 2
+
+
+def test_round_6_driver_line_is_on_the_frozen_scene():
+    """profiles/r06_bench_line_driver_command.json: the workload comes from the committed scene file and is named at the top level
+    (`matrix_tflop_per_step`, `mc_vertices`, `rays_per_iter`), `roofline.traffic` and `alg_bytes` describe the SAME launches, the
+    over-unity sampler fraction is gone, the experimental matrix mode is off the line, configs[2] carries its re-mesh split."""
+    d = json.loads((PROFILES / "r06_bench_line_driver_command.json").read_text().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "scene", "matrix_tflop_per_step", "mc_vertices", "rays_per_iter"):
+        assert key in d, key
+    assert d["scene"]["file"] == "configs/synthetic/bench_scene_v1.pt" and (PROFILES.parent / d["scene"]["file"]).is_file()
+    assert d["dtype"] == "f32" and d["vs_baseline"] is None and d["n_gpus"] == 1 and "alt_mode" not in d
+    assert 7.0 < d["matrix_tflop_per_step"] < 9.0 and len(d["mc_vertices"]) == 2 and d["rays_per_iter"] > 5000
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.02 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=2e-3)
+    assert r["traffic"] == r["traffic_large_launches"]["traffic_bytes_per_launch"]          # same launch subset as alg_bytes
+    assert 1.0 < r["traffic"] / r["alg_bytes"] < 2.5 and "r06_pmc_loop.json" in r["traffic_source"]
+    assert all("frac_survey_8d" not in k for k in d["hbm_kernels"])
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and 0 < c["value"] < d["value"]
+    split = d["config2"]["split"]
+    for key in ("remesh_ms", "plain_ms", "pyramid_query_ms", "seg3d_bookkeeping_ms", "marching_cubes_ms", "mesh_handover_ms"):
+        assert split[key] >= 0, key
+    assert abs(split["remesh_ms"] + split["plain_ms"] - d["config2"]["ms_per_step"]) < 0.5
+    assert d["remesh"]["remesh_steps_in_timed_region"] >= 1 and "device_allocations" in d["remesh"]
+    two = json.loads((PROFILES / "r06_bench_line_2ranks_one_gpu.json").read_text().strip().splitlines()[-1])
+    assert two["n_gpus"] == 2 and two["config"]["replicas_bit_identical"] is True and two["scene"]["file"] == d["scene"]["file"]

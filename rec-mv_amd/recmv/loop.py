@@ -1426,6 +1426,7 @@ class HotLoop:
         whose gradients are cleared after the curve branch (:1934; train.py passes it as a keyword, :324)."""
         N = frame_ids.numel()
         self.info = {}
+        self._tail = None
         self._def_cache, self._frag_cache, self._def_params = None, {}, None      # per-iteration caches (shared deformation / fragments)
         cameras = self._cameras()
         # a second camera object for the ray phases (its own autograd graph: the mask loss's backward frees the first
@@ -1513,17 +1514,31 @@ class HotLoop:
                 # vertices — still unqueued.  curve_aware_loss reads the curves after their AdamW step: the wait sits in front of it
                 total_loss = total_loss + self.pc_sdf_terms(
                     ratio, before_curve_term=(lambda: main.wait_event(curve_done)) if curve_done is not None else None)
+            # The terms that are still to be differentiated — render loss + pose prior — are summed ON THE RAY STREAM and kept
+            # (`_tail`): step() starts their backward from that stream as soon as the render loss exists.  Summed into the main
+            # stream's total first (rounds 2-5), the backward's root sat in the main stream's queue behind the |SDF| terms' large
+            # products and the iteration's tail (render backward + implicit differentiation, ~20 ms of small launches) started only
+            # when those had drained.  Same nodes, same accumulation order; RECMV_TAIL_STREAM=0: the old form (A/B).
+            tail_on_ray = cuda and os.environ.get('RECMV_TAIL_STREAM', '1') != '0'
             with on(s_ray), self._phase('render_loss_fwd'):
                 s_ray.wait_event(getattr(self, '_sgd_done', None))
                 render_loss = self.surface_render_loss(N, cameras_rays, frame_ids, ratio, checks, init_ps_list, samples)
+                if tail_on_ray:
+                    _, poses, trans = self._def_params if self._def_params is not None else self.get_grad_parameters(frame_ids, self.device)[:3]
+                    tail = render_loss + self.dct_poses_loss(poses, trans, frame_ids, N)
+                    self._tail = (tail, s_ray) if torch.is_tensor(tail) and tail.requires_grad else None
             main.wait_stream(s_ray)
-            if cuda:
-                self._record_handover(main, [render_loss] if torch.is_tensor(render_loss) else [])
-            total_loss = total_loss + render_loss
-            with self._phase('dct'):
-                # (the pose prior gathers its own 30-frame windows; of the batch's poses / translations it reads `requires_grad` only)
-                _, poses, trans = self._def_params if self._def_params is not None else self.get_grad_parameters(frame_ids, self.device)[:3]
-                total_loss = total_loss + self.dct_poses_loss(poses, trans, frame_ids, N)
+            if tail_on_ray:
+                self._record_handover(main, [tail] if torch.is_tensor(tail) else [])
+                total_loss = total_loss + tail        # (a caller's plain `loss.backward()` still works — from the main stream's queue)
+            else:
+                if cuda:
+                    self._record_handover(main, [render_loss] if torch.is_tensor(render_loss) else [])
+                total_loss = total_loss + render_loss
+                with self._phase('dct'):
+                    # (the pose prior gathers its own 30-frame windows; of the batch's poses / translations it reads `requires_grad` only)
+                    _, poses, trans = self._def_params if self._def_params is not None else self.get_grad_parameters(frame_ids, self.device)[:3]
+                    total_loss = total_loss + self.dct_poses_loss(poses, trans, frame_ids, N)
         self.forward_time += 1
         return total_loss
 
@@ -1711,6 +1726,40 @@ class HotLoop:
         self.optimizer = torch.optim.Adam(self.dataset.learnable_weights() + params, lr=lr)
         return self.optimizer
 
+    def backward(self, loss):
+        """`loss.backward()` for the loss forward() has just returned (train.py:325) — started from the RAY stream when forward left
+        the still-undifferentiated terms there (`_tail`: render loss + pose prior; the |SDF| terms were differentiated inside forward,
+        _backward_early): the same nodes and the same accumulation order as `loss.backward()`, whose root would wait in the main
+        stream's queue behind the |SDF| terms' large products.  The main stream joins behind it."""
+        tail, self._tail = getattr(self, '_tail', None), None
+        if tail is not None and tail[0].requires_grad:
+            # The |SDF| terms' backward may still be adding to the shared `.grad`s on the main stream: the tail's gradients are taken
+            # as VALUES on the ray stream (autograd.grad: nothing accumulated there) and added on the main stream behind the join —
+            # one addition per leaf, in the order (mask loss) + (|SDF| terms) + (render loss + pose prior) the plain backward has.
+            main = torch.cuda.current_stream(self.device)
+            leaves = [q for q in self.shared_parameters() if q.requires_grad]
+            leaves += [t for t in (getattr(self, 'TmpPs', None) or []) if t is not None and t.requires_grad]
+            with torch.cuda.stream(tail[1]):
+                grads = torch.autograd.grad(tail[0], leaves, allow_unused=True)
+            main.wait_stream(tail[1])
+            have_t, have_g, fresh = [], [], []
+            for q, g in zip(leaves, grads):
+                if g is None:
+                    continue
+                g.record_stream(main)
+                if q.grad is None:
+                    fresh.append((q, g))
+                else:
+                    have_t.append(q.grad)
+                    have_g.append(g)
+            with torch.no_grad():
+                if have_t:
+                    torch._foreach_add_(have_t, have_g)
+                for q, g in fresh:
+                    q.grad = g
+        elif torch.is_tensor(loss) and loss.requires_grad:
+            loss.backward()
+
     def step(self, it, allreduce=None, frame_ids=None):
         """train.py:317-328.  `allreduce(list_of_tensors)` is called on the gradients before each optimizer step
         when frames are sharded over ranks."""
@@ -1719,8 +1768,7 @@ class HotLoop:
         self._allreduce = allreduce
         loss = HotLoop.forward(self, frame_ids, ratio)      # (the facade subclass overrides forward(datas, ...))
         with self._phase('backward'):
-            if loss.requires_grad:                   # (the |SDF| terms were differentiated inside forward: _backward_early)
-                loss.backward()
+            self.backward(loss)
         pending = []
         if allreduce is not None and hasattr(allreduce, 'start'):
             # the colour net and the per-frame colour codes are final after the backward (the implicit differentiation below adds to

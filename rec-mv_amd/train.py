@@ -347,8 +347,7 @@ def main(argv=None, large_pose=False):
             ratio['deformerRatio'] = optNet.opt_times / 2500. + 0.5
             ratio['renderRatio'] = 1.
             loss = optNet(outs, sample_pix_num, ratio, frame_ids, debug_root, global_optimizer=optimizer)
-            if loss.requires_grad:                                                           # (train.py:325; the |SDF| terms of the mask loss were
-                loss.backward()                                                              #  differentiated inside forward, HotLoop._backward_early)
+            optNet.backward(loss)           # train.py:325 `loss.backward()`, started from the stream the open terms live on (HotLoop.backward)
             optNet.propagateTmpPsGrad(frame_ids, ratio)
             if allreduce is not None:
                 allreduce(optNet.shared_parameters())            # frame-sharded ranks: mean of the shared gradients

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B on ONE box: this tree against the round-5 tree (105ce1b, unpacked under _ab_r05/ with bench.load_scene patched in), both timing
+# A/B on ONE box: this tree against the round-5 tree (105ce1b, unpacked under _ab_r05/ by tools/make_ab_r05.sh with bench.load_scene patched in), both timing
 # the SAME frozen scene (configs/synthetic/bench_scene_v1.pt), runs taking turns.   bash tools/ab_r05.sh [rounds] [outdir]
 R=${1:-3}; O=${2:-gpurun_out/ab_r05}; mkdir -p $O
 Q="--steps 20 --warmup 5 --no-cpu-baseline --no-config2 --no-mc --no-hbm-kernels --no-alt-mode"

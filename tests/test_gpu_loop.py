@@ -290,3 +290,38 @@ def test_remesh_reuses_the_extraction_of_a_net_that_has_not_moved(monkeypatch):
     assert torch.equal(v4[0], v1[0]) and torch.equal(v4[2], v1[2]) and not (v4[1].shape == v1[1].shape and torch.equal(v4[1], v1[1]))
     v5, _ = loop.discretizeSDF(ratio, None, -0.01)                      # another iso level: another grid key, everything extracted
     assert not (v5[0].shape == v1[0].shape and torch.equal(v5[0], v1[0]))
+
+
+def test_backward_from_the_ray_stream_reaches_every_leaf_the_plain_backward_would():
+    """HotLoop.backward takes the open terms' gradients as values for a LIST of leaves (the optimiser's tensors + the surface points) —
+    a leaf of the tail's graph outside that list would silently get no gradient.  Walk the graph: every tensor an AccumulateGrad node
+    of the tail points at is in the list."""
+    loop = _loop()
+    loop.step(0)
+    frame_ids = loop.frame_batch(1)
+    ratio = {'sdfRatio': 1., 'deformerRatio': 0.5, 'renderRatio': 1.}
+    loop._allreduce = None
+    from recmv.loop import HotLoop
+    HotLoop.forward(loop, frame_ids, ratio)
+    assert loop._tail is not None, "on the device the open terms stay on the ray stream"
+    listed = {id(q) for q in loop.shared_parameters() if q.requires_grad} | {id(t) for t in loop.TmpPs if t is not None}
+    seen, stack, found = set(), [loop._tail[0].grad_fn], []
+    while stack:
+        node = stack.pop()
+        if node is None or node in seen:        # (the node objects themselves: ids of freed wrappers are recycled)
+            continue
+        seen.add(node)
+        if hasattr(node, "variable"):
+            found.append(node.variable)
+        stack.extend(fn for fn, _ in node.next_functions)
+    assert len(found) > 20 and len(seen) > 200
+    # (what stays outside the list: the per-call sample points — eikonal points, the regulariser's points — that only carry
+    # requires_grad for the jets' Jacobians; nobody reads their .grad, and not asking for it spares the input-gradient passes)
+    owned = {id(q) for m in (loop.garment_nets, loop.sdf, loop.deformer, loop.netRender) for q in m.parameters()}
+    owned |= {id(q) for q in loop.dataset.learnable_weights()}
+    missing = [tuple(v.shape) for v in found if id(v) not in listed and id(v) in owned]
+    assert not missing, "parameters in the tail's graph that HotLoop.backward does not differentiate: %s" % missing
+    assert sum(1 for v in found if id(v) in listed) > 20
+    loop.backward(None)
+    torch.cuda.synchronize()
+    assert all(t.grad is not None for t in loop.TmpPs if t is not None)

@@ -504,6 +504,16 @@ int recmv_lbs_vjp_input(const float* ps, const int64_t* frame, int64_t P, const 
 int recmv_lbs_vjp_params_stage(const float* ps, const int64_t* frame, int64_t P, int64_t B,
                                const recmv_lbs_grid* grid, const float* g_d, float* W, float* Q, float* Gs,
                                void* stream);
+/* The skinning stage as a jet (ABI v9): v [P,3] as recmv_lbs_forward and J [P,9] = d v / d p (row i = gradient of v_i) in one
+ * launch — replaces LBSkinner.forward + the three create_graph autograd.grad calls of utils/utils.py:133-156 (compute_Jacobian) at
+ * the converged ray points — and its first-order reverse: g_p [P,3] per point, the parameter side staged as W4 [4P,24],
+ * Q4 [4P, B*12], Gs [P, B*3] for gA[b,j,i,k] = recmv_gemm_tn(W4, Q4)[j, b*12 + 4i + k], gtrans = recmv_colsum(Gs).  gv / gJ: the
+ * cotangents of v and J, either may be NULL (zeros). */
+int recmv_lbs_jet_forward(const float* ps, const int64_t* frame, int64_t P, const float* A, const float* trans,
+                          int64_t B, const recmv_lbs_grid* grid, float* v, float* J, void* stream);
+int recmv_lbs_jet_backward_stage(const float* ps, const int64_t* frame, int64_t P, const float* A, int64_t B,
+                                 const recmv_lbs_grid* grid, const float* gv, const float* gJ, float* g_p, float* W4,
+                                 float* Q4, float* Gs, void* stream);
 int recmv_rootfind_update(float* p, const float* f, const float* gf, const float* loss2, const float* angle,
                           const float* gd, uint8_t* unfinished, int32_t* counter, int64_t P, float dthreshold,
                           float athreshold, float w1, float w2, int do_update, void* stream);

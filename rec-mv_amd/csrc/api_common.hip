@@ -12,7 +12,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace recmv
 
-extern "C" int recmv_abi_version(void) { return 8; }
+extern "C" int recmv_abi_version(void) { return 9; }
 extern "C" const char* recmv_last_error(void) { return recmv::g_err; }
 
 // 1 when EVERY kernel of this library was built without packed-f32 VALU instructions (rec-mv_amd/build.py under

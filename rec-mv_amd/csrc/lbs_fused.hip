@@ -224,6 +224,197 @@ __global__ __launch_bounds__(kBlk) void lbs_vjp_params_stage_kernel(const float*
   }
 }
 
+// ---- the skinning stage as a JET: value and d v / d p in one pass, first-order reverse in one pass ----------------------------
+// The render loss needs v(p) = T(p) [p;1] + trans and J(p) = dv/dp at the converged ray points and differentiates both once
+// (utils/utils.py:133-156 builds J with three create_graph autograd.grad calls through sampler -> blend -> transform, ~50 launches,
+// and the loss's backward walks the double-backward graph of all of it, ~150 more).  With w_j(p) the trilinear blend weights,
+// y_j = A_j [p;1]:      v = sum_j w_j y_j + trans        J[i][k] = sum_j w_j A_j[i][k] + sum_j (dw_j/dp_k) y_j[i]
+// and the reverse of (gv, gJ) needs the mixed second derivatives d2w_j / dp_k dp_m (k != m; the trilinear weight is linear in each
+// coordinate) — all of it per point from the same 8 corner records.  dw/dp_k = (sum over corners of +-f f vol) * clip mask * size/2 *
+// scale, as the sampler's backward forms it (GridSamplerMineKernel.cu:534-545).
+struct JetW {
+  float w[kJ];         // w_j
+  float d[3][kJ];      // dw_j / dp_k
+};
+
+__device__ __forceinline__ void jet_scales(const Cell<float>& c, const LbsGeom& G, float* m) {
+  m[0] = c.mx * (float)((double)((float)G.W) / 2.) * G.sx;
+  m[1] = c.my * (float)((double)((float)G.H) / 2.) * G.sy;
+  m[2] = c.mz * (float)((double)((float)G.D) / 2.) * G.sz;
+}
+
+__global__ __launch_bounds__(kBlk) void lbs_jet_forward_kernel(
+    const float* __restrict__ ps, const int64_t* __restrict__ frame, const float* __restrict__ A,
+    const float* __restrict__ trans, int B, const float* __restrict__ vol, LbsGeom G, int64_t P,
+    float* __restrict__ v_out, float* __restrict__ J_out) {
+  extern __shared__ __attribute__((aligned(16))) float A_s[];
+  stage_A(A, B, A_s);
+  for (int64_t i = (int64_t)blockIdx.x * kBlk + threadIdx.x; i < P; i += (int64_t)gridDim.x * kBlk) {
+    const float q[3] = {ps[3 * i], ps[3 * i + 1], ps[3 * i + 2]};
+    const int b = (int)frame[i];
+    const Cell<float> c = make_cell<float>((q[0] - G.cx) * G.sx, (q[1] - G.cy) * G.sy, (q[2] - G.cz) * G.sz, G.W, G.H, G.D);
+    JetW a;
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) a.w[j] = a.d[0][j] = a.d[1][j] = a.d[2][j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      RECMV_CORNER_BITS(k);
+      if (c.in_x[bx] && c.in_y[by] && c.in_z[bz]) {
+        float v[kJ];
+        load24(vol + (((int64_t)(c.z0 + bz) * G.H + (c.y0 + by)) * G.W + (c.x0 + bx)) * kJ, v);
+        const float wk = c.fx[bx] * c.fy[by] * c.fz[bz];
+        const float tx = bx ? c.fy[by] * c.fz[bz] : -(c.fy[by] * c.fz[bz]);
+        const float ty = by ? c.fx[bx] * c.fz[bz] : -(c.fx[bx] * c.fz[bz]);
+        const float tz = bz ? c.fx[bx] * c.fy[by] : -(c.fx[bx] * c.fy[by]);
+#pragma unroll
+        for (int j = 0; j < kJ; ++j) {
+          a.w[j] = fma(v[j], wk, a.w[j]);
+          a.d[0][j] = fma(v[j], tx, a.d[0][j]);
+          a.d[1][j] = fma(v[j], ty, a.d[1][j]);
+          a.d[2][j] = fma(v[j], tz, a.d[2][j]);
+        }
+      }
+    }
+    float m[3];
+    jet_scales(c, G, m);
+    float T[12], S[9];                 // T = sum_j w_j A_j (rows 0..2), S[i][k] = sum_j y_j[i] * (raw dw_j/dk)
+#pragma unroll
+    for (int r = 0; r < 12; ++r) T[r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) S[r] = 0.f;
+    const float* Ab = A_s + b * kJ * 12;
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) {
+      const float* aj = Ab + j * 12;
+#pragma unroll
+      for (int r = 0; r < 12; ++r) T[r] = fma(a.w[j], aj[r], T[r]);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float y = aj[4 * r] * q[0] + aj[4 * r + 1] * q[1] + aj[4 * r + 2] * q[2] + aj[4 * r + 3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) S[3 * r + k] = fma(a.d[k][j], y, S[3 * r + k]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      v_out[3 * i + r] = T[4 * r] * q[0] + T[4 * r + 1] * q[1] + T[4 * r + 2] * q[2] + T[4 * r + 3] + trans[3 * b + r];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) J_out[9 * i + 3 * r + k] = T[4 * r + k] + S[3 * r + k] * m[k];
+    }
+  }
+}
+
+// Reverse of the jet: cotangents gv [P,3] of v and gJ [P,9] of J (either may be NULL = zeros) ->
+//   g_p [P,3]                                                      (per point, written here)
+//   gA[b,j,i,k], gtrans[b,i]                                       (sums over the points of a frame, staged for two fixed-order reductions)
+// With D_jk = dw_j/dp_k:   dL/dA_j[i][k] = (gv_i w_j + sum_k' gJ[i][k'] D_jk') [p;1][k] + (k < 3) gJ[i][k] w_j
+// is a sum of four separable terms, so  gA[j, b*12 + 4i + k] = recmv_gemm_tn(W4, Q4)  with four rows per point:
+//   W4[4p + 0] = w,        Q4[4p + 0][b-block] = gv_i [p;1][k] + (k < 3) gJ[i][k]
+//   W4[4p + 1 + k'] = D_k', Q4[4p + 1 + k'][b-block] = gJ[i][k'] [p;1][k]
+// and gtrans = recmv_colsum(Gs), Gs [P, B*3] = gv in the point's frame block.
+__global__ __launch_bounds__(kBlk) void lbs_jet_backward_kernel(
+    const float* __restrict__ ps, const int64_t* __restrict__ frame, const float* __restrict__ A, int B,
+    const float* __restrict__ vol, LbsGeom G, int64_t P, const float* __restrict__ gv_in,
+    const float* __restrict__ gJ_in, float* __restrict__ g_p, float* __restrict__ W4, float* __restrict__ Q4,
+    float* __restrict__ Gs) {
+  extern __shared__ __attribute__((aligned(16))) float A_s[];
+  stage_A(A, B, A_s);
+  for (int64_t i = (int64_t)blockIdx.x * kBlk + threadIdx.x; i < P; i += (int64_t)gridDim.x * kBlk) {
+    const float q[3] = {ps[3 * i], ps[3 * i + 1], ps[3 * i + 2]};
+    const int b = (int)frame[i];
+    float gv[3], gJ[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) gv[r] = gv_in ? gv_in[3 * i + r] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) gJ[r] = gJ_in ? gJ_in[9 * i + r] : 0.f;
+    const Cell<float> c = make_cell<float>((q[0] - G.cx) * G.sx, (q[1] - G.cy) * G.sy, (q[2] - G.cz) * G.sz, G.W, G.H, G.D);
+    JetW a;
+    float h[3][kJ];                    // raw mixed second derivatives: h[0] = xy, h[1] = xz, h[2] = yz
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) {
+      a.w[j] = a.d[0][j] = a.d[1][j] = a.d[2][j] = 0.f;
+      h[0][j] = h[1][j] = h[2][j] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      RECMV_CORNER_BITS(k);
+      if (c.in_x[bx] && c.in_y[by] && c.in_z[bz]) {
+        float v[kJ];
+        load24(vol + (((int64_t)(c.z0 + bz) * G.H + (c.y0 + by)) * G.W + (c.x0 + bx)) * kJ, v);
+        const float wk = c.fx[bx] * c.fy[by] * c.fz[bz];
+        const float tx = bx ? c.fy[by] * c.fz[bz] : -(c.fy[by] * c.fz[bz]);
+        const float ty = by ? c.fx[bx] * c.fz[bz] : -(c.fx[bx] * c.fz[bz]);
+        const float tz = bz ? c.fx[bx] * c.fy[by] : -(c.fx[bx] * c.fy[by]);
+        const float hxy = (bx == by) ? c.fz[bz] : -c.fz[bz];
+        const float hxz = (bx == bz) ? c.fy[by] : -c.fy[by];
+        const float hyz = (by == bz) ? c.fx[bx] : -c.fx[bx];
+#pragma unroll
+        for (int j = 0; j < kJ; ++j) {
+          a.w[j] = fma(v[j], wk, a.w[j]);
+          a.d[0][j] = fma(v[j], tx, a.d[0][j]);
+          a.d[1][j] = fma(v[j], ty, a.d[1][j]);
+          a.d[2][j] = fma(v[j], tz, a.d[2][j]);
+          h[0][j] = fma(v[j], hxy, h[0][j]);
+          h[1][j] = fma(v[j], hxz, h[1][j]);
+          h[2][j] = fma(v[j], hyz, h[2][j]);
+        }
+      }
+    }
+    float m[3];
+    jet_scales(c, G, m);
+    const float mh[3] = {m[0] * m[1], m[0] * m[2], m[1] * m[2]};
+    float gq[3] = {0.f, 0.f, 0.f};
+    const float* Ab = A_s + b * kJ * 12;
+    float* w4 = W4 + i * (int64_t)(4 * kJ);
+#pragma unroll
+    for (int j = 0; j < kJ; ++j) {
+      const float* aj = Ab + j * 12;
+      const float D[3] = {a.d[0][j] * m[0], a.d[1][j] * m[1], a.d[2][j] * m[2]};
+      const float Hxy = h[0][j] * mh[0], Hxz = h[1][j] * mh[1], Hyz = h[2][j] * mh[2];
+      w4[j] = a.w[j];
+      w4[kJ + j] = D[0];
+      w4[2 * kJ + j] = D[1];
+      w4[3 * kJ + j] = D[2];
+      float cgy[3] = {0.f, 0.f, 0.f};       // c_k = sum_i gJ[i][k] y_i
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float y = aj[4 * r] * q[0] + aj[4 * r + 1] * q[1] + aj[4 * r + 2] * q[2] + aj[4 * r + 3];
+        // sum_i gv_i J[i][m]  with  J[i][m] = w_j A_j[i][m] + D_jm y_i  (this joint's share)
+        // sum_ik gJ[i][k] (D_jm A_j[i][k] + D_jk A_j[i][m])
+        const float gja = gJ[3 * r] * aj[4 * r] + gJ[3 * r + 1] * aj[4 * r + 1] + gJ[3 * r + 2] * aj[4 * r + 2];
+        const float gjd = gJ[3 * r] * D[0] + gJ[3 * r + 1] * D[1] + gJ[3 * r + 2] * D[2];
+#pragma unroll
+        for (int mm = 0; mm < 3; ++mm)
+          gq[mm] += gv[r] * (a.w[j] * aj[4 * r + mm] + D[mm] * y) + D[mm] * gja + gjd * aj[4 * r + mm];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cgy[k] = fma(gJ[3 * r + k], y, cgy[k]);
+      }
+      // sum_ik gJ[i][k] H_j,km y_i = sum_{k != m} H_km c_k
+      gq[0] += Hxy * cgy[1] + Hxz * cgy[2];
+      gq[1] += Hxy * cgy[0] + Hyz * cgy[2];
+      gq[2] += Hxz * cgy[0] + Hyz * cgy[1];
+    }
+    g_p[3 * i] = gq[0];
+    g_p[3 * i + 1] = gq[1];
+    g_p[3 * i + 2] = gq[2];
+    const float ph[4] = {q[0], q[1], q[2], 1.f};
+    float* q4 = Q4 + i * (int64_t)(4 * B * 12);
+    float* gs = Gs + i * (int64_t)(B * 3);
+    for (int bb = 0; bb < B; ++bb) {
+      const float on = bb == b ? 1.f : 0.f;
+#pragma unroll
+      for (int r = 0; r < 12; ++r) {
+        const int ii = r >> 2, k = r & 3;
+        q4[bb * 12 + r] = on * (gv[ii] * ph[k] + (k < 3 ? gJ[3 * ii + k] : 0.f));
+#pragma unroll
+        for (int kp = 0; kp < 3; ++kp) q4[(1 + kp) * (B * 12) + bb * 12 + r] = on * (gJ[3 * ii + kp] * ph[k]);
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) gs[bb * 3 + r] = on * gv[r];
+    }
+  }
+}
+
 // One step of utils/FindSurfacePs.py:316-351 on all rays.
 __global__ __launch_bounds__(kBlk) void rootfind_update_kernel(float* __restrict__ p, const float* __restrict__ f,
                                                                const float* __restrict__ gf,
@@ -375,6 +566,38 @@ extern "C" int recmv_lbs_vjp_params_stage(const float* ps, const int64_t* frame,
   hipLaunchKernelGGL(lbs_vjp_params_stage_kernel, dim3(stream_grid(P, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, ps,
                      frame, (int)B, grid->volume, to_geom(grid), P, g_d, W, Q, Gs);
   return check_launch("lbs_vjp_params_stage");
+}
+
+// Skinning jet (value + d v / d p) and its first-order reverse; see the kernels.  v [P,3], J [P,9] (row i = grad of v_i).
+extern "C" int recmv_lbs_jet_forward(const float* ps, const int64_t* frame, int64_t P, const float* A,
+                                     const float* trans, int64_t B, const recmv_lbs_grid* grid, float* v, float* J,
+                                     void* stream) {
+  RECMV_REQUIRE(P >= 0 && B >= 1 && B <= 128, "lbs_jet_forward: bad size (P=%lld, B=%lld)", (long long)P, (long long)B);
+  if (P == 0) return RECMV_OK;
+  int rc = check_geom(grid);
+  if (rc) return rc;
+  RECMV_REQUIRE(ps && frame && A && trans && v && J, "lbs_jet_forward: NULL pointer");
+  const int lds = (int)(B * kJ * 12 * sizeof(float));
+  hipLaunchKernelGGL(lbs_jet_forward_kernel, dim3(stream_grid(P, kBlk)), dim3(kBlk), lds, (hipStream_t)stream, ps, frame,
+                     A, trans, (int)B, grid->volume, to_geom(grid), P, v, J);
+  return check_launch("lbs_jet_forward");
+}
+
+// g_p [P,3] and the staged parameter side: W4 [4P,24], Q4 [4P, B*12], Gs [P, B*3]; the caller runs
+// recmv_gemm_tn(W4, Q4) -> gA[j, b*12 + 4i + k] and recmv_colsum(Gs) -> gtrans[b*3 + i].  gv or gJ may be NULL (zeros).
+extern "C" int recmv_lbs_jet_backward_stage(const float* ps, const int64_t* frame, int64_t P, const float* A, int64_t B,
+                                            const recmv_lbs_grid* grid, const float* gv, const float* gJ, float* g_p,
+                                            float* W4, float* Q4, float* Gs, void* stream) {
+  RECMV_REQUIRE(P >= 0 && B >= 1 && B <= 128, "lbs_jet_backward_stage: bad size (P=%lld, B=%lld)", (long long)P,
+                (long long)B);
+  if (P == 0) return RECMV_OK;
+  int rc = check_geom(grid);
+  if (rc) return rc;
+  RECMV_REQUIRE(ps && frame && A && g_p && W4 && Q4 && Gs, "lbs_jet_backward_stage: NULL pointer");
+  const int lds = (int)(B * kJ * 12 * sizeof(float));
+  hipLaunchKernelGGL(lbs_jet_backward_kernel, dim3(stream_grid(P, kBlk)), dim3(kBlk), lds, (hipStream_t)stream, ps,
+                     frame, A, (int)B, grid->volume, to_geom(grid), P, gv, gJ, g_p, W4, Q4, Gs);
+  return check_launch("lbs_jet_backward_stage");
 }
 
 extern "C" int recmv_rootfind_step(float* p, const float* f, const float* gf, const float* loss2, const float* angle,

@@ -16,7 +16,7 @@ _PKG = Path(__file__).resolve().parent.parent          # rec-mv_amd/
 LIB_PATH = Path(os.environ["RECMV_LIB_PATH"]) if os.environ.get("RECMV_LIB_PATH") else _PKG / "lib" / "librecmv_hip.so"   # (override: A/B builds of tools/)
 
 RECMV_OK = 0
-ABI_VERSION = 8          # include/recmv_hip.h; bumped when a signature changes (v8: recmv_cam_* added; v7: recmv_get_sampler_mode, recmv_set_jet_fill added; v5: second weight set + split_row in recmv_mlp; v6: recmv_def_regu, recmv_b3_*, recmv_mlp_rows_*, recmv_mc_run_batch added)
+ABI_VERSION = 9          # include/recmv_hip.h; bumped when a signature changes (v9: recmv_lbs_jet_* added; v8: recmv_cam_* added; v7: recmv_get_sampler_mode, recmv_set_jet_fill added; v5: second weight set + split_row in recmv_mlp; v6: recmv_def_regu, recmv_b3_*, recmv_mlp_rows_*, recmv_mc_run_batch added)
 F32, F64 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = 0, 1, 2, 3
 
@@ -154,6 +154,8 @@ def _declare(lib):
         "recmv_lbs_forward": (C.c_int, [vp, vp, i64, vp, vp, i64, C.POINTER(LbsGrid), vp, vp, vp, vp, vp, vp, vp]),
         "recmv_lbs_vjp_input": (C.c_int, [vp, vp, i64, vp, i64, C.POINTER(LbsGrid), vp, vp, vp]),
         "recmv_lbs_vjp_params_stage": (C.c_int, [vp, vp, i64, i64, C.POINTER(LbsGrid), vp, vp, vp, vp, vp]),
+        "recmv_lbs_jet_forward": (C.c_int, [vp, vp, i64, vp, vp, i64, C.POINTER(LbsGrid), vp, vp, vp]),
+        "recmv_lbs_jet_backward_stage": (C.c_int, [vp, vp, i64, vp, i64, C.POINTER(LbsGrid), vp, vp, vp, vp, vp, vp, vp]),
         "recmv_rootfind_update": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
         "recmv_rootfind_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]),
         "recmv_rasterize_meshes_workspace_bytes": (i64, [i64, i64, i64, i64]),

@@ -397,6 +397,64 @@ def lbs_vjp_params(ps, frame, A_shape, grid, g_d):
     return gA, gt.view(B, 3)
 
 
+class LbsJet(torch.autograd.Function):
+    """(v [P,3], J [P,3,3]) = the skinning stage and its Jacobian d v / d p at `ps` in ONE launch (recmv_lbs_jet_forward) instead of
+    the sampler -> blend -> transform composition plus three create_graph autograd.grad calls through it (utils/utils.py:133-156 of
+    the reference).  backward: one launch for the per-point part (recmv_lbs_jet_backward_stage: the gradient wrt ps, with the mixed
+    second derivatives of the trilinear weights) + the two fixed-order reductions of the parameter side (gA, gtrans).
+    Differentiable ONCE: the loss needs first-order gradients of (v, J) only."""
+
+    @staticmethod
+    def forward(ctx, ps, A, trans, frame, grid):
+        psd = ps.detach().contiguous()
+        Ad = A.detach().contiguous()
+        td = trans.detach().contiguous()
+        P, B = psd.shape[0], Ad.shape[0]
+        dev = psd.device
+        v = L.scratch((P, 3), torch.float32, dev)
+        J = L.scratch((P, 3, 3), torch.float32, dev)
+        with L.device_guard(dev):
+            L.check(L.lib().recmv_lbs_jet_forward(L.ptr(psd), L.ptr(frame), P, L.ptr(Ad), L.ptr(td), B, C.byref(grid), L.ptr(v),
+                                                  L.ptr(J), L.stream_ptr(dev)), "lbs_jet_forward")
+        ctx.save_for_backward(psd, Ad)
+        ctx.frame, ctx.grid, ctx.A_shape = frame, grid, tuple(A.shape)
+        ctx.set_materialize_grads(False)
+        return v, J
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gv, gJ):
+        from . import ops
+        psd, Ad = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        if gv is None and gJ is None:
+            return None, None, None, None, None
+        P, B = psd.shape[0], Ad.shape[0]
+        dev = psd.device
+        gv = gv.contiguous() if gv is not None else None
+        gJ = gJ.contiguous() if gJ is not None else None
+        g_p = L.scratch((P, 3), torch.float32, dev)
+        W4 = L.scratch((4 * P, 24), torch.float32, dev)
+        Q4 = L.scratch((4 * P, B * 12), torch.float32, dev)
+        Gs = L.scratch((P, B * 3), torch.float32, dev)
+        lib = L.lib()
+        gA = gt = None
+        with L.device_guard(dev):
+            L.check(lib.recmv_lbs_jet_backward_stage(L.ptr(psd), L.ptr(ctx.frame), P, L.ptr(Ad), B, C.byref(ctx.grid), L.ptr(gv),
+                                                     L.ptr(gJ), L.ptr(g_p), L.ptr(W4), L.ptr(Q4), L.ptr(Gs), L.stream_ptr(dev)),
+                    "lbs_jet_backward_stage")
+            if need[1] and P > 0:
+                gAm = ops.gemm_tn(W4, Q4)                                          # [24, B*12]
+                gA = torch.zeros(ctx.A_shape, dtype=torch.float32, device=dev)
+                gA[:, :, :3, :] = gAm.view(24, B, 3, 4).permute(1, 0, 2, 3)
+            if need[2] and P > 0 and gv is not None:
+                ws = L.scratch(max(int(lib.recmv_colsum_workspace_bytes(P, B * 3)), 256), torch.uint8, dev)
+                gt = L.scratch(B * 3, torch.float32, dev)
+                L.check(lib.recmv_colsum(L.ptr(Gs), B * 3, P, B * 3, L.ptr(gt), L.ptr(ws), ws.numel(), L.stream_ptr(dev)), "colsum")
+                gt = gt.view(B, 3)
+        return (g_p if need[0] else None), gA, gt, None, None
+
+
 class LbsFused(torch.autograd.Function):
     """d = (sum_j w_j(p) A[frame,j]) [p;1] + trans[frame] in one kernel; backward = the input VJP kernel plus the staged
     parameter VJP.  When a graph is being built in backward (create_graph=True — the Jacobian terms of the loss), it

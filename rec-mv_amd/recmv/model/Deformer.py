@@ -12,6 +12,8 @@ channels-last copy of the weight volume (one 96-byte record per corner instead o
 and the per-point 24->16 blend is an MFMA product against all frames at once followed by a gather, which
 removes the reference's per-batch-id Python loop with its `.any().item()` host syncs (:438-443).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -513,14 +515,24 @@ class LBSkinner(nn.Module):
             binds = batch_inds
         fused = (tps is ps and flat.is_cuda and flat.dtype == torch.float32 and not kwargs.get('jet', False)
                  and torch.is_grad_enabled() and A.shape[1:] == (24, 4, 4))
+        jet = (kwargs.get('jet', False) and tps is ps and flat.is_cuda and flat.dtype == torch.float32 and torch.is_grad_enabled()
+               and A.shape[1:] == (24, 4, 4) and not self.ws.requires_grad and os.environ.get('RECMV_LBS_JET', '1') != '0')
+        J = None
         if fused:
             # first-order path: one kernel forward, fused VJP kernels backward (csrc/lbs_fused.hip)
             from ..chains import LbsFused
             v = LbsFused.apply(flat, A, trans, binds.contiguous(), self._lbs_grid(), self._blend_classic)
+        elif jet:
+            # value + Jacobian d v / d ps in one kernel, once-differentiable (csrc/lbs_fused.hip: lbs_jet_*): utils.compute_Jacobian(ps,
+            # v) finds it on the output instead of differentiating the composition below three times with create_graph
+            from ..chains import LbsJet
+            v, J = LbsJet.apply(flat, A, trans, binds.contiguous(), self._lbs_grid())
         else:
             v = self._blend_classic(flat, A, trans, binds, tps=tps)
         if batch_inds is None:
-            return v.view(batch_size, pnum, 3)
+            v = v.view(batch_size, pnum, 3)
+        if J is not None:
+            v._recmv_jac = (ps, J)
         return v
 
     def _blend_classic(self, flat, A, trans, binds, tps=None):

@@ -558,6 +558,77 @@ def test_translator_and_composite_jet_jacobian(nets):
         close(a, b, rtol=2e-3, atol=2e-6 + 1e-3 * float(b.abs().max()))
 
 
+class _env:
+    """Set environment variables for a block (the switches below are read at call time)."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_lbs_jet_equals_the_classic_composition_differentiated_by_autograd(nets):
+    """LBSkinner.forward(..., jet=True) (csrc/lbs_fused.hip lbs_jet_*: value + Jacobian in one launch, once-differentiable reverse with
+    the mixed second derivatives of the trilinear weights) against what it replaces — sampler -> blend -> transform as differentiable
+    ops, the Jacobian by three create_graph autograd.grad calls (utils/utils.py:133-156), the loss's backward through the double-
+    backward graph: same v, same J, same gradients of a loss in (v, J) wrt points, poses and translations.  Points inside the skinning
+    volume and well outside it (clipped coordinates: zero weight derivatives)."""
+    from recmv.utils import utils as U
+    gl = load("lbs")
+    sk = nets["sk"]
+    g = torch.Generator().manual_seed(23)
+    for scale, n in ((0.4, 900), (1.6, 700)):
+        binds = torch.randint(0, 3, (n,), generator=g).to(DEV)
+        q0 = (torch.randn(n, 3, generator=g) * scale).to(DEV)
+        wv = torch.randn(n, 3, generator=g).to(DEV)
+        wj = torch.randn(n, 3, 3, generator=g).to(DEV)
+
+        def run(classic):
+            poses = gl["poses"].to(DEV).clone().requires_grad_(True)
+            trans = gl["trans"].to(DEV).clone().requires_grad_(True)
+            p = q0.clone().requires_grad_(True)
+            with _env(RECMV_LBS_JET="0" if classic else "1"):
+                d = sk(p, [poses, trans], binds, jet=True)
+                assert (getattr(d, "_recmv_jac", None) is None) == classic
+                J = U.compute_Jacobian(p, d, True, True)
+            loss = (d * wv).sum() / n + (J * wj).sum() / n + (J.pow(2).sum() + d.pow(2).sum()) / n
+            return d, J, _grads(loss, [p, poses, trans])
+
+        d1, J1, g1 = run(False)
+        d0, J0, g0 = run(True)
+        close(d1, d0, rtol=1e-5, atol=2e-6)
+        close(J1, J0, rtol=1e-4, atol=2e-5)
+        assert float((J0 - torch.eye(3, device=DEV)).abs().max()) > 0.05           # (a Jacobian worth the name)
+        for a, b in zip(g1, g0):
+            close(a, b, rtol=1e-3, atol=2e-6 + 2e-4 * float(b.abs().max()))
+    # the [B, n, 3] form (frame-major blocks, no frame ids)
+    p0 = (torch.randn(3, 200, 3, generator=g) * 0.4).to(DEV)
+
+    def run3(classic):
+        poses = gl["poses"].to(DEV).clone().requires_grad_(True)
+        p = p0.clone().requires_grad_(True)
+        with _env(RECMV_LBS_JET="0" if classic else "1"):
+            d = sk(p, [poses, gl["trans"].to(DEV)], jet=True)
+            J = U.compute_Jacobian(p, d, True, True)
+        return d, J, _grads(J.pow(2).sum() + d.sum(), [p, poses])
+
+    d1, J1, g1 = run3(False)
+    d0, J0, g0 = run3(True)
+    close(d1, d0, rtol=1e-5, atol=2e-6)
+    close(J1.reshape(-1, 3, 3), J0.reshape(-1, 3, 3), rtol=1e-4, atol=2e-5)
+    for a, b in zip(g1, g0):
+        close(a, b, rtol=1e-3, atol=2e-6 + 2e-4 * float(b.abs().max()))
+
+
 def test_lbs_fused_first_order_equals_classic(nets):
     """LBSkinner.forward's fused first-order path (csrc/lbs_fused.hip: one forward kernel, input-VJP kernel, staged
     parameter VJP) gives the same output and the same gradients wrt points, poses and translations as the
@@ -572,7 +643,8 @@ def test_lbs_fused_first_order_equals_classic(nets):
         poses = gl["poses"].to(DEV).clone().requires_grad_(True)
         trans = gl["trans"].to(DEV).clone().requires_grad_(True)
         p = p0.clone().requires_grad_(True)
-        d = sk(p, [poses, trans], jet=jet)          # jet=True selects the classic composition
+        with _env(RECMV_LBS_JET="0"):               # jet=True + RECMV_LBS_JET=0 selects the classic composition
+            d = sk(p, [poses, trans], jet=jet)
         loss = (d * wd).sum() / 500 + d.pow(2).mean()
         return d, _grads(loss, [p, poses, trans])
 
@@ -589,7 +661,8 @@ def test_lbs_fused_first_order_equals_classic(nets):
         poses = gl["poses"].to(DEV).clone().requires_grad_(True)
         trans = gl["trans"].to(DEV).clone().requires_grad_(True)
         p = q0.clone().requires_grad_(True)
-        d = sk(p, [poses, trans], binds, jet=jet)
+        with _env(RECMV_LBS_JET="0"):
+            d = sk(p, [poses, trans], binds, jet=jet)
         return d, _grads(d.pow(2).sum(), [p, poses, trans])
 
     e1, h1 = run2(False)

@@ -794,6 +794,10 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                      else args.scene, first_iteration=it,
                      vertices_at_load=[int(v.shape[0]) for v in loop.garment_vs])
         log("frozen scene loaded: %s, MC vertices %s" % (scene["file"], [int(v.shape[0]) for v in loop.garment_vs]))
+    t_res = time.perf_counter()
+    reserved = loop.reserve_memory() if on_gpu and os.environ.get("RECMV_SHARE_GPU0") != "1" else 0      # (train.py does the same)
+    sync()
+    reserve_ms = (time.perf_counter() - t_res) * 1e3          # = the host's price of a few hipMalloc calls on this box right now
     torch.manual_seed(20261001 + rank)       # the draws of the warm-up and the timed region: one fixed sequence per rank
     for _ in range(args.settle_iters):
         loop.step(it, allreduce)
@@ -1054,7 +1058,9 @@ def main(argv=None, device_type="cuda", hotloop_kw=None, conf_overrides=None):
                                        "in_the_step_after": [dev_allocs[k + 1] for k in remesh_steps if k + 1 < len(dev_allocs)],
                                        "in_all_other_steps": sum(a for k, a in enumerate(dev_allocs)
                                                                  if k not in remesh_steps and (k - 1) not in remesh_steps),
-                                       "note": "hipMalloc calls of torch's caching allocator (memory_stats num_device_alloc)"},
+                                       "reserved_bytes_parked_per_process": int(reserved), "reserve_ms": round(reserve_ms, 2),
+                                       "note": "hipMalloc calls of torch's caching allocator (memory_stats num_device_alloc); "
+                                               "HotLoop.reserve_memory parks one large free block per stream at start"},
                 "note": "GPU time between HIP events recorded at the step boundaries (rank 0); `value` has %d re-mesh(es) "
                         "in %d steps, the reference's cadence is 1 in %d" % (len(with_r), args.steps, period)}
         log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))

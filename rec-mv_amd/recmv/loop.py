@@ -564,6 +564,33 @@ class HotLoop:
                                 balance_value) for v in vols]
         return [r[0] for r in res], [r[1] for r in res]
 
+    def reserve_memory(self, megabytes=None):
+        """Park one large free block per stream of the loop in torch's caching allocator (allocate, release: the block stays cached and
+        later requests are split off it).  A re-mesh re-sizes every vertex-sized buffer; whatever does not fit a cached block goes to
+        hipMalloc in the middle of that step — 3-4 calls, and on a host that is busy (a box in its first minutes) they were +30 ms on
+        the re-mesh step (profiles/r06_remesh_first_process.txt).  `megabytes`: per stream in the order main, ray, curve, second garment
+        (default RECMV_RESERVE_MB or 6144,3072,1024,3072 — a few percent of the 288 GB); 0 entries are skipped.  Call once, after the
+        first mesh exists; returns the bytes parked."""
+        if torch.device(self.device).type != 'cuda':
+            return 0
+        if megabytes is None:
+            megabytes = [int(v) for v in os.environ.get('RECMV_RESERVE_MB', '6144,3072,1024,3072').split(',') if v.strip()]
+        if getattr(self, '_surface_stream', None) is None:
+            self._surface_stream = _make_stream(self.device)
+        if getattr(self, '_curve_stream', None) is None:
+            self._curve_stream = _make_stream(self.device)
+        from .utils.FindSurfacePs import _streams
+        streams = [torch.cuda.current_stream(self.device), self._surface_stream, self._curve_stream]
+        streams += _streams(torch.device(self.device), max(self.garment_size - 1, 0))
+        total = 0
+        for st, mb in zip(streams, megabytes):
+            if mb > 0:
+                with torch.cuda.stream(st):
+                    block = torch.empty(mb << 20, dtype=torch.uint8, device=self.device)
+                total += block.numel()
+                del block
+        return total
+
     def marching_cube_update(self, ratio):
         """OptimGarmentNetwork.py:678-740 (openmesh vertex->face tables are never read by the loop: dropped)."""
         trace = getattr(self, 'remesh_trace', None)

@@ -328,6 +328,7 @@ def main(argv=None, large_pose=False):
 
     nepochs = config.get_int('train.nepoch') + (1 if large_pose else 0)                  # train_large_pose.py:289
     done = 0
+    optNet.reserve_memory()              # one large cached block per stream: a re-mesh's re-sized buffers never reach hipMalloc
     for epoch in range(start_epoch, nepochs):
         new_stage = stage_of_epoch(config, epoch)
         if new_stage != stage:
@@ -338,6 +339,7 @@ def main(argv=None, large_pose=False):
             optNet.isfine = new_stage == 'fine'                  # train.py:312
             stage = new_stage
             torch.cuda.empty_cache()
+            optNet.reserve_memory()
             print('enable %s hierarchical' % stage)
         for data_index, (frame_ids, outs) in enumerate(dataloader.set_epoch(epoch)):
             t0 = time.perf_counter()

@@ -255,6 +255,26 @@ def test_schedule_switches_leave_the_iteration_unchanged(switch, monkeypatch):
             assert torch.allclose(a, b, rtol=0, atol=2e-5 * (float(a.abs().max()) + 1e-6) + 1e-7)
 
 
+def test_reserved_memory_serves_later_allocations_without_hipmalloc():
+    """HotLoop.reserve_memory parks one free block per stream of the loop in torch's caching allocator: afterwards a buffer that fits
+    none of the cached blocks of its stream is split off the parked one — no device allocation (what a re-mesh's re-sized activation
+    buffers need)."""
+    loop = _loop()
+    dev = loop.device
+    n_alloc = lambda: int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))          # noqa: E731
+    a0 = n_alloc()
+    parked = loop.reserve_memory([192, 96, 0, 96])
+    assert parked == (192 + 96 + 96) << 20 and 1 <= n_alloc() - a0 <= 3
+    a1 = n_alloc()
+    keep = []
+    for st in (torch.cuda.current_stream(dev), loop._surface_stream):
+        with torch.cuda.stream(st):
+            keep.append(torch.empty(37 << 20, dtype=torch.uint8, device=dev))                # a size nothing cached has
+            keep.append(torch.empty(23 << 20, dtype=torch.uint8, device=dev))
+    assert n_alloc() == a1
+    assert loop.reserve_memory([0, 0, 0, 0]) == 0
+
+
 def test_remesh_reuses_the_extraction_of_a_net_that_has_not_moved(monkeypatch):
     """discretizeSDF keeps a net's (vertices, faces) while its parameters are unchanged (the body net throughout the optimisation
     stage; every net in the large-pose stage): the cached result equals a fresh extraction bit for bit, a net that moved is extracted

@@ -18,6 +18,8 @@ conf = ConfigFactory.parse_file(str(REPO / "configs" / "synthetic" / "people_sna
 loop = HotLoop(conf, dev, stage="coarse", curves=True, **bench.HOTLOOP_KW)
 it = bench.load_scene(loop, bench.SCENE_FILE)
 ratio = {'sdfRatio': 1., 'deformerRatio': loop.opt_times / 2500. + 0.5, 'renderRatio': 1.}
+# (round 6: a net whose parameters have not moved is not extracted again — HotLoop.discretizeSDF's cache — so the split below is the
+# garments' two pyramids; RECMV_REMESH_CACHE=0 gives all three)
 FLOP_PER_POINT = 2 * 1966592 - 2 * 256 * 512          # SDF value only: the last layer's 256 feature rows are skipped
 
 
@@ -33,6 +35,10 @@ def run(tag):
         for rep in range(3):
             sizes.clear()
             loop.remesh_trace = []
+            # the loop's case: the garment nets have moved since the last re-mesh, the body net has not (its entry stays cached)
+            for i in list(getattr(loop, '_remesh_cache', {})):
+                if i > 0:
+                    del loop._remesh_cache[i]
             torch.cuda.synchronize()
             loop.marching_cube_update(ratio)
             torch.cuda.synchronize()

@@ -262,6 +262,8 @@ def test_reserved_memory_serves_later_allocations_without_hipmalloc():
     loop = _loop()
     dev = loop.device
     n_alloc = lambda: int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))          # noqa: E731
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                     # (what earlier tests of this process left cached would serve the reservation itself)
     a0 = n_alloc()
     parked = loop.reserve_memory([192, 96, 0, 96])
     assert parked == (192 + 96 + 96) << 20 and 1 <= n_alloc() - a0 <= 3
